@@ -1,0 +1,200 @@
+/*
+ * rt_abi.h — C ABI of the MI355X path-tracer hot path.
+ *
+ * The reference (dps/rust-raytracer) has NO FFI of its own: the seam this
+ * header defines is cut at the rayon closure in
+ *   raytracer/src/raytracer.rs:260-262   bands.into_par_iter().for_each(render_line)
+ * Inputs of that closure are the immutable `Config` (raytracer/src/config.rs:66-75)
+ * and the light list (`find_lights`, raytracer.rs:220-229); its output is the
+ * `pixels: Vec<u8>` framebuffer (raytracer.rs:254), row-major, top row first, RGB8.
+ * Everything in this file is plain C: pointers, sizes, POD structs.  No torch /
+ * HIP types appear in signatures (streams and device pointers travel as void*).
+ *
+ * Three shared libraries implement parts of it:
+ *   librt_host.so  (C++, product)   scene JSON/JPEG/PNG/camera — the host plumbing
+ *                                   that stays on the CPU (main.rs, config.rs, camera.rs)
+ *   librt_hip.so   (HIP,  product)  the gfx950 megakernel = render_line/ray_color/hit_world
+ *   oracle/librt_oracle.so (C, TEST INFRASTRUCTURE ONLY) the CPU restatement
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1u
+
+/* Nested light-ray recursion (raytracer.rs:103-110 calls ray_color(.., 2, 1), which can
+ * itself trigger light sampling again) is unbounded in the reference.  Oracle and kernel
+ * both stop spawning new light rays below this nesting level (level 0 = camera path). */
+#define RT_MAX_LIGHT_NEST 8u
+
+/* ---- error codes (the reference panics; a C ABI returns codes instead) ---- */
+enum {
+  RT_OK = 0,
+  RT_ERR_INVALID = -1,   /* null pointer / inconsistent scene                      */
+  RT_ERR_NO_DEVICE = -2, /* no gfx950 device visible                               */
+  RT_ERR_HIP = -3,       /* a HIP runtime call failed (see rt_hip_last_error)      */
+  RT_ERR_IO = -4,        /* main.rs:14 "Unable to read config file."               */
+  RT_ERR_PARSE = -5,     /* main.rs:15 "Unable to parse config json"               */
+  RT_ERR_TEXTURE = -6,   /* materials.rs:214-217 / config.rs:37-40 texture failure */
+  RT_ERR_PNG = -7,       /* raytracer.rs:265 "error writing image"                 */
+  RT_ERR_UNSUPPORTED = -8
+};
+
+/* materials.rs:35-42  enum Material, in declaration order */
+enum {
+  RT_MAT_LAMBERTIAN = 0,
+  RT_MAT_METAL = 1,
+  RT_MAT_GLASS = 2,
+  RT_MAT_TEXTURE = 3,
+  RT_MAT_LIGHT = 4
+};
+
+/* config.rs:22-28, 49-64: sky null -> black; {"texture":""} -> gradient; path -> texture */
+enum { RT_SKY_NONE = 0, RT_SKY_GRADIENT = 1, RT_SKY_TEXTURE = 2 };
+
+/* sphere.rs:18-23 + the material payloads (materials.rs:71-76, 97-103, 131-134, 201-211).
+ * Spheres are kept in JSON object order: closest-hit ties (raytracer.rs:52-57) and the
+ * light order (raytracer.rs:220-229) follow it. */
+typedef struct RtSphere {
+  double center[3];
+  double radius;      /* may be negative: hollow glass, test_scene.json:137 */
+  double fuzz_or_ior; /* Metal.fuzz | Glass.index_of_refraction             */
+  double h_offset;    /* Texture.h_offset                                   */
+  uint64_t tex_w;     /* Texture.width / height AS WRITTEN IN THE JSON      */
+  uint64_t tex_h;     /*   (materials.rs:206-210), not the decoded size     */
+  float albedo[3];    /* Lambertian/Metal albedo; ignored for Texture       */
+  uint32_t kind;      /* RT_MAT_*                                           */
+  uint32_t tex_id;    /* index into RtScene.textures when kind==TEXTURE     */
+  uint32_t reserved;
+} RtSphere;
+
+/* decoded texture pixels, RGB8 (materials.rs:213-219) */
+typedef struct RtTexture {
+  const uint8_t* rgb8;
+  uint64_t nbytes;
+  uint32_t width, height; /* decoded size, informational */
+} RtTexture;
+
+/* config.rs:66-75 Config, with the camera already derived (camera.rs:45-77). */
+typedef struct RtScene {
+  uint32_t abi_version; /* RT_ABI_VERSION */
+  uint32_t width, height;
+  uint32_t samples_per_pixel;
+  uint32_t max_depth;
+  uint32_t sky_mode; /* RT_SKY_* */
+  double cam_origin[3];
+  double cam_lower_left[3];
+  double cam_horizontal[3];
+  double cam_vertical[3];
+  const uint8_t* sky_rgb8; /* sky_mode==TEXTURE */
+  uint64_t sky_w, sky_h;
+  const RtSphere* spheres;
+  uint32_t n_spheres;
+  uint32_t n_textures;
+  const RtTexture* textures;
+  uint64_t seed; /* Philox key; replaces rand::thread_rng (raytracer.rs:78,192) */
+} RtScene;
+
+/* Which scanline tiles to render.  Tile k covers rows [k*tile_rows, (k+1)*tile_rows).
+ * This call renders tiles first_tile, first_tile+tile_stride, ... and packs them back to
+ * back in the output (local tile j <-> global tile first_tile + j*tile_stride).
+ * NULL, or tile_rows==0, means the whole frame.  Rank r of G GPUs uses {T, r, G}. */
+typedef struct RtRowTiles {
+  uint32_t tile_rows;
+  uint32_t first_tile;
+  uint32_t tile_stride;
+} RtRowTiles;
+
+typedef struct RtStats {
+  uint64_t samples;      /* camera paths traced = pixels * spp                              */
+  uint64_t segments;     /* ray_color invocations that ran hit_world (raytracer.rs:83)      */
+  uint64_t sphere_tests; /* ALGORITHMIC ray-sphere tests = segments * n_spheres             */
+  uint64_t exact_tests;  /* f64 Sphere::hit evaluations actually executed (after culling)   */
+  uint64_t tex_oob;      /* texture fetches the reference would have panicked on            */
+  double kernel_ms;      /* device time of the render kernel(s)                             */
+  double frame_ms;       /* wall time of the whole call                                     */
+} RtStats;
+
+/* rows this call renders (its packed RGB8 output is rows*width*3 bytes) */
+static inline uint32_t rt_tiles_local_rows(uint32_t height, const RtRowTiles* tiles) {
+  if (!tiles || tiles->tile_rows == 0 || tiles->tile_stride == 0) return height;
+  uint32_t rows = 0;
+  uint64_t n_tiles = ((uint64_t)height + tiles->tile_rows - 1) / tiles->tile_rows;
+  for (uint64_t k = tiles->first_tile; k < n_tiles; k += tiles->tile_stride) {
+    uint64_t r0 = k * tiles->tile_rows, r1 = r0 + tiles->tile_rows;
+    if (r1 > height) r1 = height;
+    rows += (uint32_t)(r1 - r0);
+  }
+  return rows;
+}
+/* global row of local packed row `lr` (inverse of the packing above) */
+static inline uint32_t rt_tiles_global_row(const RtRowTiles* tiles, uint32_t lr) {
+  if (!tiles || tiles->tile_rows == 0 || tiles->tile_stride == 0) return lr;
+  uint32_t j = lr / tiles->tile_rows, r = lr % tiles->tile_rows;
+  return (tiles->first_tile + j * tiles->tile_stride) * tiles->tile_rows + r;
+}
+
+/* ------------------------------------------------------------------------------------
+ * librt_host.so — host plumbing (stays on the CPU, like main.rs/config.rs/camera.rs)
+ * ---------------------------------------------------------------------------------- */
+typedef struct RtSceneFile RtSceneFile; /* owns the RtScene and every buffer it points to */
+
+/* main.rs:14-15: read + parse a scene file; texture paths resolve relative to cwd. */
+int rt_scene_load_file(const char* json_path, RtSceneFile** out);
+int rt_scene_load_string(const char* json_text, size_t len, RtSceneFile** out);
+const RtScene* rt_scene_get(const RtSceneFile*);
+RtScene* rt_scene_get_mut(RtSceneFile*); /* tests override width/height like raytracer.rs:272-273 */
+void rt_scene_free(RtSceneFile*);
+/* serde_json::to_string(&config) — exact strings of config.rs:101,128 */
+int rt_scene_to_json(const RtSceneFile*, char* buf, size_t cap, size_t* needed);
+const char* rt_host_last_error(void);
+
+/* camera.rs:45-77 Camera::new: out = origin[3], lower_left[3], horizontal[3], vertical[3], focal_length */
+void rt_camera_derive(const double look_from[3], const double look_at[3], const double vup[3],
+                      double vfov_deg, double aspect, double out[13]);
+/* raytracer.rs:220-229 find_lights: writes indices of Light spheres in object order */
+uint32_t rt_find_lights(const RtSphere* spheres, uint32_t n, uint32_t* out_idx, uint32_t cap);
+/* materials.rs:213-219 load_texture_image: baseline JPEG -> RGB8 (malloc'd, free with rt_free) */
+int rt_jpeg_decode_file(const char* path, uint8_t** rgb8, uint32_t* w, uint32_t* h);
+int rt_jpeg_decode_mem(const uint8_t* data, size_t len, uint8_t** rgb8, uint32_t* w, uint32_t* h);
+/* raytracer.rs:33-42 write_image: PNG, ColorType::RGB(8) */
+int rt_png_write_rgb8(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h);
+void rt_free(void*);
+
+/* ------------------------------------------------------------------------------------
+ * librt_hip.so — the hot path on gfx950 (replaces raytracer.rs:260-262)
+ * ---------------------------------------------------------------------------------- */
+typedef struct RtHipScene RtHipScene; /* scene tables + textures resident in HBM on one GPU */
+
+int rt_hip_device_count(void);
+const char* rt_hip_last_error(void);
+/* Upload scene tables, textures and sky to HBM of `device`.  The caller may free the
+ * RtScene and everything it points to as soon as this returns. */
+int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene** out);
+void rt_hip_scene_destroy(RtHipScene*);
+/* Launch the megakernel for the given row tiles on `stream` (a hipStream_t, NULL = default).
+ *   d_rgb8    device buffer, rt_tiles_local_rows()*width*3 bytes, packed, top row first
+ *   d_linear  optional device buffer of 3 floats per pixel: mean radiance before the
+ *             sqrt gamma (raytracer.rs:207-212) — what the parity tests compare
+ * Asynchronous: returns after enqueueing.  Inputs are already in HBM. */
+int rt_hip_render(RtHipScene*, const RtRowTiles* tiles, void* d_rgb8, void* d_linear, void* stream);
+/* Block until the last rt_hip_render on this scene finished; fill counters and the HIP-event
+ * duration of its kernel (events are recorded on the stream the kernel was launched on). */
+int rt_hip_wait(RtHipScene*, RtStats* stats);
+/* variant selection for A/B benchmarking (0 = default); see DESIGN.md */
+int rt_hip_set_option(RtHipScene*, const char* key, int64_t value);
+/* Convenience = the drop-in for render()'s parallel loop: host buffers in, host RGB8 out.
+ * Blocking; uploads, renders the whole frame on device 0, downloads. */
+int rt_render_rgb8(const RtScene* scene, uint8_t* out_rgb8, RtStats* stats);
+const char* rt_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

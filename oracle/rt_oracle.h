@@ -1,0 +1,77 @@
+/*
+ * rt_oracle.h — CPU oracle of the ray_color hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (librt_hip.so, librt_host.so, the
+ * `raytracer` CLI, the python package) may link, load or call this library.  Its only users
+ * are tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg.
+ *
+ * It restates, in plain C with f64 geometry / f32 colour and NO fused multiply-adds
+ * (-ffp-contract=off, like rustc), the reference functions
+ *   raytracer/src/raytracer.rs:44-59  hit_world      :61-69  clamp      :71-165 ray_color
+ *   raytracer/src/raytracer.rs:191-218 render_line   :220-229 find_lights :250-266 render
+ *   raytracer/src/sphere.rs:35-79     u_v_from_sphere_hit_point, Sphere::hit
+ *   raytracer/src/materials.rs:44-54, 65-69, 84-95, 111-129, 144-155, 176-199, 236-267
+ *   raytracer/src/camera.rs:45-84     Camera::new, get_ray
+ *   raytracer/src/point3d.rs:22-38, 52-177
+ * with one substitution: rand::thread_rng() (OS-seeded ChaCha, unreproducible) is replaced
+ * by counter-based Philox4x32-10 addressed by (pixel, sample, path node, slot); see
+ * DESIGN.md "RNG addressing".
+ *
+ * Parity pinning: the reference cannot be built here (no cargo/rustc), it holds no golden
+ * images and its RNG is unseeded, so IMAGE parity against the Rust binary is unpinned by
+ * construction.  What IS pinned: every known-answer unit test the reference holds for this
+ * path is replayed against the functions below in tests/test_oracle_kat.py,
+ * and the Philox core is pinned by the Random123 known-answer vectors.
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+
+#include "../include/rt_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* render() minus PNG: raytracer.rs:250-263.  rgb8 and linear are host buffers of
+ * rt_tiles_local_rows()*width*3 bytes / floats (either may be NULL).  n_threads<=0 -> all
+ * cores (one scanline per task, dynamic schedule = rayon's work stealing). */
+int rt_oracle_render(const RtScene* scene, const RtRowTiles* tiles, uint8_t* rgb8, float* linear,
+                     RtStats* stats, int n_threads);
+int rt_oracle_threads(void);
+
+/* ---- hooks for the reference's known-answer tests ---- */
+/* Philox4x32-10, Random123 layout */
+void rt_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* sphere.rs:46-78; returns 1 on hit. out = t, p[3], normal[3], front_face, u, v (10 doubles) */
+int rt_oracle_sphere_hit(const double center[3], double radius, const double origin[3],
+                         const double dir[3], double t_min, double t_max, double out[10]);
+/* materials.rs:144-149 */
+void rt_oracle_refract(const double uv[3], const double n[3], double etai_over_etat, double out[3]);
+/* materials.rs:151-155 */
+double rt_oracle_reflectance(double cosine, double ref_idx);
+/* materials.rs:111-113 */
+void rt_oracle_reflect(const double v[3], const double n[3], double out[3]);
+/* camera.rs:45-77; out = origin, lower_left, horizontal, vertical, focal_length (13 doubles) */
+void rt_oracle_camera_new(const double look_from[3], const double look_at[3], const double vup[3],
+                          double vfov_deg, double aspect, double out[13]);
+/* camera.rs:79-84; out = origin[3], direction[3] */
+void rt_oracle_get_ray(const RtScene* scene, double u, double v, double out[6]);
+/* raytracer.rs:71-165 for one explicit ray at (pixel,sample) RNG address; root call */
+void rt_oracle_ray_color(const RtScene* scene, const double origin[3], const double dir[3],
+                         uint32_t max_depth, uint32_t depth, uint32_t pixel, uint32_t sample,
+                         float out_rgb[3]);
+/* materials.rs:236-254 Texture::get_albedo */
+void rt_oracle_texture_albedo(const RtSphere* s, const RtTexture* tex, double u, double v,
+                              float out_rgb[3]);
+/* raytracer.rs:213: palette f32 -> u8 */
+uint8_t rt_oracle_f32_to_u8(float x);
+/* raytracer.rs:220-229 */
+uint32_t rt_oracle_find_lights(const RtSphere* spheres, uint32_t n, uint32_t* out_idx, uint32_t cap);
+/* the two RNG draw flavours: (53-bit gen::<f64>(), gen_range(-1..1) grid) for a counter */
+void rt_oracle_draws(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t node, uint32_t slot,
+                     double out_u01[2], double out_range[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

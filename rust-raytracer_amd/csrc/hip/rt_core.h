@@ -1,0 +1,549 @@
+// rt_core.h — per-lane path-tracing logic of the gfx950 megakernel.
+//
+// Everything here is a per-lane function: the wave-level orchestration (sphere scan with
+// scalar-broadcast tables, LDS candidate lists, ballots, sample refill) lives in
+// rt_kernel.hip.  The functions are __host__ __device__ so that tests/hostsim can run the
+// very same arithmetic on the CPU for development; the product only ever runs them on the GPU.
+//
+// Arithmetic contract (what makes the GPU image match the CPU oracle):
+//   * geometry is f64 with the reference's exact operation order and NO fused multiply-add
+//     (compile with -ffp-contract=off; the only FMAs are the explicit ones in the f32 cull,
+//     which never decides a hit on its own);
+//   * colour is f32; the per-level `clamp(light + albedo*child)` recursion of
+//     raytracer.rs:118-122 is carried forward as a clamped-affine map (struct Fwd), so the
+//     f32 products associate differently from the recursion (documented tolerance);
+//   * randomness is Philox4x32-10 addressed by (pixel, sample, node, slot) — order-free.
+//
+// Reference lines are cited as file:line relative to /root/reference/raytracer/src/.
+#pragma once
+#include <stdint.h>
+
+#include "../../../include/rt_abi.h"
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#include <cmath>
+#define RT_HD inline
+#endif
+
+namespace rtc {
+
+// ------------------------------------------------------------------ device scene tables
+struct SphereGeom {  // 32 B, f64: sphere.rs:18-23 center + radius
+  double cx, cy, cz, r;
+};
+struct SphereMat {  // 64 B: materials.rs:35-42 payloads
+  float albedo[3];
+  uint32_t kind;
+  double fuzz_or_ior;
+  double h_offset;
+  uint64_t tex_w, tex_h;  // as written in the JSON (materials.rs:206-210)
+  uint64_t tex_off;       // byte offset of this texture in the texture blob
+  uint64_t tex_nbytes;
+};
+// f32 cull record for TWO spheres (SoA so one packed f32 instruction handles both):
+// centre rounded to f32 and R = r^2 inflated by the rounding budget of that sphere.
+struct CullPair {  // 32 B
+  float cx[2], cy[2], cz[2], R[2];
+};
+
+struct DevScene {
+  uint32_t width, height, spp, max_depth;
+  uint32_t sky_mode, n_spheres, n_lights, n_pairs;
+  uint32_t seed_lo, seed_hi;
+  uint32_t pad0, pad1;
+  double cam_origin[3], cam_ll[3], cam_h[3], cam_v[3];
+  const SphereGeom* geom;
+  const SphereMat* mat;
+  const CullPair* cull;
+  const uint32_t* lights;  // sphere indices of Light spheres, object order (raytracer.rs:220-229)
+  const uint8_t* tex;      // all textures back to back, RGB8
+  const uint8_t* sky;      // sky texture RGB8
+  uint64_t sky_w, sky_h;
+};
+
+// ------------------------------------------------------------------ point3d.rs
+struct V3 {
+  double x, y, z;
+};
+RT_HD V3 v3(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_HD V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }           // :89-99
+RT_HD V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }           // :101-111
+RT_HD V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }                                // :113-123
+RT_HD V3 muls(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }            // :137-147
+RT_HD V3 divs(V3 a, double s) { return v3(a.x / s, a.y / s, a.z / s); }            // :161-171
+RT_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }         // :72-74
+RT_HD double length_squared(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }    // :59-61
+RT_HD double length(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }      // :52-57, :63-65
+RT_HD V3 unit_vector(V3 a) { double l = length(a); return v3(a.x / l, a.y / l, a.z / l); }  // :67-70
+RT_HD bool near_zero(V3 a) {                                                       // :84-86
+  const double eps = 2.220446049250313e-16;
+  return fabs(a.x) < eps && fabs(a.y) < eps && fabs(a.z) < eps;
+}
+
+struct Rgb {
+  float r, g, b;
+};
+RT_HD Rgb rgb(float r, float g, float b) { Rgb c; c.r = r; c.g = g; c.b = b; return c; }
+RT_HD float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }  // raytracer.rs:61-69
+
+// ------------------------------------------------------------------ Philox4x32-10
+struct U4 {
+  uint32_t x, y, z, w;
+};
+RT_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  U4 r; r.x = c0; r.y = c1; r.z = c2; r.w = c3;
+  return r;
+}
+// RNG addressing: counter = (pixel, sample, node, slot), key = seed.
+//   node NODE_CAMERA, slot 0 : camera jitter                      (raytracer.rs:199-200)
+//   node n, slot 0           : .x.y Glass reflectance draw         (materials.rs:189)
+//                              .z.w light-sampling draw            (raytracer.rs:100)
+//   node n, slot 1+a         : attempt a of random_in_unit_sphere  (point3d.rs:31-38)
+constexpr uint32_t NODE_CAMERA = 0xFFFFFFFFu;
+RT_HD double u01_53(uint32_t lo, uint32_t hi) {  // rand 0.8 Standard f64: (u64 >> 11) * 2^-53
+  uint64_t u = ((uint64_t)hi << 32) | lo;
+  return (double)(u >> 11) * (1.0 / 9007199254740992.0);
+}
+RT_HD double range_m1_1(uint32_t w) {  // gen_range(-1.0..1.0) on a 2^-32 grid: v*(hi-lo)+lo
+  double value0_1 = (double)w * (1.0 / 4294967296.0);
+  return value0_1 * 2.0 + (-1.0);
+}
+RT_HD uint32_t child_node(uint32_t node, uint32_t light_j) {
+  uint32_t x = node * 0x9E3779B1u + (light_j + 1u) * 0x85EBCA77u;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
+  return 0x80000000u | (x & 0x7FFFFFFEu);
+}
+
+struct RngAddr {
+  uint32_t pixel, sample, k0, k1;
+};
+RT_HD U4 rng(const RngAddr& a, uint32_t node, uint32_t slot) {
+  return philox4x32_10(a.pixel, a.sample, node, slot, a.k0, a.k1);
+}
+// point3d.rs:22-38
+RT_HD V3 random_in_unit_sphere(const RngAddr& a, uint32_t node) {
+  for (uint32_t attempt = 0;; ++attempt) {
+    U4 w = rng(a, node, 1u + attempt);
+    V3 p = v3(range_m1_1(w.x), range_m1_1(w.y), range_m1_1(w.z));
+    if (length_squared(p) < 1.0) return p;
+  }
+}
+
+// ------------------------------------------------------------------ conservative f32 cull
+// A sphere can only be hit (sphere.rs:51-53, discriminant >= 0) if the f32 quantity below is
+// not negative.  With unit direction dh, oc = o - c:   disc/a = (oc.dh)^2 - |oc|^2 + r^2.
+// Every f32 rounding (inputs o, c, dh rounded to f32, then ~20 operations) is covered by the
+// margin  A*|oc|^2 + 2u|o|^2 + 2u|c|^2  with u = 2^-24, A = 2^-17  (derivation: DESIGN.md
+// "Cull margin").  2u|c|^2 and r^2 are folded into CullPair.R on the host, 2u|o|^2 is the
+// per-ray constant `Ko`.  The test is written `!(disc < 0)` so NaN/inf (overflowing or
+// degenerate rays) PASS and fall through to the exact test — the cull can only over-accept.
+constexpr float CULL_A = 7.62939453125e-06f;    // 2^-17
+constexpr float CULL_2U = 1.1920928955078125e-07f;  // 2 * 2^-24
+
+struct RayF32 {  // per-ray constants of the cull
+  float ox, oy, oz, dx, dy, dz, Ko;
+};
+RT_HD RayF32 make_ray_f32(V3 o, V3 d) {
+  RayF32 r;
+  r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
+  float fx = (float)d.x, fy = (float)d.y, fz = (float)d.z;
+  float l2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+#if defined(__HIP_DEVICE_COMPILE__)
+  float inv = __builtin_amdgcn_rsqf(l2);  // 1 ulp; budgeted in CULL_A
+#else
+  float inv = 1.0f / sqrtf(l2);
+#endif
+  r.dx = fx * inv; r.dy = fy * inv; r.dz = fz * inv;
+  r.Ko = CULL_2U * __builtin_fmaf(r.oz, r.oz, __builtin_fmaf(r.oy, r.oy, r.ox * r.ox));
+  return r;
+}
+// scalar form (one sphere); the kernel evaluates the same sequence on packed pairs
+RT_HD float cull_disc(const RayF32& r, float cx, float cy, float cz, float R) {
+  float ocx = r.ox - cx, ocy = r.oy - cy, ocz = r.oz - cz;
+  float b = __builtin_fmaf(ocz, r.dz, __builtin_fmaf(ocy, r.dy, ocx * r.dx));
+  float q = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, ocx * ocx));
+  float t = __builtin_fmaf(q, CULL_A - 1.0f, R + r.Ko);
+  return __builtin_fmaf(b, b, t);
+}
+RT_HD bool cull_pass(float disc) { return !(disc < 0.0f); }
+
+// host-side table construction (f64 -> f32 with outward rounding)
+inline float f32_round_up(double x) {
+  float f = (float)x;
+  if ((double)f < x) f = nextafterf(f, INFINITY);
+  return f;
+}
+inline void build_cull_entry(const RtSphere& s, float* cx, float* cy, float* cz, float* R) {
+  *cx = (float)s.center[0]; *cy = (float)s.center[1]; *cz = (float)s.center[2];
+  double c2 = s.center[0] * s.center[0] + s.center[1] * s.center[1] + s.center[2] * s.center[2];
+  double r2 = s.radius * s.radius;
+  *R = f32_round_up(r2 * (1.0 + 1e-6) + 2.0 * (double)CULL_2U * c2 + 1e-30);
+}
+
+// ------------------------------------------------------------------ exact hit (sphere.rs:46-58)
+// Returns the root Sphere::hit would accept for this sphere given (t_min, t_max), or a
+// negative number when it rejects.  Bit-identical arithmetic to the oracle.
+RT_HD double exact_root(V3 o, V3 d, double a, const SphereGeom& g, double t_min, double t_max) {
+  V3 oc = sub(o, v3(g.cx, g.cy, g.cz));
+  double half_b = dot(oc, d);
+  double c = length_squared(oc) - g.r * g.r;
+  double discriminant = (half_b * half_b) - (a * c);
+  if (discriminant >= 0.0) {
+    double sqrtd = sqrt(discriminant);
+    double root_a = ((-half_b) - sqrtd) / a;
+    if (root_a < t_max && root_a > t_min) return root_a;
+    double root_b = ((-half_b) + sqrtd) / a;
+    if (root_b < t_max && root_b > t_min) return root_b;
+  }
+  return -1.0;
+}
+constexpr double T_MIN = 0.001;                     // raytracer.rs:83
+constexpr double T_MAX = 1.7976931348623157e308;    // f64::MAX
+
+// ------------------------------------------------------------------ materials.rs
+RT_HD V3 reflect(V3 v, V3 n) { return sub(v, muls(n, 2.0 * dot(v, n))); }  // :111-113
+RT_HD V3 refract(V3 uv, V3 n, double etai_over_etat) {                     // :144-149
+  double cos_theta = fmin(dot(neg(uv), n), 1.0);
+  V3 r_out_perp = muls(add(uv, muls(n, cos_theta)), etai_over_etat);
+  V3 r_out_parallel = muls(n, -1.0 * sqrt(fabs(1.0 - length_squared(r_out_perp))));
+  return add(r_out_perp, r_out_parallel);
+}
+RT_HD double reflectance(double cosine, double ref_idx) {                  // :151-155
+  double r0 = (1.0 - ref_idx) / (1.0 + ref_idx);
+  r0 = r0 * r0;
+  double x = 1.0 - cosine;
+  double x2 = x * x, x4 = x2 * x2;
+  return r0 + (1.0 - r0) * (x * x4);  // powi(5)
+}
+RT_HD uint64_t sat_u64(double x) {  // Rust `f64 as u64`
+  if (!(x > 0.0)) return 0;
+  if (x >= 18446744073709551616.0) return ~0ull;
+  return (uint64_t)x;
+}
+RT_HD uint64_t sat_u64_f32(float x) {  // Rust `f32 as usize`
+  if (!(x > 0.0f)) return 0;
+  if (x >= 18446744073709551616.0f) return ~0ull;
+  return (uint64_t)x;
+}
+// materials.rs:236-254 (out-of-range index: clamp + count; the reference panics)
+RT_HD Rgb texture_albedo(const DevScene& sc, const SphereMat& m, double u, double v, uint32_t& tex_oob) {
+  double rot = u + m.h_offset;
+  if (rot > 1.0) rot = rot - 1.0;
+  double uu = rot * (double)m.tex_w;
+  double vv = (1.0 - v) * (double)(m.tex_h - 1);
+  uint64_t base_pixel = 3 * (sat_u64(floor(vv)) * m.tex_w + sat_u64(floor(uu)));
+  if (m.tex_nbytes < 3) { tex_oob++; return rgb(0.f, 0.f, 0.f); }
+  if (base_pixel > m.tex_nbytes - 3) { tex_oob++; base_pixel = (m.tex_nbytes / 3 - 1) * 3; }
+  const uint8_t* px = sc.tex + m.tex_off + base_pixel;
+  return rgb((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+}
+
+// ------------------------------------------------------------------ colour: forward form
+// ray_color returns clamp01(light + albedo * child) at every level (raytracer.rs:118-122).
+// Composing those maps outermost-first gives, per channel, G(x) = min(max(p + q*x, lo), hi):
+//   G o f (x),  f(x) = clamp01(L + a*x)   =>   p' = p + q*L,  q' = q*a,
+//                                              [lo', hi'] = sorted {G(0), G(1)}
+// (G is monotone, so G(clamp01(z)) = clamp(G(z), G(0), G(1))).  Exact in real arithmetic for
+// any sign of a; in f32 the products associate outermost-first instead of innermost-first.
+struct Fwd {
+  float p[3], q[3], lo[3], hi[3];
+};
+RT_HD void fwd_init(Fwd& f) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { f.p[i] = 0.0f; f.q[i] = 1.0f; f.lo[i] = -3.4028234663852886e38f; f.hi[i] = 3.4028234663852886e38f; }
+}
+RT_HD float fwd_eval1(const Fwd& f, int i, float x) {
+  float y = f.p[i] + f.q[i] * x;
+  y = y < f.lo[i] ? f.lo[i] : y;
+  y = y > f.hi[i] ? f.hi[i] : y;
+  return y;
+}
+RT_HD void fwd_compose(Fwd& f, const float L[3], const float a[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float g0 = fwd_eval1(f, i, 0.0f), g1 = fwd_eval1(f, i, 1.0f);
+    f.p[i] = f.p[i] + f.q[i] * L[i];
+    f.q[i] = f.q[i] * a[i];
+    f.lo[i] = g0 < g1 ? g0 : g1;
+    f.hi[i] = g0 < g1 ? g1 : g0;
+  }
+}
+
+// raytracer.rs:134-160: colour of a ray that left the scene
+RT_HD Rgb sky_color(const DevScene& sc, V3 d, uint32_t& tex_oob) {
+  if (sc.sky_mode == RT_SKY_NONE) return rgb(0.0f, 0.0f, 0.0f);
+  double l = length(d);
+  float t = clamp01(0.5f * ((float)(d.y / l) + 1.0f));
+  if (sc.sky_mode == RT_SKY_GRADIENT)
+    return rgb((1.0f - t) * 1.0f + t * 0.5f, (1.0f - t) * 1.0f + t * 0.7f, (1.0f - t) * 1.0f + t * 1.0f);
+  float u = clamp01(0.5f * ((float)(d.x / l) + 1.0f));
+  uint64_t x = sat_u64_f32(u * (float)(sc.sky_w - 1));
+  uint64_t y = sat_u64_f32((1.0f - t) * (float)(sc.sky_h - 1));
+  uint64_t base = (y * sc.sky_w + x) * 3;
+  if (base + 2 >= sc.sky_w * sc.sky_h * 3) { tex_oob++; base = (sc.sky_w * sc.sky_h - 1) * 3; }
+  const uint8_t* px = sc.sky + base;
+  return rgb(0.7f * (float)px[0] / 255.0f, 0.7f * (float)px[1] / 255.0f, 0.7f * (float)px[2] / 255.0f);
+}
+
+// ------------------------------------------------------------------ scatter (materials.rs:44-54)
+enum { SCATTER_ABSORBED = 0, SCATTER_EMIT = 1, SCATTER_RAY = 2 };
+struct Surface {  // what Sphere::hit records for the accepted root (sphere.rs:59-75)
+  V3 point, normal;
+  bool front_face;
+};
+RT_HD Surface surface_at(V3 o, V3 d, double t, const SphereGeom& g) {
+  Surface s;
+  s.point = add(o, muls(d, t));                                  // ray.rs:18-20
+  V3 outward = divs(sub(s.point, v3(g.cx, g.cy, g.cz)), g.r);    // sphere.rs:60
+  s.front_face = dot(d, outward) < 0.0;                          // :61
+  s.normal = s.front_face ? outward : neg(outward);              // :68
+  return s;
+}
+// sphere.rs:35-43, evaluated only when the closest hit is a Texture (a pure function of the
+// accepted hit, so skipping it for the other candidates changes nothing)
+RT_HD void sphere_uv(V3 point, const SphereGeom& g, double& u, double& v) {
+  V3 n = unit_vector(sub(point, v3(g.cx, g.cy, g.cz)));
+  u = (atan2(n.x, n.z) / (2.0 * 3.14159265358979323846264338327950288)) + 0.5;
+  v = n.y * 0.5 + 0.5;
+}
+RT_HD int scatter(const DevScene& sc, const RngAddr& ra, uint32_t node, V3 in_dir, const Surface& h,
+                  const SphereGeom& g, const SphereMat& m, V3& out_dir, float att[3], uint32_t& tex_oob) {
+  switch (m.kind) {
+    case RT_MAT_LIGHT:  // :65-69
+      att[0] = att[1] = att[2] = 1.0f;
+      return SCATTER_EMIT;
+    case RT_MAT_LAMBERTIAN:  // :84-95
+    case RT_MAT_TEXTURE: {   // :256-267
+      V3 sd = add(h.normal, random_in_unit_sphere(ra, node));
+      if (near_zero(sd)) sd = h.normal;
+      V3 target = add(h.point, sd);
+      out_dir = sub(target, h.point);  // (p + d) - p, as the reference computes it
+      if (m.kind == RT_MAT_TEXTURE) {
+        double u, v;
+        sphere_uv(h.point, g, u, v);
+        Rgb a = texture_albedo(sc, m, u, v, tex_oob);
+        att[0] = a.r; att[1] = a.g; att[2] = a.b;
+      } else {
+        att[0] = m.albedo[0]; att[1] = m.albedo[1]; att[2] = m.albedo[2];
+      }
+      return SCATTER_RAY;
+    }
+    case RT_MAT_METAL: {  // :115-129
+      V3 reflected = reflect(in_dir, h.normal);
+      out_dir = add(reflected, muls(random_in_unit_sphere(ra, node), m.fuzz_or_ior));
+      att[0] = m.albedo[0]; att[1] = m.albedo[1]; att[2] = m.albedo[2];
+      return dot(out_dir, h.normal) > 0.0 ? SCATTER_RAY : SCATTER_ABSORBED;
+    }
+    case RT_MAT_GLASS: {  // :176-199
+      att[0] = att[1] = att[2] = 1.0f;
+      double refraction_ratio = h.front_face ? 1.0 / m.fuzz_or_ior : m.fuzz_or_ior;
+      V3 unit_direction = unit_vector(in_dir);
+      double cos_theta = fmin(dot(neg(unit_direction), h.normal), 1.0);
+      double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+      bool do_reflect = refraction_ratio * sin_theta > 1.0;
+      if (!do_reflect) {
+        U4 w = rng(ra, node, 0);
+        do_reflect = reflectance(cos_theta, refraction_ratio) > u01_53(w.x, w.y);
+      }
+      out_dir = do_reflect ? reflect(unit_direction, h.normal) : refract(unit_direction, h.normal, refraction_ratio);
+      return SCATTER_RAY;
+    }
+    default:
+      att[0] = att[1] = att[2] = 0.0f;
+      return SCATTER_ABSORBED;
+  }
+}
+
+// ------------------------------------------------------------------ per-lane path state machine
+// One lane owns one pixel and walks its samples one ray segment at a time.  Each call of
+// lane_shade() consumes the closest hit of the lane's CURRENT ray (camera-path segment or
+// nested light ray, raytracer.rs:103-110) and leaves the NEXT ray in (o, d), so that the
+// expensive part — the sphere scan — is always executed by all live lanes together.
+struct LightFrame {  // one ray_color activation that is summing over the lights
+  V3 P;              // hit point = origin of its light rays
+  float a[3];        // its albedo
+  float acc[3];      // light_red/green/blue so far (raytracer.rs:89-91)
+  uint32_t j;        // next light
+  uint32_t node;     // its RNG node (children are child_node(node, j))
+};
+template <bool HAS_LIGHTS>
+struct LightState {};
+template <>
+struct LightState<true> {
+  LightFrame fr[RT_MAX_LIGHT_NEST];  // fr[0] = the camera-path hit, fr[m] = nesting level m
+  V3 saved_d;                        // scattered direction of the camera path, resumed afterwards
+  int top;
+};
+
+template <bool HAS_LIGHTS>
+struct Lane {
+  V3 o, d;        // current ray
+  uint32_t node;  // RNG node of the current ray
+  uint32_t k;     // camera-path segment index of the current (or suspended) camera ray
+  uint32_t s;     // current sample
+  uint32_t in_light;  // 1 while the current ray is a nested light ray
+  Fwd fwd;
+  float acc[3];   // pixel_colors (raytracer.rs:197)
+  RngAddr ra;
+  LightState<HAS_LIGHTS> ls;
+  // counters
+  uint32_t n_segments, n_exact, n_tex_oob;
+};
+
+// raytracer.rs:199-201 + camera.rs:79-84
+template <bool HL>
+RT_HD void lane_begin_sample(const DevScene& sc, Lane<HL>& L, uint32_t px, uint32_t py) {
+  L.ra.sample = L.s;
+  U4 w = rng(L.ra, NODE_CAMERA, 0);
+  double u = ((double)px + u01_53(w.x, w.y)) / ((double)sc.width - 1.0);
+  double v = ((double)sc.height - ((double)py + u01_53(w.z, w.w))) / ((double)sc.height - 1.0);
+  V3 origin = v3(sc.cam_origin[0], sc.cam_origin[1], sc.cam_origin[2]);
+  V3 llc = v3(sc.cam_ll[0], sc.cam_ll[1], sc.cam_ll[2]);
+  V3 hor = v3(sc.cam_h[0], sc.cam_h[1], sc.cam_h[2]);
+  V3 ver = v3(sc.cam_v[0], sc.cam_v[1], sc.cam_v[2]);
+  L.o = origin;
+  L.d = sub(add(add(llc, muls(hor, u)), muls(ver, v)), origin);
+  L.node = 0; L.k = 0; L.in_light = 0;
+  fwd_init(L.fwd);
+}
+
+// the sample's radiance is known: fold it through the forward map and accumulate (:203-205)
+template <bool HL>
+RT_HD void lane_finish_sample(Lane<HL>& L, Rgb leaf) {
+  L.acc[0] += fwd_eval1(L.fwd, 0, leaf.r);
+  L.acc[1] += fwd_eval1(L.fwd, 1, leaf.g);
+  L.acc[2] += fwd_eval1(L.fwd, 2, leaf.b);
+  L.s += 1;
+}
+
+// Continue the camera path after its hit at level k has been fully evaluated:
+// compose clamp(light + albedo*child) and step to the scattered ray.  Returns true when the
+// sample finished (depth exhausted: the child is ray_color(.., depth 0) = black, :80-82).
+template <bool HL>
+RT_HD bool lane_continue_main(const DevScene& sc, Lane<HL>& L, V3 point, V3 out_dir, const float light[3], const float att[3]) {
+  fwd_compose(L.fwd, light, att);
+  L.k += 1;
+  if (L.k >= sc.max_depth) { lane_finish_sample(L, rgb(0.0f, 0.0f, 0.0f)); return true; }
+  L.o = point; L.d = out_dir; L.node = L.k; L.in_light = 0;
+  return false;
+}
+
+#if 1
+// aim the current ray at light j of frame `top` (raytracer.rs:104-106)
+RT_HD void lane_aim_light(const DevScene& sc, Lane<true>& L) {
+  LightFrame& f = L.ls.fr[L.ls.top];
+  const SphereGeom& lg = sc.geom[sc.lights[f.j]];
+  L.o = f.P;
+  L.d = sub(v3(lg.cx, lg.cy, lg.cz), f.P);
+  L.node = child_node(f.node, f.j);
+  L.in_light = 1;
+}
+// a nested light ray produced colour tc: hand it to its parent activation(s) (:107-113)
+RT_HD bool lane_light_return(const DevScene& sc, Lane<true>& L, Rgb tc) {
+  for (;;) {
+    LightFrame& f = L.ls.fr[L.ls.top];
+    f.acc[0] += f.a[0] * tc.r; f.acc[1] += f.a[1] * tc.g; f.acc[2] += f.a[2] * tc.b;
+    f.j += 1;
+    if (f.j < sc.n_lights) { lane_aim_light(sc, L); return false; }
+    float nl = (float)sc.n_lights;
+    float light[3] = {f.acc[0] / nl, f.acc[1] / nl, f.acc[2] / nl};
+    if (L.ls.top == 0)  // back on the camera path: clamp(light + albedo*child), child = scattered ray
+      return lane_continue_main(sc, L, f.P, L.ls.saved_d, light, f.a);
+    // a nested activation (max_depth 2, depth 1): its own child is depth 0 = black (:117-122)
+    tc = rgb(clamp01(light[0] + f.a[0] * 0.0f), clamp01(light[1] + f.a[1] * 0.0f), clamp01(light[2] + f.a[2] * 0.0f));
+    L.ls.top -= 1;
+  }
+}
+#endif
+
+// Consume the closest hit (idx < 0: miss) of the lane's current ray.  Returns true when the
+// lane's current sample finished (L.s was advanced; the caller starts the next sample).
+template <bool HL>
+RT_HD bool lane_shade(const DevScene& sc, Lane<HL>& L, int idx, double t) {
+  if (idx < 0) {  // raytracer.rs:133-163
+    Rgb sky = sky_color(sc, L.d, L.n_tex_oob);
+    if constexpr (HL) {
+      if (L.in_light) return lane_light_return(sc, L, sky);
+    }
+    lane_finish_sample(L, sky);
+    return true;
+  }
+  const SphereGeom g = sc.geom[idx];
+  const SphereMat m = sc.mat[idx];
+  Surface h = surface_at(L.o, L.d, t, g);
+  V3 out_dir = v3(0, 0, 0);
+  float att[3];
+  int st = scatter(sc, L.ra, L.node, L.d, h, g, m, out_dir, att, L.n_tex_oob);
+  const float zero3[3] = {0.0f, 0.0f, 0.0f};
+
+  if constexpr (HL) {
+    if (L.in_light) {
+      // nested activation ray_color(light_ray, 2, 1) at nesting level top+1
+      if (st == SCATTER_EMIT) return lane_light_return(sc, L, rgb(att[0], att[1], att[2]));  // :124
+      if (st == SCATTER_ABSORBED) return lane_light_return(sc, L, rgb(0.f, 0.f, 0.f));        // :127-131
+      const uint32_t level = (uint32_t)L.ls.top + 1u;
+      if (level < RT_MAX_LIGHT_NEST) {
+        double prob = m.kind == RT_MAT_GLASS ? 0.05 : 0.1;
+        U4 w = rng(L.ra, L.node, 0);
+        if (u01_53(w.z, w.w) > (1.0 - (double)sc.n_lights * prob)) {
+          L.ls.top += 1;
+          LightFrame& f = L.ls.fr[L.ls.top];
+          f.P = h.point; f.a[0] = att[0]; f.a[1] = att[1]; f.a[2] = att[2];
+          f.acc[0] = f.acc[1] = f.acc[2] = 0.0f; f.j = 0; f.node = L.node;
+          lane_aim_light(sc, L);
+          return false;
+        }
+      }
+      // no light sampling: clamp(0 + albedo * black)
+      return lane_light_return(sc, L, rgb(clamp01(0.0f + att[0] * 0.0f), clamp01(0.0f + att[1] * 0.0f), clamp01(0.0f + att[2] * 0.0f)));
+    }
+  }
+
+  if (st == SCATTER_ABSORBED) { lane_finish_sample(L, rgb(0.f, 0.f, 0.f)); return true; }       // :127-131
+  if (st == SCATTER_EMIT) { lane_finish_sample(L, rgb(att[0], att[1], att[2])); return true; }  // :124
+  if constexpr (HL) {
+    // raytracer.rs:99-102: depth > max_depth-2  <=>  k < 2 (and max_depth >= 2, usize wrap)
+    if (sc.max_depth >= 2 && L.k < 2) {
+      double prob = m.kind == RT_MAT_GLASS ? 0.05 : 0.1;
+      U4 w = rng(L.ra, L.node, 0);
+      if (u01_53(w.z, w.w) > (1.0 - (double)sc.n_lights * prob)) {
+        L.ls.top = 0;
+        LightFrame& f = L.ls.fr[0];
+        f.P = h.point; f.a[0] = att[0]; f.a[1] = att[1]; f.a[2] = att[2];
+        f.acc[0] = f.acc[1] = f.acc[2] = 0.0f; f.j = 0; f.node = L.node;
+        L.ls.saved_d = out_dir;
+        lane_aim_light(sc, L);
+        return false;
+      }
+    }
+  }
+  return lane_continue_main(sc, L, h.point, out_dir, zero3, att);
+}
+
+// raytracer.rs:207-213: mean, sqrt gamma, palette f32 -> u8 (round-half-even of min(x*255,255))
+RT_HD uint8_t f32_to_u8(float x) {
+  float scaled = x * 255.0f;
+  if (!(scaled > 0.0f)) return 0;
+  if (scaled > 255.0f) scaled = 255.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint8_t)__builtin_rintf(scaled);
+#else
+  return (uint8_t)nearbyintf(scaled);
+#endif
+}
+
+}  // namespace rtc

@@ -1,0 +1,373 @@
+// jpeg.cpp — baseline / extended-sequential Huffman JPEG -> RGB8.
+// Stands in for the `jpeg-decoder` crate the reference calls while deserializing textures
+// (reference materials.rs:213-219 load_texture_image, config.rs:36-47).  Texel values of a
+// lossy decode are decoder-specific (IDCT + chroma upsampling), and no reference test pins
+// them; what matters for parity is that oracle and GPU consume the SAME decoded buffer,
+// which they do (both receive RtTexture.rgb8 from this file).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/rt_abi.h"
+
+namespace {
+
+struct Huff {
+  // canonical decode tables
+  uint8_t bits[17] = {0};
+  uint8_t vals[256] = {0};
+  int32_t mincode[17], maxcode[18], valptr[17];
+  uint8_t look_nbits[512];  // 9-bit fast lookup
+  uint8_t look_sym[512];
+  bool present = false;
+  void build() {
+    int code = 0, k = 0;
+    std::memset(look_nbits, 0, sizeof look_nbits);
+    for (int l = 1; l <= 16; ++l) {
+      valptr[l] = k;
+      mincode[l] = code;
+      for (int i = 0; i < bits[l]; ++i, ++k, ++code) {
+        if (l <= 9) {
+          int base = code << (9 - l);
+          for (int f = 0; f < (1 << (9 - l)); ++f) { look_nbits[base + f] = uint8_t(l); look_sym[base + f] = vals[k]; }
+        }
+      }
+      maxcode[l] = bits[l] ? code - 1 : -1;
+      code <<= 1;
+    }
+    maxcode[17] = 0x7fffffff;
+    present = true;
+  }
+};
+
+struct Comp {
+  int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
+  int bw = 0, bh = 0;  // blocks per line / column (padded to MCU)
+  int pred = 0;
+  std::vector<uint8_t> plane;  // bw*8 x bh*8
+};
+
+struct BitReader {
+  const uint8_t* p; const uint8_t* end;
+  uint32_t acc = 0; int cnt = 0; bool hit_marker = false;
+  void fill() {
+    while (cnt <= 24) {
+      uint32_t byte = 0;
+      if (!hit_marker && p < end) {
+        byte = *p;
+        if (byte == 0xFF) {
+          if (p + 1 < end && p[1] == 0x00) { p += 2; }
+          else { hit_marker = true; byte = 0; }  // leave the marker in place, feed zeros
+        } else ++p;
+      }
+      acc |= byte << (24 - cnt);
+      cnt += 8;
+    }
+  }
+  inline uint32_t peek(int n) { if (cnt < n) fill(); return acc >> (32 - n); }
+  inline void skip(int n) { acc <<= n; cnt -= n; }
+  inline int get(int n) { if (!n) return 0; uint32_t v = peek(n); skip(n); return int(v); }
+  void reset() { acc = 0; cnt = 0; hit_marker = false; }
+};
+
+inline int extend(int v, int n) { return v < (1 << (n - 1)) ? v - (1 << n) + 1 : v; }
+
+int decode_sym(BitReader& br, const Huff& h) {
+  uint32_t look = br.peek(9);
+  int nb = h.look_nbits[look];
+  if (nb) { br.skip(nb); return h.look_sym[look]; }
+  uint32_t bits16 = br.peek(16);
+  for (int l = 10; l <= 16; ++l) {
+    int code = int(bits16 >> (16 - l));
+    if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) {
+      br.skip(l);
+      return h.vals[h.valptr[l] + code - h.mincode[l]];
+    }
+  }
+  return -1;
+}
+
+const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
+                             12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+                             58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// separable 8x8 inverse DCT in double precision (reference-quality, not speed-tuned)
+struct IdctTable {
+  double c[8][8];  // c[x][u] = 0.5 * C(u) * cos((2x+1) u pi / 16)
+  IdctTable() {
+    for (int x = 0; x < 8; ++x)
+      for (int u = 0; u < 8; ++u)
+        c[x][u] = 0.5 * (u == 0 ? std::sqrt(0.5) : 1.0) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0);
+  }
+};
+const IdctTable kIdct;
+
+void idct_block(const int* coef, uint8_t* out, int stride) {
+  double tmp[64];
+  for (int v = 0; v < 8; ++v) {  // rows: over u
+    const int* row = coef + v * 8;
+    bool ac = false;
+    for (int u = 1; u < 8; ++u) ac |= row[u] != 0;
+    for (int x = 0; x < 8; ++x) {
+      double s = kIdct.c[x][0] * row[0];
+      if (ac) for (int u = 1; u < 8; ++u) s += kIdct.c[x][u] * row[u];
+      tmp[v * 8 + x] = s;
+    }
+  }
+  for (int x = 0; x < 8; ++x)
+    for (int y = 0; y < 8; ++y) {
+      double s = 0;
+      for (int v = 0; v < 8; ++v) s += kIdct.c[y][v] * tmp[v * 8 + x];
+      long r = std::lround(s) + 128;
+      out[y * stride + x] = uint8_t(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+}
+
+inline uint16_t be16(const uint8_t* p) { return uint16_t((p[0] << 8) | p[1]); }
+
+struct Decoder {
+  const uint8_t* data; size_t len;
+  std::string err;
+  int width = 0, height = 0, ncomp = 0, hmax = 1, vmax = 1;
+  uint16_t qt[4][64] = {{0}};
+  bool qt_present[4] = {false, false, false, false};
+  Huff dc[4], ac[4];
+  Comp comp[3];
+  int restart_interval = 0;
+  bool adobe = false; int adobe_transform = 0;
+  bool sof_seen = false;
+
+  bool fail(const std::string& m) { err = m; return false; }
+
+  bool decode_scan(const uint8_t* p, const uint8_t* end, const uint8_t** next) {
+    BitReader br{p, end};
+    int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+    int coef[64];
+    int rst_left = restart_interval;
+    for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
+    for (int my = 0; my < mcuy; ++my)
+      for (int mx = 0; mx < mcux; ++mx) {
+        if (restart_interval && rst_left == 0) {
+          // byte-align, expect RSTn
+          br.reset();
+          const uint8_t* q = br.p;
+          while (q + 1 < end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
+          if (q + 1 >= end) return fail("missing restart marker");
+          br.p = q + 2;
+          for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
+          rst_left = restart_interval;
+        }
+        for (int c = 0; c < ncomp; ++c) {
+          Comp& cp = comp[c];
+          const Huff& hd = dc[cp.td]; const Huff& ha = ac[cp.ta];
+          const uint16_t* q = qt[cp.tq];
+          for (int by = 0; by < cp.v; ++by)
+            for (int bx = 0; bx < cp.h; ++bx) {
+              std::memset(coef, 0, sizeof coef);
+              int t = decode_sym(br, hd);
+              if (t < 0 || t > 11) return fail("bad DC huffman code");
+              int diff = t ? extend(br.get(t), t) : 0;
+              cp.pred += diff;
+              coef[0] = cp.pred * q[0];
+              for (int k = 1; k < 64;) {
+                int rs = decode_sym(br, ha);
+                if (rs < 0) return fail("bad AC huffman code");
+                int r = rs >> 4, s = rs & 15;
+                if (s == 0) { if (r == 15) { k += 16; continue; } break; }
+                k += r;
+                if (k > 63) return fail("AC index overflow");
+                coef[kZigzag[k]] = extend(br.get(s), s) * q[k];
+                ++k;
+              }
+              int px = (mx * cp.h + bx) * 8, py = (my * cp.v + by) * 8;
+              idct_block(coef, cp.plane.data() + size_t(py) * (cp.bw * 8) + px, cp.bw * 8);
+            }
+        }
+        if (restart_interval) --rst_left;
+      }
+    *next = br.p;
+    return true;
+  }
+
+  bool parse() {
+    if (len < 4 || data[0] != 0xFF || data[1] != 0xD8) return fail("not a JPEG (no SOI)");
+    const uint8_t* p = data + 2; const uint8_t* end = data + len;
+    bool scanned = false;
+    while (p + 4 <= end) {
+      if (p[0] != 0xFF) { ++p; continue; }
+      uint8_t m = p[1];
+      if (m == 0xFF) { ++p; continue; }
+      if (m == 0xD9) break;
+      if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) { p += 2; continue; }
+      uint16_t L = be16(p + 2);
+      if (L < 2 || p + 2 + L > end) return fail("truncated segment");
+      const uint8_t* s = p + 4; const uint8_t* se = p + 2 + L;
+      if (m == 0xDB) {
+        while (s < se) {
+          int pq = s[0] >> 4, tq = s[0] & 15; ++s;
+          if (tq > 3) return fail("bad DQT id");
+          for (int i = 0; i < 64; ++i) {
+            if (pq) { if (s + 2 > se) return fail("bad DQT"); qt[tq][i] = be16(s); s += 2; }
+            else { if (s + 1 > se) return fail("bad DQT"); qt[tq][i] = *s++; }
+          }
+          qt_present[tq] = true;
+        }
+      } else if (m == 0xC4) {
+        while (s < se) {
+          int tc = s[0] >> 4, th = s[0] & 15; ++s;
+          if (th > 3 || tc > 1 || s + 16 > se) return fail("bad DHT");
+          Huff& h = tc ? ac[th] : dc[th];
+          int total = 0; h.bits[0] = 0;
+          for (int i = 1; i <= 16; ++i) { h.bits[i] = s[i - 1]; total += s[i - 1]; }
+          s += 16;
+          if (total > 256 || s + total > se) return fail("bad DHT");
+          std::memcpy(h.vals, s, total); s += total;
+          h.build();
+        }
+      } else if (m == 0xC0 || m == 0xC1) {
+        if (s[0] != 8) return fail("only 8-bit JPEG supported");
+        height = be16(s + 1); width = be16(s + 3); ncomp = s[5];
+        if (!(ncomp == 1 || ncomp == 3) || width <= 0 || height <= 0) return fail("unsupported component count");
+        hmax = vmax = 1;
+        for (int c = 0; c < ncomp; ++c) {
+          comp[c].id = s[6 + 3 * c]; comp[c].h = s[7 + 3 * c] >> 4; comp[c].v = s[7 + 3 * c] & 15;
+          comp[c].tq = s[8 + 3 * c];
+          if (comp[c].h < 1 || comp[c].h > 4 || comp[c].v < 1 || comp[c].v > 4 || comp[c].tq > 3) return fail("bad SOF");
+          if (comp[c].h > hmax) hmax = comp[c].h;
+          if (comp[c].v > vmax) vmax = comp[c].v;
+        }
+        int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+        for (int c = 0; c < ncomp; ++c) {
+          comp[c].bw = mcux * comp[c].h; comp[c].bh = mcuy * comp[c].v;
+          comp[c].plane.assign(size_t(comp[c].bw) * 8 * comp[c].bh * 8, 0);
+        }
+        sof_seen = true;
+      } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+        return fail("progressive / lossless / arithmetic JPEG not supported");
+      } else if (m == 0xDD) {
+        restart_interval = be16(s);
+      } else if (m == 0xEE && L >= 14 && std::memcmp(s, "Adobe", 5) == 0) {
+        adobe = true; adobe_transform = s[11];
+      } else if (m == 0xDA) {
+        if (!sof_seen) return fail("SOS before SOF");
+        int ns = s[0];
+        if (ns != ncomp) return fail("non-interleaved scans not supported");
+        for (int i = 0; i < ns; ++i) {
+          int cid = s[1 + 2 * i], tbl = s[2 + 2 * i];
+          int c = -1;
+          for (int k = 0; k < ncomp; ++k) if (comp[k].id == cid) c = k;
+          if (c < 0) return fail("bad SOS component");
+          comp[c].td = tbl >> 4; comp[c].ta = tbl & 15;
+          if (comp[c].td > 3 || comp[c].ta > 3 || !dc[comp[c].td].present || !ac[comp[c].ta].present || !qt_present[comp[c].tq])
+            return fail("scan references a missing table");
+        }
+        const uint8_t* next = nullptr;
+        if (!decode_scan(se, end, &next)) return false;
+        scanned = true;
+        p = next;
+        continue;
+      }
+      p += 2 + L;
+    }
+    if (!scanned) return fail("no image data");
+    return true;
+  }
+
+  // libjpeg-style "fancy" (triangle filter) upsampling of one component to full size
+  void upsample(const Comp& c, std::vector<uint8_t>& out) const {
+    const int W = width, H = height, pw = c.bw * 8, ph = c.bh * 8;
+    out.resize(size_t(W) * H);
+    const int fx = hmax / c.h, fy = vmax / c.v;
+    const bool exact = (hmax % c.h == 0) && (vmax % c.v == 0);
+    // number of valid source samples (rest of the plane is MCU padding)
+    const int sw = (W * c.h + hmax - 1) / hmax, sh = (H * c.v + vmax - 1) / vmax;
+    auto S = [&](int x, int y) -> int {
+      x = x < 0 ? 0 : (x >= sw ? sw - 1 : x);
+      y = y < 0 ? 0 : (y >= sh ? sh - 1 : y);
+      (void)ph;
+      return c.plane[size_t(y) * pw + x];
+    };
+    if (exact && fx == 1 && fy == 1) {
+      for (int y = 0; y < H; ++y) std::memcpy(&out[size_t(y) * W], &c.plane[size_t(y) * pw], W);
+    } else if (exact && fx == 2 && fy == 2) {
+      for (int y = 0; y < H; ++y) {
+        int sy = y >> 1, ny = (y & 1) ? sy + 1 : sy - 1;
+        for (int x = 0; x < W; ++x) {
+          int sx = x >> 1, nx = (x & 1) ? sx + 1 : sx - 1;
+          int thiscol = 3 * S(sx, sy) + S(sx, ny), nextcol = 3 * S(nx, sy) + S(nx, ny);
+          out[size_t(y) * W + x] = uint8_t((3 * thiscol + nextcol + ((x & 1) ? 7 : 8)) >> 4);
+        }
+      }
+    } else if (exact && fx == 2 && fy == 1) {
+      for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+          int sx = x >> 1, nx = (x & 1) ? sx + 1 : sx - 1;
+          out[size_t(y) * W + x] = uint8_t((3 * S(sx, y) + S(nx, y) + ((x & 1) ? 2 : 1)) >> 2);
+        }
+    } else if (exact && fx == 1 && fy == 2) {
+      for (int y = 0; y < H; ++y) {
+        int sy = y >> 1, ny = (y & 1) ? sy + 1 : sy - 1;
+        for (int x = 0; x < W; ++x)
+          out[size_t(y) * W + x] = uint8_t((3 * S(x, sy) + S(x, ny) + ((y & 1) ? 2 : 1)) >> 2);
+      }
+    } else {  // uncommon ratios: nearest
+      for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) out[size_t(y) * W + x] = uint8_t(S(x * c.h / hmax, y * c.v / vmax));
+    }
+  }
+
+  void to_rgb(uint8_t* rgb) const {
+    const size_t n = size_t(width) * height;
+    std::vector<uint8_t> p0, p1, p2;
+    upsample(comp[0], p0);
+    if (ncomp == 1) {
+      for (size_t i = 0; i < n; ++i) rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = p0[i];
+      return;
+    }
+    upsample(comp[1], p1);
+    upsample(comp[2], p2);
+    const bool ycc = adobe ? adobe_transform != 0 : true;
+    auto clamp8 = [](int v) { return uint8_t(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+    for (size_t i = 0; i < n; ++i) {
+      if (!ycc) { rgb[3 * i] = p0[i]; rgb[3 * i + 1] = p1[i]; rgb[3 * i + 2] = p2[i]; continue; }
+      // JFIF YCbCr -> RGB, 16-bit fixed point like libjpeg's jdcolor.c
+      int y = p0[i], cb = p1[i] - 128, cr = p2[i] - 128;
+      int r = y + ((91881 * cr + 32768) >> 16);
+      int g = y + ((-22554 * cb - 46802 * cr + 32768) >> 16);
+      int b = y + ((116130 * cb + 32768) >> 16);
+      rgb[3 * i] = clamp8(r); rgb[3 * i + 1] = clamp8(g); rgb[3 * i + 2] = clamp8(b);
+    }
+  }
+};
+
+thread_local std::string g_jpeg_err;
+
+}  // namespace
+
+extern "C" const char* rt_jpeg_last_error(void) { return g_jpeg_err.c_str(); }
+
+extern "C" int rt_jpeg_decode_mem(const uint8_t* data, size_t len, uint8_t** rgb8, uint32_t* w, uint32_t* h) {
+  if (!data || !rgb8 || !w || !h) return RT_ERR_INVALID;
+  Decoder d; d.data = data; d.len = len;
+  if (!d.parse()) { g_jpeg_err = d.err; return RT_ERR_TEXTURE; }
+  uint8_t* out = static_cast<uint8_t*>(std::malloc(size_t(d.width) * d.height * 3));
+  if (!out) { g_jpeg_err = "out of memory"; return RT_ERR_TEXTURE; }
+  d.to_rgb(out);
+  *rgb8 = out; *w = uint32_t(d.width); *h = uint32_t(d.height);
+  return RT_OK;
+}
+
+extern "C" int rt_jpeg_decode_file(const char* path, uint8_t** rgb8, uint32_t* w, uint32_t* h) {
+  if (!path) return RT_ERR_INVALID;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { g_jpeg_err = std::string("cannot open ") + path; return RT_ERR_TEXTURE; }
+  std::vector<uint8_t> buf;
+  uint8_t tmp[65536]; size_t n;
+  while ((n = std::fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+  std::fclose(f);
+  return rt_jpeg_decode_mem(buf.data(), buf.size(), rgb8, w, h);
+}

@@ -1,0 +1,376 @@
+// scene.cpp — host plumbing of librt_host.so: the JSON scene schema, Camera::new,
+// find_lights, PNG output.  C++ stand-in for the Rust host code that stays on the CPU
+// (reference main.rs:7-20, config.rs:20-75, camera.rs:9-77, sphere.rs:18-23,
+// materials.rs:18-42/56-76/97-103/131-134/201-234, raytracer.rs:33-42/220-229).
+// No path-tracing arithmetic lives here; that is librt_hip.so.
+#include <zlib.h>
+
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/rt_abi.h"
+#include "json.hpp"
+
+extern "C" const char* rt_jpeg_last_error(void);
+
+namespace {
+
+thread_local std::string g_err;
+int set_err(int code, const std::string& m) { g_err = m; return code; }
+
+struct SchemaError { std::string msg; };
+[[noreturn]] void bad(const std::string& m) { throw SchemaError{m}; }
+
+using rtjson::Value;
+
+const Value& field(const Value& obj, const char* key, const char* where) {
+  if (obj.kind != Value::Object) bad(std::string("expected object for ") + where);
+  const Value* v = obj.find(key);
+  if (!v) bad(std::string("missing field `") + key + "` in " + where);
+  return *v;
+}
+double as_f64(const Value& v, const char* what) {
+  if (v.kind != Value::Number) bad(std::string("expected number for ") + what);
+  return std::strtod(v.text.c_str(), nullptr);
+}
+float as_f32(const Value& v, const char* what) {
+  // serde_json parses the literal as f64 and casts (`as f32`)
+  return static_cast<float>(as_f64(v, what));
+}
+uint64_t as_u64(const Value& v, const char* what, uint64_t max) {
+  if (v.kind != Value::Number) bad(std::string("expected unsigned integer for ") + what);
+  const std::string& t = v.text;
+  if (t.empty() || t.find_first_not_of("0123456789") != std::string::npos)
+    bad(std::string("invalid type: expected unsigned integer for ") + what);
+  errno = 0;
+  unsigned long long x = std::strtoull(t.c_str(), nullptr, 10);
+  if (errno == ERANGE || x > max) bad(std::string("integer out of range for ") + what);
+  return x;
+}
+void as_point(const Value& v, const char* what, double out[3]) {
+  out[0] = as_f64(field(v, "x", what), what);
+  out[1] = as_f64(field(v, "y", what), what);
+  out[2] = as_f64(field(v, "z", what), what);
+}
+
+}  // namespace
+
+// reference camera.rs:45-77
+extern "C" void rt_camera_derive(const double lf[3], const double la[3], const double up[3], double vfov_deg,
+                                 double aspect, double out[13]) {
+  auto unit = [](const double v[3], double o[3]) {
+    double l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    o[0] = v[0] / l; o[1] = v[1] / l; o[2] = v[2] / l;
+  };
+  auto cross = [](const double a[3], const double b[3], double o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+  };
+  const double theta = vfov_deg * (3.14159265358979323846264338327950288 / 180.0);
+  const double half_height = std::tan(theta / 2.0);
+  const double half_width = aspect * half_height;
+  double d[3] = {lf[0] - la[0], lf[1] - la[1], lf[2] - la[2]};
+  double w[3], u[3], v[3], c[3];
+  unit(d, w);
+  cross(up, w, c);
+  unit(c, u);
+  cross(w, u, v);
+  for (int i = 0; i < 3; ++i) {
+    out[i] = lf[i];
+    out[3 + i] = ((lf[i] - u[i] * half_width) - v[i] * half_height) - w[i];
+    out[6 + i] = (u[i] * 2.0) * half_width;
+    out[9 + i] = (v[i] * 2.0) * half_height;
+  }
+  out[12] = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+}
+
+// reference raytracer.rs:220-229
+extern "C" uint32_t rt_find_lights(const RtSphere* spheres, uint32_t n, uint32_t* out_idx, uint32_t cap) {
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < n; ++i)
+    if (spheres[i].kind == RT_MAT_LIGHT) {
+      if (out_idx && k < cap) out_idx[k] = i;
+      ++k;
+    }
+  return k;
+}
+
+struct RtSceneFile {
+  RtScene scene{};
+  std::vector<RtSphere> spheres;
+  std::vector<RtTexture> textures;
+  std::vector<std::unique_ptr<uint8_t, void (*)(void*)>> pixel_store;
+  std::vector<std::string> texture_paths;  // per RtTexture
+  std::unique_ptr<uint8_t, void (*)(void*)> sky_pixels{nullptr, std::free};
+  std::string sky_path;
+  double look_from[3]{}, look_at[3]{}, vup[3]{}, vfov = 0, aspect = 0, focal_length = 0;
+};
+
+namespace {
+
+// materials.rs:213-219 / config.rs:36-47; `File::open(path).expect(path)` -> RT_ERR_TEXTURE
+uint32_t load_texture(RtSceneFile& sf, std::map<std::string, uint32_t>& cache, const std::string& path) {
+  auto it = cache.find(path);
+  if (it != cache.end()) return it->second;
+  uint8_t* px = nullptr; uint32_t w = 0, h = 0;
+  int rc = rt_jpeg_decode_file(path.c_str(), &px, &w, &h);
+  if (rc != RT_OK) bad("texture " + path + ": " + rt_jpeg_last_error());
+  sf.pixel_store.emplace_back(px, std::free);
+  RtTexture t{};
+  t.rgb8 = px; t.nbytes = uint64_t(w) * h * 3; t.width = w; t.height = h;
+  sf.textures.push_back(t);
+  sf.texture_paths.push_back(path);
+  uint32_t id = uint32_t(sf.textures.size() - 1);
+  cache[path] = id;
+  return id;
+}
+
+void parse_albedo(const Value& v, float out[3]) {
+  if (v.kind != Value::Array || v.items.size() != 3) bad("albedo: expected an array of length 3");
+  for (int i = 0; i < 3; ++i) out[i] = as_f32(*v.items[i], "albedo");
+}
+
+void build_scene(const Value& root, RtSceneFile& sf) {
+  if (root.kind != Value::Object) bad("expected a Config object");
+  RtScene& sc = sf.scene;
+  sc.abi_version = RT_ABI_VERSION;
+  sc.width = uint32_t(as_u64(field(root, "width", "Config"), "width", 0xFFFFFFFFull));
+  sc.height = uint32_t(as_u64(field(root, "height", "Config"), "height", 0xFFFFFFFFull));
+  sc.samples_per_pixel = uint32_t(as_u64(field(root, "samples_per_pixel", "Config"), "samples_per_pixel", 0xFFFFFFFFull));
+  sc.max_depth = uint32_t(as_u64(field(root, "max_depth", "Config"), "max_depth", 0x7FFFFFFFull));
+
+  std::map<std::string, uint32_t> cache;
+  // config.rs:22-28, 49-64: Option<Sky>; texture "" -> None
+  const Value* sky = root.find("sky");
+  sc.sky_mode = RT_SKY_NONE;
+  if (sky && sky->kind != Value::Null) {
+    const Value& tex = field(*sky, "texture", "Sky");
+    if (tex.kind != Value::String) bad("Sky.texture: expected a string");
+    if (tex.text.empty()) sc.sky_mode = RT_SKY_GRADIENT;
+    else {
+      uint8_t* px = nullptr; uint32_t w = 0, h = 0;
+      if (rt_jpeg_decode_file(tex.text.c_str(), &px, &w, &h) != RT_OK)
+        bad("sky texture " + tex.text + ": " + rt_jpeg_last_error());
+      sf.sky_pixels.reset(px);
+      sf.sky_path = tex.text;
+      sc.sky_mode = RT_SKY_TEXTURE; sc.sky_rgb8 = px; sc.sky_w = w; sc.sky_h = h;
+    }
+  }
+
+  // camera.rs:29-42 CameraParams -> Camera::new
+  const Value& cam = field(root, "camera", "Config");
+  as_point(field(cam, "look_from", "camera"), "camera.look_from", sf.look_from);
+  as_point(field(cam, "look_at", "camera"), "camera.look_at", sf.look_at);
+  as_point(field(cam, "vup", "camera"), "camera.vup", sf.vup);
+  sf.vfov = as_f64(field(cam, "vfov", "camera"), "camera.vfov");
+  sf.aspect = as_f64(field(cam, "aspect", "camera"), "camera.aspect");
+  double c[13];
+  rt_camera_derive(sf.look_from, sf.look_at, sf.vup, sf.vfov, sf.aspect, c);
+  std::memcpy(sc.cam_origin, c, 24); std::memcpy(sc.cam_lower_left, c + 3, 24);
+  std::memcpy(sc.cam_horizontal, c + 6, 24); std::memcpy(sc.cam_vertical, c + 9, 24);
+  sf.focal_length = c[12];
+
+  const Value& objs = field(root, "objects", "Config");
+  if (objs.kind != Value::Array) bad("objects: expected an array");
+  sf.spheres.reserve(objs.items.size());
+  for (auto& o : objs.items) {
+    RtSphere s{};
+    as_point(field(*o, "center", "Sphere"), "Sphere.center", s.center);
+    s.radius = as_f64(field(*o, "radius", "Sphere"), "Sphere.radius");
+    const Value& m = field(*o, "material", "Sphere");
+    if (m.kind != Value::Object || m.members.size() != 1) bad("material: expected a single-key enum object");
+    const std::string& tag = m.members[0].first;
+    const Value& body = *m.members[0].second;
+    if (tag == "Lambertian") {
+      s.kind = RT_MAT_LAMBERTIAN; parse_albedo(field(body, "albedo", "Lambertian"), s.albedo);
+    } else if (tag == "Metal") {
+      s.kind = RT_MAT_METAL; parse_albedo(field(body, "albedo", "Metal"), s.albedo);
+      s.fuzz_or_ior = as_f64(field(body, "fuzz", "Metal"), "Metal.fuzz");
+    } else if (tag == "Glass") {
+      s.kind = RT_MAT_GLASS;
+      s.fuzz_or_ior = as_f64(field(body, "index_of_refraction", "Glass"), "Glass.index_of_refraction");
+    } else if (tag == "Texture") {
+      s.kind = RT_MAT_TEXTURE; parse_albedo(field(body, "albedo", "Texture"), s.albedo);
+      const Value& px = field(body, "pixels", "Texture");
+      if (px.kind != Value::String) bad("Texture.pixels: expected a path string");
+      s.tex_w = as_u64(field(body, "width", "Texture"), "Texture.width", ~0ull);
+      s.tex_h = as_u64(field(body, "height", "Texture"), "Texture.height", ~0ull);
+      s.h_offset = as_f64(field(body, "h_offset", "Texture"), "Texture.h_offset");
+      s.tex_id = load_texture(sf, cache, px.text);
+    } else if (tag == "Light") {
+      if (body.kind != Value::Object) bad("Light: expected {}");
+      s.kind = RT_MAT_LIGHT;
+    } else {
+      bad("unknown variant `" + tag + "`, expected one of `Lambertian`, `Metal`, `Glass`, `Texture`, `Light`");
+    }
+    sf.spheres.push_back(s);
+  }
+  sc.spheres = sf.spheres.data(); sc.n_spheres = uint32_t(sf.spheres.size());
+  sc.textures = sf.textures.data(); sc.n_textures = uint32_t(sf.textures.size());
+  sc.seed = 0;
+}
+
+// ---- serde_json::to_string number formatting (ryu "pretty" layout) ----
+template <typename F>
+std::string shortest(F x, int max_prec, bool is32) {
+  if (x == 0) return std::signbit(x) ? "-0.0" : "0.0";
+  char buf[64];
+  int prec = 0;
+  for (; prec <= max_prec; ++prec) {
+    std::snprintf(buf, sizeof buf, "%.*e", prec, double(x));
+    if (is32 ? (std::strtof(buf, nullptr) == float(x)) : (std::strtod(buf, nullptr) == double(x))) break;
+  }
+  // buf = d.ddddde[+-]XX
+  std::string s(buf);
+  bool neg = s[0] == '-';
+  if (neg) s.erase(0, 1);
+  size_t epos = s.find('e');
+  int exp10 = std::atoi(s.c_str() + epos + 1);
+  std::string digits;
+  for (size_t i = 0; i < epos; ++i) if (s[i] != '.') digits += s[i];
+  while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+  const int len = int(digits.size());
+  const int kk = exp10 + 1;      // position of the decimal point relative to digits start
+  const int k = kk - len;        // exponent of the last digit
+  const int hi = is32 ? 13 : 16, lo = is32 ? -6 : -5;
+  std::string out = neg ? "-" : "";
+  if (0 <= k && kk <= hi) { out += digits + std::string(k, '0') + ".0"; }
+  else if (0 < kk && kk <= hi) { out += digits.substr(0, kk) + "." + digits.substr(kk); }
+  else if (lo < kk && kk <= 0) { out += "0." + std::string(-kk, '0') + digits; }
+  else if (len == 1) { out += digits + "e" + std::to_string(kk - 1); }
+  else { out += digits.substr(0, 1) + "." + digits.substr(1) + "e" + std::to_string(kk - 1); }
+  return out;
+}
+std::string f64s(double x) { return shortest<double>(x, 17, false); }
+std::string f32s(float x) { return shortest<float>(x, 9, true); }
+std::string jstr(const std::string& s) {
+  std::string o = "\"";
+  for (unsigned char c : s) {
+    if (c == '"') o += "\\\"";
+    else if (c == '\\') o += "\\\\";
+    else if (c == '\n') o += "\\n";
+    else if (c == '\r') o += "\\r";
+    else if (c == '\t') o += "\\t";
+    else if (c < 0x20) { char b[8]; std::snprintf(b, sizeof b, "\\u%04x", c); o += b; }
+    else o += char(c);
+  }
+  return o + "\"";
+}
+std::string point(const double p[3]) {
+  return "{\"x\":" + f64s(p[0]) + ",\"y\":" + f64s(p[1]) + ",\"z\":" + f64s(p[2]) + "}";
+}
+std::string albedo(const float a[3]) { return "[" + f32s(a[0]) + "," + f32s(a[1]) + "," + f32s(a[2]) + "]"; }
+
+std::string scene_json(const RtSceneFile& sf) {
+  const RtScene& sc = sf.scene;
+  std::string o = "{\"width\":" + std::to_string(sc.width) + ",\"height\":" + std::to_string(sc.height) +
+                  ",\"samples_per_pixel\":" + std::to_string(sc.samples_per_pixel) +
+                  ",\"max_depth\":" + std::to_string(sc.max_depth) + ",\"sky\":";
+  if (sc.sky_mode == RT_SKY_NONE) o += "null";
+  else o += "{\"texture\":" + jstr(sc.sky_mode == RT_SKY_TEXTURE ? sf.sky_path : std::string()) + "}";
+  o += ",\"camera\":{\"look_from\":" + point(sf.look_from) + ",\"look_at\":" + point(sf.look_at) +
+       ",\"vup\":" + point(sf.vup) + ",\"vfov\":" + f64s(sf.vfov) + ",\"aspect\":" + f64s(sf.aspect) + "},\"objects\":[";
+  for (size_t i = 0; i < sf.spheres.size(); ++i) {
+    const RtSphere& s = sf.spheres[i];
+    if (i) o += ",";
+    o += "{\"center\":" + point(s.center) + ",\"radius\":" + f64s(s.radius) + ",\"material\":{";
+    switch (s.kind) {
+      case RT_MAT_LAMBERTIAN: o += "\"Lambertian\":{\"albedo\":" + albedo(s.albedo) + "}"; break;
+      case RT_MAT_METAL: o += "\"Metal\":{\"albedo\":" + albedo(s.albedo) + ",\"fuzz\":" + f64s(s.fuzz_or_ior) + "}"; break;
+      case RT_MAT_GLASS: o += "\"Glass\":{\"index_of_refraction\":" + f64s(s.fuzz_or_ior) + "}"; break;
+      case RT_MAT_TEXTURE:  // materials.rs:28-33: pixels always serialize as "/tmp/texture.jpg"
+        o += "\"Texture\":{\"albedo\":" + albedo(s.albedo) + ",\"pixels\":\"/tmp/texture.jpg\",\"width\":" +
+             std::to_string(s.tex_w) + ",\"height\":" + std::to_string(s.tex_h) + ",\"h_offset\":" + f64s(s.h_offset) + "}";
+        break;
+      default: o += "\"Light\":{}"; break;
+    }
+    o += "}}";
+  }
+  return o + "]}";
+}
+
+}  // namespace
+
+extern "C" const char* rt_host_last_error(void) { return g_err.c_str(); }
+
+extern "C" int rt_scene_load_string(const char* json_text, size_t len, RtSceneFile** out) {
+  if (!json_text || !out) return set_err(RT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  std::unique_ptr<RtSceneFile> sf(new RtSceneFile);
+  try {
+    rtjson::ValuePtr root = rtjson::parse(json_text, len);
+    build_scene(*root, *sf);
+  } catch (const rtjson::ParseError& e) {
+    return set_err(RT_ERR_PARSE, std::string("Unable to parse config json: ") + e.what());
+  } catch (const SchemaError& e) {
+    bool tex = e.msg.rfind("texture ", 0) == 0 || e.msg.rfind("sky texture ", 0) == 0;
+    return set_err(tex ? RT_ERR_TEXTURE : RT_ERR_PARSE, (tex ? std::string() : std::string("Unable to parse config json: ")) + e.msg);
+  }
+  *out = sf.release();
+  return RT_OK;
+}
+
+extern "C" int rt_scene_load_file(const char* json_path, RtSceneFile** out) {
+  if (!json_path || !out) return set_err(RT_ERR_INVALID, "null argument");
+  FILE* f = std::fopen(json_path, "rb");
+  if (!f) return set_err(RT_ERR_IO, std::string("Unable to read config file. (") + json_path + ": " + std::strerror(errno) + ")");
+  std::string text; char buf[65536]; size_t n;
+  while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+  std::fclose(f);
+  return rt_scene_load_string(text.data(), text.size(), out);
+}
+
+extern "C" const RtScene* rt_scene_get(const RtSceneFile* sf) { return sf ? &sf->scene : nullptr; }
+extern "C" RtScene* rt_scene_get_mut(RtSceneFile* sf) { return sf ? &sf->scene : nullptr; }
+extern "C" void rt_scene_free(RtSceneFile* sf) { delete sf; }
+extern "C" void rt_free(void* p) { std::free(p); }
+
+extern "C" int rt_scene_to_json(const RtSceneFile* sf, char* buf, size_t cap, size_t* needed) {
+  if (!sf) return set_err(RT_ERR_INVALID, "null scene");
+  std::string s = scene_json(*sf);
+  if (needed) *needed = s.size() + 1;
+  if (buf && cap) {
+    size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
+    std::memcpy(buf, s.data(), n);
+    buf[n] = 0;
+  }
+  return (buf && cap > s.size()) || !buf ? RT_OK : RT_ERR_INVALID;
+}
+
+// reference raytracer.rs:33-42 write_image: PNG, 8-bit RGB, non-interlaced
+extern "C" int rt_png_write_rgb8(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h) {
+  if (!path || !rgb8 || !w || !h) return set_err(RT_ERR_INVALID, "bad png arguments");
+  const size_t stride = size_t(w) * 3;
+  std::vector<uint8_t> raw((stride + 1) * h);
+  for (uint32_t y = 0; y < h; ++y) {  // filter type 1 (Sub) compresses rendered images well
+    uint8_t* dst = &raw[(stride + 1) * y];
+    const uint8_t* src = rgb8 + stride * y;
+    dst[0] = 1;
+    for (size_t i = 0; i < stride; ++i) dst[1 + i] = uint8_t(src[i] - (i >= 3 ? src[i - 3] : 0));
+  }
+  uLongf zlen = compressBound(uLong(raw.size()));
+  std::vector<uint8_t> z(zlen);
+  if (compress2(z.data(), &zlen, raw.data(), uLong(raw.size()), 6) != Z_OK) return set_err(RT_ERR_PNG, "error writing image (deflate)");
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return set_err(RT_ERR_PNG, std::string("error writing image: ") + std::strerror(errno));
+  auto be32 = [](uint8_t* p, uint32_t v) { p[0] = uint8_t(v >> 24); p[1] = uint8_t(v >> 16); p[2] = uint8_t(v >> 8); p[3] = uint8_t(v); };
+  auto chunk = [&](const char* type, const uint8_t* data, uint32_t n) {
+    uint8_t hdr[8]; be32(hdr, n); std::memcpy(hdr + 4, type, 4);
+    uLong crc = crc32(0L, hdr + 4, 4);
+    if (n) crc = crc32(crc, data, n);
+    uint8_t tail[4]; be32(tail, uint32_t(crc));
+    return std::fwrite(hdr, 1, 8, f) == 8 && (!n || std::fwrite(data, 1, n, f) == n) && std::fwrite(tail, 1, 4, f) == 4;
+  };
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+  uint8_t ihdr[13]; be32(ihdr, w); be32(ihdr + 4, h);
+  ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+  bool ok = std::fwrite(sig, 1, 8, f) == 8 && chunk("IHDR", ihdr, 13) && chunk("IDAT", z.data(), uint32_t(zlen)) && chunk("IEND", nullptr, 0);
+  ok = (std::fclose(f) == 0) && ok;
+  return ok ? RT_OK : set_err(RT_ERR_PNG, "error writing image");
+}

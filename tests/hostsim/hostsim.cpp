@@ -1,0 +1,97 @@
+// hostsim.cpp — DEVELOPMENT/TEST TOOL, not part of the product.
+// Compiles the megakernel's per-lane logic (rust-raytracer_amd/csrc/hip/rt_core.h) for the
+// CPU with a trivial one-lane-at-a-time driver, so the state machine, RNG addressing, cull
+// margin and forward colour map can be checked against the oracle without a GPU.  The
+// product never loads this; librt_hip.so has no CPU fallback.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../rust-raytracer_amd/csrc/hip/rt_tables.h"
+
+using namespace rtc;
+
+namespace {
+template <bool HL>
+void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, const RtRowTiles* tiles, uint8_t* rgb8,
+                 float* linear, RtStats* stats, int use_cull) {
+  const uint32_t rows = rt_tiles_local_rows(sc.height, tiles);
+  uint64_t segs = 0, exact = 0, oob = 0, cull_false_reject = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : segs, exact, oob, cull_false_reject)
+  for (uint32_t lr = 0; lr < rows; ++lr) {
+    const uint32_t y = rt_tiles_global_row(tiles, lr);
+    for (uint32_t x = 0; x < sc.width; ++x) {
+      Lane<HL> L;
+      std::memset(&L, 0, sizeof L);
+      L.ra.pixel = y * sc.width + x; L.ra.k0 = ds.seed_lo; L.ra.k1 = ds.seed_hi;
+      bool need_new = true;
+      for (;;) {
+        if (need_new) {
+          if (L.s >= sc.samples_per_pixel) break;
+          lane_begin_sample(ds, L, x, y);
+          need_new = false;
+        }
+        // ---- trace: f32 cull + exact confirm, object order
+        const double a = length_squared(L.d);
+        const RayF32 rf = make_ray_f32(L.o, L.d);
+        double closest = T_MAX; int best = -1;
+        L.n_segments++;
+        for (uint32_t i = 0; i < sc.n_spheres; ++i) {
+          const CullPair& cp = t.cull[i / 2];
+          bool pass = cull_pass(cull_disc(rf, cp.cx[i & 1], cp.cy[i & 1], cp.cz[i & 1], cp.R[i & 1]));
+          if (use_cull == 2) {  // audit mode: run the exact test anyway and flag false rejects
+            double r = exact_root(L.o, L.d, a, t.geom[i], T_MIN, closest);
+            if (r >= 0.0 && !pass) cull_false_reject++;
+            pass = true;
+          }
+          if (!use_cull) pass = true;
+          if (!pass) continue;
+          L.n_exact++;
+          double r = exact_root(L.o, L.d, a, t.geom[i], T_MIN, closest);
+          if (r >= 0.0) { closest = r; best = (int)i; }
+        }
+        need_new = lane_shade(ds, L, best, closest);
+      }
+      float scale = 1.0f / (float)sc.samples_per_pixel;
+      for (int k = 0; k < 3; ++k) {
+        float lin = scale * L.acc[k];
+        size_t o = ((size_t)lr * sc.width + x) * 3 + k;
+        if (linear) linear[o] = lin;
+        if (rgb8) rgb8[o] = f32_to_u8(sqrtf(lin));
+      }
+      segs += L.n_segments; exact += L.n_exact; oob += L.n_tex_oob;
+    }
+  }
+  if (stats) {
+    stats->samples = (uint64_t)rows * sc.width * sc.samples_per_pixel;
+    stats->segments = segs; stats->sphere_tests = segs * sc.n_spheres; stats->exact_tests = exact;
+    stats->tex_oob = oob; stats->kernel_ms = (double)cull_false_reject; stats->frame_ms = 0;
+  }
+}
+}  // namespace
+
+// use_cull: 0 = exact test for every sphere, 1 = product behaviour (cull + confirm),
+//           2 = audit (stats->kernel_ms returns the number of false rejects; must be 0)
+extern "C" int hostsim_render(const RtScene* scene, const RtRowTiles* tiles, uint8_t* rgb8, float* linear,
+                              RtStats* stats, int use_cull) {
+  HostTables t;
+  if (!scene || !build_tables(*scene, t).empty()) return RT_ERR_INVALID;
+  DevScene ds;
+  fill_dev_scene(*scene, t, ds);
+  std::vector<uint8_t> blob(t.tex_bytes ? t.tex_bytes : 1);
+  for (uint32_t i = 0; i < scene->n_textures; ++i)
+    if (scene->textures[i].nbytes) std::memcpy(&blob[t.tex_off[i]], scene->textures[i].rgb8, scene->textures[i].nbytes);
+  ds.geom = t.geom.data(); ds.mat = t.mat.data(); ds.cull = t.cull.data(); ds.lights = t.lights.data();
+  ds.tex = blob.data(); ds.sky = scene->sky_rgb8;
+  if (t.lights.empty()) render_rows<false>(*scene, t, ds, tiles, rgb8, linear, stats, use_cull);
+  else render_rows<true>(*scene, t, ds, tiles, rgb8, linear, stats, use_cull);
+  return RT_OK;
+}
+
+extern "C" float hostsim_cull_disc(const double o[3], const double d[3], const RtSphere* s) {
+  float cx, cy, cz, R;
+  build_cull_entry(*s, &cx, &cy, &cz, &R);
+  RayF32 rf = make_ray_f32(v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]));
+  return cull_disc(rf, cx, cy, cz, R);
+}
