@@ -10,11 +10,11 @@
  * Everything in this file is plain C: pointers, sizes, POD structs.  No torch /
  * HIP types appear in signatures (streams and device pointers travel as void*).
  *
- * Three shared libraries implement parts of it:
+ * Two product libraries implement it (the CPU checker under oracle/ reuses the structs
+ * below but is test infrastructure and is never linked into either):
  *   librt_host.so  (C++, product)   scene JSON/JPEG/PNG/camera — the host plumbing
  *                                   that stays on the CPU (main.rs, config.rs, camera.rs)
  *   librt_hip.so   (HIP,  product)  the gfx950 megakernel = render_line/ray_color/hit_world
- *   oracle/librt_oracle.so (C, TEST INFRASTRUCTURE ONLY) the CPU restatement
  */
 #ifndef RT_ABI_H
 #define RT_ABI_H

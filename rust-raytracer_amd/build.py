@@ -1,0 +1,63 @@
+"""In-tree build of the native pieces (no cmake; plain g++ / hipcc command lines)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CXXFLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra"]
+HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), file=sys.stderr, flush=True)
+    subprocess.run(cmd, check=True, cwd=HERE)
+
+
+def _srcs(*rel):
+    return [os.path.join(HERE, r) for r in rel]
+
+
+def build_host(force=False):
+    out = os.path.join(HERE, "librt_host.so")
+    src = _srcs("csrc/host/scene.cpp", "csrc/host/jpeg.cpp")
+    deps = src + _srcs("csrc/host/json.hpp") + [os.path.join(ROOT, "include/rt_abi.h")]
+    if force or _newer(out, deps):
+        _run(["g++", *CXXFLAGS, "-shared", *src, "-o", out, "-lz"])
+    return out
+
+
+def build_hip(force=False):
+    out = os.path.join(HERE, "librt_hip.so")
+    src = _srcs("csrc/hip/rt_hip_api.hip")
+    deps = src + _srcs("csrc/hip/rt_kernel.hip", "csrc/hip/rt_core.h", "csrc/hip/rt_tables.h") + [os.path.join(ROOT, "include/rt_abi.h")]
+    if force or _newer(out, deps):
+        _run(["hipcc", *HIPFLAGS, "-shared", *src, "-o", out])
+    return out
+
+
+def build_cli(force=False):
+    """the `raytracer <config_file> <output_file>` binary (reference main.rs)"""
+    out = os.path.join(HERE, "raytracer")
+    src = _srcs("csrc/host/main.cpp")
+    deps = src + [os.path.join(HERE, "librt_host.so"), os.path.join(HERE, "librt_hip.so")]
+    if os.path.exists(src[0]) and (force or _newer(out, deps)):
+        _run(["g++", *CXXFLAGS, *src, "-o", out, "-L" + HERE, "-lrt_host", "-lrt_hip", "-Wl,-rpath,$ORIGIN"])
+    return out
+
+
+def build_all(force=False):
+    build_host(force)
+    build_hip(force)
+    build_cli(force)
+
+
+if __name__ == "__main__":
+    build_all("--force" in sys.argv)

@@ -1,0 +1,181 @@
+// rt_kernel.hip — the gfx950 megakernel: render_line + ray_color + hit_world of the reference
+// (raytracer/src/raytracer.rs:191-218, 71-165, 44-59) as ONE launch.
+//
+// Shape (CDNA4-first):
+//   * one work-item per pixel, 256-thread workgroups = four 8x8-pixel wave tiles;
+//   * each lane walks ITS samples as a state machine: one loop iteration = one ray segment
+//     (camera-path segment or nested light ray).  A lane whose path ended starts its next
+//     sample immediately, so all 64 lanes enter the sphere scan together every iteration —
+//     the bounce loop has no per-sample divergence, only an end-of-pixel tail;
+//   * hit_world = (a) packed-f32 conservative cull over ALL spheres, two spheres per
+//     v_pk_* instruction, the sphere table broadcast through the scalar cache into SGPRs
+//     (wave-uniform index -> s_load, zero VGPRs / zero LDS bandwidth for the table);
+//     (b) survivors are appended to a per-lane candidate list in LDS; (c) each lane then
+//     runs the reference's exact f64 Sphere::hit on ITS OWN candidates, in object order,
+//     so accepted hits are bit-identical to the CPU oracle;
+//   * Philox4x32-10 per lane, addressed by (pixel, sample, node, slot);
+//   * RGB8 framebuffer written once per pixel.
+#include <hip/hip_runtime.h>
+
+#include "rt_core.h"
+
+namespace rtk {
+using namespace rtc;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct KArgs {
+  DevScene sc;
+  uint8_t* out_rgb8;
+  float* out_linear;
+  unsigned long long* counters;  // [0] segments, [1] exact tests, [2] tex_oob
+  uint32_t local_rows, tile_rows, first_tile, tile_stride;
+};
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+constexpr int TILE_W = 16, TILE_H = 16;  // block tile; wave tile is 8x8
+constexpr int CAND_SLOTS = 32;           // per-lane candidate capacity between flushes
+constexpr int SCAN_CHUNK = 8;            // pairs per chunk (16 spheres); flush if count > SLOTS-16
+
+// constant-address-space views: a wave-uniform index into these becomes s_load_dwordx8
+typedef const float __attribute__((address_space(4))) * CullPtrK;  // 8 floats per CullPair
+
+__device__ __forceinline__ f32x2 splat(float x) { return f32x2{x, x}; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <bool HL, int VARIANT>
+__global__ __launch_bounds__(BLOCK) void rt_megakernel(const KArgs ka) {
+  const DevScene& sc = ka.sc;
+  __shared__ uint16_t lds_cand[WAVES][CAND_SLOTS][64];
+
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t tiles_x = (sc.width + TILE_W - 1) / TILE_W;
+  const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+  const uint32_t px = bx * TILE_W + (wave & 1u) * 8u + (lane & 7u);
+  const uint32_t lr = by * TILE_H + (wave >> 1) * 8u + (lane >> 3);  // local (packed) row
+  // max_depth == 0: ray_color returns black before tracing anything (raytracer.rs:80-82)
+  bool alive = px < sc.width && lr < ka.local_rows && sc.max_depth != 0u;
+  uint32_t py = lr;  // global scanline (raytracer.rs:255: band index, 0 = top)
+  if (ka.tile_rows != 0u) py = (ka.first_tile + (lr / ka.tile_rows) * ka.tile_stride) * ka.tile_rows + lr % ka.tile_rows;
+
+  Lane<HL> L;
+  L.s = 0; L.k = 0; L.node = 0; L.in_light = 0;
+  L.acc[0] = L.acc[1] = L.acc[2] = 0.0f;
+  L.n_segments = L.n_exact = L.n_tex_oob = 0;
+  L.ra.pixel = py * sc.width + px; L.ra.sample = 0; L.ra.k0 = sc.seed_lo; L.ra.k1 = sc.seed_hi;
+  L.o = v3(0, 0, 0); L.d = v3(0, 0, 1);
+  fwd_init(L.fwd);
+  if constexpr (HL) L.ls.top = 0;
+
+  uint16_t* const my_cand = &lds_cand[wave][0][0] + lane;
+  const CullPtrK cull = (CullPtrK)(uintptr_t)sc.cull;
+  const uint32_t n_pairs = sc.n_pairs, n_spheres = sc.n_spheres;
+  bool need_new = true;
+
+  for (;;) {
+    if (alive && need_new) {
+      if (L.s >= sc.spp) alive = false;
+      else { lane_begin_sample(sc, L, px, py); need_new = false; }
+    }
+    if (!__any(alive)) break;
+
+    // ------------------------------------------------------------ hit_world (raytracer.rs:44-59)
+    const double a = length_squared(L.d);
+    double closest = T_MAX;
+    int best = -1;
+    uint32_t count = 0;
+
+    auto confirm = [&]() {  // exact Sphere::hit on this lane's own candidates, object order
+      for (uint32_t c = 0; __any(c < count); ++c) {
+        if (c < count) {
+          const uint32_t idx = my_cand[c * 64u];
+          const SphereGeom g = sc.geom[idx];
+          const double r = exact_root(L.o, L.d, a, g, T_MIN, closest);
+          L.n_exact++;
+          if (r >= 0.0) { closest = r; best = (int)idx; }
+        }
+      }
+      count = 0;
+    };
+
+    if constexpr (VARIANT == 1) {
+      // validation variant: the reference's brute force, exact test on every sphere
+      for (uint32_t i = 0; i < n_spheres; ++i) {
+        if (alive) {
+          const double r = exact_root(L.o, L.d, a, sc.geom[i], T_MIN, closest);
+          L.n_exact++;
+          if (r >= 0.0) { closest = r; best = (int)i; }
+        }
+      }
+    } else {
+      const RayF32 rf = make_ray_f32(L.o, L.d);
+      const f32x2 ox = splat(rf.ox), oy = splat(rf.oy), oz = splat(rf.oz);
+      const f32x2 dx = splat(rf.dx), dy = splat(rf.dy), dz = splat(rf.dz);
+      const f32x2 Ko = splat(rf.Ko), Am1 = splat(CULL_A - 1.0f);
+      for (uint32_t base = 0; base < n_pairs; base += SCAN_CHUNK) {
+        if (__any(count > (uint32_t)(CAND_SLOTS - 2 * SCAN_CHUNK))) confirm();
+#pragma unroll
+        for (int u = 0; u < SCAN_CHUNK; ++u) {
+          const uint32_t pi = base + u;
+          if (pi >= n_pairs) break;
+          const CullPtrK cp = cull + (size_t)pi * 8u;  // {cx0,cx1,cy0,cy1,cz0,cz1,R0,R1}
+          const f32x2 ocx = ox - f32x2{cp[0], cp[1]};
+          const f32x2 ocy = oy - f32x2{cp[2], cp[3]};
+          const f32x2 ocz = oz - f32x2{cp[4], cp[5]};
+          const f32x2 b = pk_fma(ocz, dz, pk_fma(ocy, dy, ocx * dx));
+          const f32x2 q = pk_fma(ocz, ocz, pk_fma(ocy, ocy, ocx * ocx));
+          const f32x2 t = pk_fma(q, Am1, f32x2{cp[6], cp[7]} + Ko);
+          const f32x2 disc = pk_fma(b, b, t);
+          if (alive && !(disc.x < 0.0f)) { my_cand[count * 64u] = (uint16_t)(2u * pi); count++; }
+          if (alive && !(disc.y < 0.0f) && 2u * pi + 1u < n_spheres) { my_cand[count * 64u] = (uint16_t)(2u * pi + 1u); count++; }
+        }
+      }
+      confirm();
+    }
+
+    // ------------------------------------------------------------ ray_color body
+    if (alive) {
+      L.n_segments++;
+      need_new = lane_shade(sc, L, best, closest);
+    }
+  }
+
+  // raytracer.rs:207-216: mean, sqrt gamma, f32 -> u8, store
+  if (px < sc.width && lr < ka.local_rows) {
+    const float scale = 1.0f / (float)sc.spp;
+    const size_t o = ((size_t)lr * sc.width + px) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float lin = scale * L.acc[k];
+      if (ka.out_linear) ka.out_linear[o + k] = lin;
+      ka.out_rgb8[o + k] = f32_to_u8(__builtin_sqrtf(lin));
+    }
+  }
+
+  // counters: wave reduction, one atomic per wave
+  unsigned long long c0 = L.n_segments, c1 = L.n_exact, c2 = L.n_tex_oob;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    c0 += __shfl_down(c0, off); c1 += __shfl_down(c1, off); c2 += __shfl_down(c2, off);
+  }
+  if (lane == 0) {
+    atomicAdd(&ka.counters[0], c0); atomicAdd(&ka.counters[1], c1);
+    if (c2) atomicAdd(&ka.counters[2], c2);
+  }
+}
+
+// --------------------------------------------------------------------------- device self-test
+// f64 sqrt / divide / f32 sqrt must be correctly rounded on the GPU for bit-parity with the CPU
+// oracle; tests/test_gpu_parity.py checks these against numpy.
+__global__ void rt_math_probe(const double* x, const double* y, double* out_sqrt, double* out_div, float* out_sqrtf,
+                              double* out_atan2, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out_sqrt[i] = sqrt(x[i]);
+  out_div[i] = x[i] / y[i];
+  out_sqrtf[i] = __builtin_sqrtf((float)x[i]);
+  out_atan2[i] = atan2(x[i] - 0.5, y[i] - 0.5);
+}
+
+}  // namespace rtk

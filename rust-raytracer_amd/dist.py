@@ -1,0 +1,50 @@
+"""Multi-GPU frame sharding: interleaved scanline tiles + ONE gather at frame end.
+
+The reference parallelises over scanlines inside one process (rayon, raytracer.rs:255-262).
+Across GPUs the same decomposition is used: tile k (TILE_ROWS scanlines) belongs to rank
+k mod G — interleaved because row cost is very non-uniform (sky rows are 1 segment/sample,
+ground rows 3+).  Pixels are independent and the RNG is addressed by GLOBAL pixel index, so
+the assembled frame is bit-identical for every G.  There is no intra-frame communication;
+the only collective is one `gather` of the packed RGB8 tiles to rank 0 (RCCL over xGMI when
+the backend is "nccl", gloo in the CPU tests).  The renderer is a parameter: this module
+never imports a renderer itself.
+"""
+import torch
+import torch.distributed as dist
+
+from . import abi
+
+TILE_ROWS = 8
+
+
+def shard(rank, world, tile_rows=TILE_ROWS):
+    """RtRowTiles for `rank` of `world` (None = whole frame when world == 1)."""
+    if world <= 1:
+        return None
+    return abi.RtRowTiles(tile_rows, rank, world)
+
+
+def max_local_rows(height, world, tile_rows=TILE_ROWS):
+    return max(abi.tiles_local_rows(height, shard(r, world, tile_rows)) for r in range(world))
+
+
+def gather_frame(local_rgb8, height, width, rank, world, tile_rows=TILE_ROWS, dst=0):
+    """local_rgb8: uint8 tensor [max_local_rows, width, 3] on this rank's device (rows beyond
+    this rank's share are padding).  Returns the assembled [height, width, 3] frame on `dst`,
+    None elsewhere.  One collective."""
+    if world <= 1:
+        return local_rgb8[:height]
+    pad_rows = max_local_rows(height, world, tile_rows)
+    assert local_rgb8.shape[0] == pad_rows, (local_rgb8.shape, pad_rows)
+    if rank == dst:
+        parts = [torch.empty_like(local_rgb8) for _ in range(world)]
+        dist.gather(local_rgb8, parts, dst=dst)
+        frame = torch.empty((height, width, 3), dtype=torch.uint8, device=local_rgb8.device)
+        for r in range(world):  # de-interleave: packed local rows -> global scanlines
+            rows = abi.tiles_global_rows(height, shard(r, world, tile_rows))
+            if rows:
+                idx = torch.as_tensor(rows, device=local_rgb8.device, dtype=torch.long)
+                frame.index_copy_(0, idx, parts[r][: len(rows)])
+        return frame
+    dist.gather(local_rgb8, None, dst=dst)
+    return None

@@ -1,0 +1,94 @@
+"""librt_hip.so — the gfx950 megakernel behind the C ABI (include/rt_abi.h), via ctypes.
+
+This module is the product's only compute path.  It raises ImportError when the HIP library
+has not been built and RtError(RT_ERR_NO_DEVICE) when no GPU is visible: there is no CPU
+fallback, by design.  torch is used by callers only to own device buffers and streams; this
+module passes raw device pointers.
+"""
+import ctypes as C
+import os
+
+from . import abi
+from .host import RtError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing — build it with __graft_entry__.build(); "
+                              "there is no CPU fallback for the hot path")
+        L = C.CDLL(LIB_PATH)
+        L.rt_hip_device_count.restype = C.c_int
+        L.rt_hip_last_error.restype = C.c_char_p
+        L.rt_strerror.argtypes = [C.c_int]
+        L.rt_strerror.restype = C.c_char_p
+        L.rt_hip_scene_create.argtypes = [C.POINTER(abi.RtScene), C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_hip_scene_destroy.argtypes = [C.c_void_p]
+        L.rt_hip_scene_destroy.restype = None
+        L.rt_hip_render.argtypes = [C.c_void_p, C.POINTER(abi.RtRowTiles), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_hip_wait.argtypes = [C.c_void_p, C.POINTER(abi.RtStats)]
+        L.rt_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.rt_render_rgb8.argtypes = [C.POINTER(abi.RtScene), C.c_void_p, C.POINTER(abi.RtStats)]
+        L.rt_hip_math_probe.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != abi.RT_OK:
+        L = lib()
+        raise RtError(rc, f"{L.rt_strerror(rc).decode()}: {L.rt_hip_last_error().decode('utf-8', 'replace')}")
+
+
+def device_count():
+    return lib().rt_hip_device_count()
+
+
+class HipScene:
+    """Scene tables + textures resident in HBM of one GPU (rt_hip_scene_create)."""
+
+    def __init__(self, scene_ptr, device=0):
+        self._h = C.c_void_p()
+        _check(lib().rt_hip_scene_create(scene_ptr, device, C.byref(self._h)))
+        sc = scene_ptr.contents
+        self.width, self.height = sc.width, sc.height
+        self.device = device
+
+    def set_option(self, key, value):
+        _check(lib().rt_hip_set_option(self._h, key.encode(), int(value)))
+
+    def render(self, d_rgb8, d_linear=0, tiles=None, stream=0):
+        """enqueue the megakernel; d_* are raw device pointers (ints), stream a hipStream_t"""
+        _check(lib().rt_hip_render(self._h, C.byref(tiles) if tiles is not None else None,
+                                   C.c_void_p(d_rgb8), C.c_void_p(d_linear or None), C.c_void_p(stream or None)))
+
+    def wait(self):
+        st = abi.RtStats()
+        _check(lib().rt_hip_wait(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def close(self):
+        if self._h:
+            lib().rt_hip_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def render_rgb8(scene_ptr):
+    """rt_render_rgb8: host scene in, host RGB8 out (numpy [h,w,3]) + stats"""
+    import numpy as np
+    sc = scene_ptr.contents
+    out = np.zeros((sc.height, sc.width, 3), np.uint8)
+    st = abi.RtStats()
+    _check(lib().rt_render_rgb8(scene_ptr, out.ctypes.data, C.byref(st)))
+    return out, st.as_dict()

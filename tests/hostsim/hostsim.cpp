@@ -28,7 +28,7 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
       bool need_new = true;
       for (;;) {
         if (need_new) {
-          if (L.s >= sc.samples_per_pixel) break;
+          if (L.s >= sc.samples_per_pixel || sc.max_depth == 0) break;
           lane_begin_sample(ds, L, x, y);
           need_new = false;
         }

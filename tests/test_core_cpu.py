@@ -1,0 +1,124 @@
+"""CPU-side checks of the kernel's per-lane logic (rt_core.h compiled for the host by
+tests/hostsim — a development tool, not a product path) against the oracle, plus the
+oracle against its frozen golden vectors.  The real parity tests run on the GPU
+(tests/test_gpu_parity.py)."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import dvec
+from parity import assert_parity
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = {
+    "cover_96x64_spp4": ("cover", 96, 64, 4, 50, 0),
+    "cover_60x40_spp2_seed7": ("cover", 60, 40, 2, 50, 7),
+    "test_80x60_spp4": ("test", 80, 60, 4, 8, 0),
+    "test_40x30_spp8_depth50": ("test", 40, 30, 8, 50, 3),
+    "cover_tex_64x36_spp4": ("cover4k_tex", 64, 36, 4, 50, 0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_matches_golden(name, oracle, abi, load_scene):
+    scene, w, h, spp, depth, seed = CASES[name]
+    sc = load_scene(scene, w, h, spp, depth, seed)
+    rgb, lin, st = oracle.render(abi, sc.ptr)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    assert st["samples"] == int(g["samples"]) == w * h * spp
+    # bit-exact on the machine that made them; libm's atan2 is the only non-IEEE input, so
+    # allow a texel flip or two on a different CPU
+    assert int((rgb != g["rgb8"]).sum()) <= 3 and np.abs(lin - g["linear"]).max() <= (0.0 if "cover_9" in name or "cover_6" in name else 0.05)
+    if "cover_9" in name or "cover_6" in name:  # no textures, no libm: exactly reproducible
+        assert st["segments"] == int(g["segments"]) and np.array_equal(rgb, g["rgb8"]) and np.array_equal(lin, g["linear"])
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_core_matches_oracle(name, hostsim, oracle, abi, load_scene):
+    scene, w, h, spp, depth, seed = CASES[name]
+    sc = load_scene(scene, w, h, spp, depth, seed)
+    o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+    for mode in (1, 0):  # product behaviour (cull + exact confirm), then exact test on every sphere
+        rgb, lin, st = hostsim.render(sc.ptr, None, mode)
+        assert_parity(rgb, lin, o_rgb, o_lin, f"{name} mode {mode}")
+        assert st["samples"] == o_st["samples"]
+        if sc.lights():  # the kernel skips the light loops the reference computes and discards (raytracer.rs:124)
+            assert st["segments"] <= o_st["segments"]
+        else:
+            assert st["segments"] == o_st["segments"]
+    assert st["exact_tests"] == st["sphere_tests"]
+
+
+def test_cull_never_rejects_a_hit_in_scenes(hostsim, load_scene):
+    """audit mode: every sphere gets the exact test AND the cull; false rejects must be 0"""
+    for scene, w, h, spp, depth in (("cover", 120, 80, 4, 50), ("test", 80, 60, 4, 8), ("cover4k_tex", 64, 36, 2, 50)):
+        sc = load_scene(scene, w, h, spp, depth)
+        _, _, st = hostsim.render(sc.ptr, None, 2)
+        assert st["kernel_ms"] == 0.0, f"{scene}: {st['kernel_ms']} false rejects"
+        _, _, st1 = hostsim.render(sc.ptr, None, 1)
+        assert st1["exact_tests"] < 0.02 * st1["sphere_tests"] or sc.c.n_spheres < 16  # and it actually culls
+
+
+def test_cull_margin_adversarial(hostsim, oracle, abi):
+    """Near-tangent rays at many scales and offsets from the origin: whenever the exact f64
+    Sphere::hit (sphere.rs:46-58) accepts, the f32 cull must pass (disc >= 0 or NaN)."""
+    rng = np.random.default_rng(1234)
+    L = oracle.lib(abi)
+    out = (C.c_double * 10)()
+    n_hit = n_checked = 0
+    for trial in range(40000):
+        scale = 10.0 ** rng.uniform(-3, 3.5)
+        offs = 10.0 ** rng.uniform(-2, 4) * rng.standard_normal(3) if trial % 3 else np.zeros(3)
+        c = offs + scale * rng.standard_normal(3)
+        r = scale * 10.0 ** rng.uniform(-2, 1) * (1 if trial % 7 else -1)
+        n = rng.standard_normal(3); n /= np.linalg.norm(n)
+        tdir = np.cross(n, rng.standard_normal(3)); tdir /= np.linalg.norm(tdir)
+        grazing = abs(r) * (1.0 + rng.choice([-1, 1]) * 10.0 ** rng.uniform(-16, -3))
+        p = c + n * grazing
+        dist = abs(r) * 10.0 ** rng.uniform(-2, 3)
+        dlen = 10.0 ** rng.uniform(-3, 3)
+        o = p - tdir * dist
+        d = tdir * dlen
+        s = abi.RtSphere(radius=r)
+        for i in range(3):
+            s.center[i] = c[i]
+        hit = L.rt_oracle_sphere_hit(dvec(*c), r, dvec(*o), dvec(*d), 0.001, math.inf, out)
+        disc = hostsim.hostsim_cull_disc(dvec(*o), dvec(*d), C.byref(s))
+        n_checked += 1
+        if hit:
+            n_hit += 1
+            assert not (disc < 0.0), (trial, disc, c, r, o, d)
+    assert n_hit > n_checked // 10
+
+
+def test_row_tiles_are_bit_identical(hostsim, oracle, abi, load_scene):
+    """RNG is addressed by global pixel index: any tiling reproduces the full frame exactly."""
+    sc = load_scene("cover", 40, 27, 2, 50)
+    full_rgb, full_lin, _ = oracle.render(abi, sc.ptr)
+    for world in (2, 3):
+        for rank in range(world):
+            t = abi.RtRowTiles(8, rank, world)
+            rows = abi.tiles_global_rows(27, t)
+            rgb, lin, _ = oracle.render(abi, sc.ptr, t)
+            assert np.array_equal(rgb, full_rgb[rows]) and np.array_equal(lin, full_lin[rows])
+            rgb2, lin2, _ = hostsim.render(sc.ptr, t, 1)
+            assert_parity(rgb2, lin2, full_rgb[rows], full_lin[rows])
+
+
+def test_degenerate_scenes(hostsim, oracle, abi, host):
+    """edge cases: empty world, max_depth 0/1, single pixel column, null sky, light-only"""
+    base = ('{"width":9,"height":5,"samples_per_pixel":3,"max_depth":%d,"sky":%s,"camera":{"look_from":{"x":0.0,"y":0.0,"z":0.0},'
+            '"look_at":{"x":0.0,"y":0.0,"z":-1.0},"vup":{"x":0.0,"y":1.0,"z":0.0},"vfov":90.0,"aspect":1.8},"objects":[%s]}')
+    lam = '{"center":{"x":0.0,"y":0.0,"z":-1.0},"radius":0.5,"material":{"Lambertian":{"albedo":[0.8,0.3,0.3]}}}'
+    light = '{"center":{"x":0.0,"y":3.0,"z":-1.0},"radius":1.0,"material":{"Light":{}}}'
+    bright = '{"center":{"x":0.0,"y":-100.5,"z":-1.0},"radius":100.0,"material":{"Metal":{"albedo":[1.5,0.2,2.0],"fuzz":0.3}}}'
+    for depth in (0, 1, 2, 5):
+        for sky in ("null", '{"texture":""}'):
+            for objs in ("", lam, lam + "," + light, light + "," + lam + "," + light + "," + bright):
+                sc = host.Scene.loads(base % (depth, sky, objs))
+                o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+                rgb, lin, st = hostsim.render(sc.ptr, None, 1)
+                assert_parity(rgb, lin, o_rgb, o_lin, f"depth {depth} sky {sky} objs {len(objs)}")

@@ -1,0 +1,56 @@
+"""N>1 path on CPU: two processes (gloo), each renders its interleaved scanline tiles, ONE
+gather assembles the frame on rank 0 (rust-raytracer_amd/dist.py).  The row renderer here
+is the oracle (tests may use it); on the GPU box bench.py plugs the HIP megakernel into the
+same shard/gather code with backend nccl (= RCCL)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, w, h, out_path):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    os.chdir(ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = graft.load_package()
+        oracle = graft.load_oracle()
+        from rust_raytracer_amd import dist as rdist
+        sc = pkg.host.Scene.load("scenes/cfg2_cover_1200x800_spp128.json")
+        sc.c.width, sc.c.height, sc.c.samples_per_pixel = w, h, 2
+        tiles = rdist.shard(rank, world)
+        rgb, _, _ = oracle.render(pkg.abi, sc.ptr, tiles, n_threads=2, want_linear=False)
+        pad = rdist.max_local_rows(h, world)
+        local = torch.zeros((pad, w, 3), dtype=torch.uint8)
+        local[: rgb.shape[0]] = torch.from_numpy(rgb)
+        frame = rdist.gather_frame(local, h, w, rank, world)
+        if rank == 0:
+            np.save(out_path, frame.numpy())
+        else:
+            assert frame is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("w,h", [(40, 30), (33, 8), (16, 5)])  # ragged: last tile short / fewer tiles than ranks
+def test_two_rank_gather_matches_single(tmp_path, oracle, abi, load_scene, w, h):
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(2, _free_port(), w, h, out), nprocs=2, join=True)
+    sc = load_scene("cover", w, h, 2)
+    full, _, _ = oracle.render(abi, sc.ptr, want_linear=False)
+    assert np.array_equal(np.load(out), full)

@@ -1,0 +1,129 @@
+"""Host plumbing (librt_host.so): the JSON scene schema round-trips of the reference
+(config.rs:78-147, sphere.rs:91-137, camera.rs:125-141, materials.rs:279-283), error
+behaviour of main.rs:14-15, JPEG decode and PNG output."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+CFG_DEFAULT_SKY = ('{"width":100,"height":100,"samples_per_pixel":1,"max_depth":1,"sky":{"texture":""},"camera":{"look_from":{"x":0.0,"y":0.0,"z":0.0},'
+                   '"look_at":{"x":0.0,"y":0.0,"z":-1.0},"vup":{"x":0.0,"y":1.0,"z":0.0},"vfov":90.0,"aspect":1.0},"objects":[{"center":{"x":0.0,"y":0.0,"z":-1.0},'
+                   '"radius":0.5,"material":{"Lambertian":{"albedo":[0.8,0.3,0.3]}}}]}')
+CFG_NULL_SKY = CFG_DEFAULT_SKY.replace('"sky":{"texture":""}', '"sky":null')
+
+
+def test_config_roundtrip_default_sky(host, abi):
+    """config.rs:78-102 test_to_json: exact serde_json string."""
+    sc = host.Scene.loads(CFG_DEFAULT_SKY)
+    assert sc.to_json() == CFG_DEFAULT_SKY
+    assert sc.c.sky_mode == abi.RT_SKY_GRADIENT and sc.c.n_spheres == 1
+    assert list(sc.c.spheres[0].albedo) == [np.float32(0.8), np.float32(0.3), np.float32(0.3)]
+
+
+def test_config_roundtrip_null_sky_and_sky_texture(host, abi):
+    """config.rs:104-147 test_sky_perms_to_from_json."""
+    sc = host.Scene.loads(CFG_NULL_SKY)
+    assert sc.to_json() == CFG_NULL_SKY and sc.c.sky_mode == abi.RT_SKY_NONE
+    tex = CFG_DEFAULT_SKY.replace('"sky":{"texture":""}', '"sky":{"texture":"scenes/data/earth.jpg"}')
+    sc = host.Scene.loads(tex)
+    assert sc.c.sky_mode == abi.RT_SKY_TEXTURE and (sc.c.sky_w, sc.c.sky_h) == (2048, 1024)
+    assert sc.to_json() == tex
+
+
+def test_sphere_and_texture_json(host, abi):
+    """sphere.rs:91-137: Lambertian sphere string; Texture serialises pixels as
+    "/tmp/texture.jpg" (materials.rs:28-33) and loads them from the given path."""
+    base = CFG_DEFAULT_SKY[:CFG_DEFAULT_SKY.index('"objects":')]
+    lam = '{"center":{"x":0.0,"y":0.0,"z":0.0},"radius":1.0,"material":{"Lambertian":{"albedo":[0.5,0.5,0.5]}}}'
+    sc = host.Scene.loads(base + '"objects":[' + lam + "]}")
+    assert sc.to_json().endswith('"objects":[' + lam + "]}")
+    tload = ('{"center":{"x":0.0,"y":0.0,"z":0.0},"radius":1.0,"material":{"Texture":{"albedo":[0.5,0.5,0.5],"pixels":"scenes/data/earth.jpg",'
+             '"width":2048,"height":1024,"h_offset":0.0}}}')
+    sc = host.Scene.loads(base + '"objects":[' + tload + "," + tload + "]}")
+    assert sc.to_json().endswith(tload.replace("scenes/data/earth.jpg", "/tmp/texture.jpg") + "]}")
+    assert sc.c.n_textures == 1  # same path decoded once, shared
+    t = sc.c.textures[0]
+    assert (t.width, t.height, t.nbytes) == (2048, 1024, 2048 * 1024 * 3)
+    px = host.jpeg_decode("scenes/data/earth.jpg")
+    assert np.array_equal(np.ctypeslib.as_array(t.rgb8, shape=(t.nbytes,)), px.reshape(-1))
+
+
+def test_camera_and_metal_json(host):
+    """camera.rs:125-141 (aspect `(800/600) as f64` == 1.0), materials.rs:279-283."""
+    cam = '"camera":{"look_from":{"x":-4.0,"y":4.0,"z":1.0},"look_at":{"x":0.0,"y":0.0,"z":-1.0},"vup":{"x":0.0,"y":1.0,"z":0.0},"vfov":160.0,"aspect":1.0}'
+    metal = '{"center":{"x":0.0,"y":0.0,"z":0.0},"radius":1.0,"material":{"Metal":{"albedo":[0.8,0.8,0.8],"fuzz":2.0}}}'
+    text = '{"width":8,"height":6,"samples_per_pixel":1,"max_depth":1,"sky":null,' + cam + ',"objects":[' + metal + "]}"
+    sc = host.Scene.loads(text)
+    assert sc.to_json() == text
+    d = host.camera_derive([-4, 4, 1], [0, 0, -1], [0, 1, 0], 160.0, 1.0)
+    assert list(sc.c.cam_origin) == d["origin"] and list(sc.c.cam_lower_left) == d["lower_left_corner"]
+    assert list(sc.c.cam_horizontal) == d["horizontal"] and list(sc.c.cam_vertical) == d["vertical"]
+
+
+def test_reference_scenes_load(host, abi):
+    """config.rs:249-255 test_from_file + the committed benchmark configs."""
+    sc = host.Scene.load("scenes/cfg1_test_800x600_spp16.json")
+    c = sc.c
+    assert (c.width, c.height, c.samples_per_pixel, c.max_depth) == (800, 600, 16, 8)
+    assert c.n_spheres == 7 and c.n_textures == 2 and c.sky_mode == abi.RT_SKY_TEXTURE and (c.sky_w, c.sky_h) == (2410, 1205)
+    kinds = [c.spheres[i].kind for i in range(7)]
+    assert kinds == [abi.RT_MAT_TEXTURE, abi.RT_MAT_TEXTURE, abi.RT_MAT_METAL, abi.RT_MAT_LIGHT, abi.RT_MAT_METAL, abi.RT_MAT_GLASS, abi.RT_MAT_GLASS]
+    assert c.spheres[6].radius == -0.45 and sc.lights() == [3]
+    sc = host.Scene.load("scenes/cfg2_cover_1200x800_spp128.json")
+    c = sc.c
+    assert (c.width, c.height, c.samples_per_pixel, c.max_depth, c.n_spheres) == (1200, 800, 128, 50, 484)
+    kinds = np.array([c.spheres[i].kind for i in range(484)])
+    assert [(kinds == k).sum() for k in range(5)] == [407, 56, 21, 0, 0]  # SURVEY §2 census
+    # a serde round trip of the whole file reproduces every number (shortest-repr floats)
+    again = host.Scene.loads(sc.to_json())
+    assert again.to_json() == sc.to_json()
+    assert json.loads(sc.to_json()) == json.load(open("scenes/cfg2_cover_1200x800_spp128.json"))
+
+
+@pytest.mark.parametrize("text,code", [
+    ("{", "RT_ERR_PARSE"), ('{"width":1}', "RT_ERR_PARSE"), (CFG_DEFAULT_SKY.replace('"width":100', '"width":-1'), "RT_ERR_PARSE"),
+    (CFG_DEFAULT_SKY.replace('"width":100', '"width":1.5'), "RT_ERR_PARSE"), (CFG_DEFAULT_SKY.replace("Lambertian", "Plastic"), "RT_ERR_PARSE"),
+    (CFG_DEFAULT_SKY.replace('[0.8,0.3,0.3]', '[0.8,0.3]'), "RT_ERR_PARSE"),
+    (CFG_DEFAULT_SKY.replace('"sky":{"texture":""}', '"sky":{"texture":"nope.jpg"}'), "RT_ERR_TEXTURE"),
+])
+def test_errors_instead_of_panics(host, abi, text, code):
+    """main.rs:14-15 / materials.rs:214 expect() panics become error codes."""
+    with pytest.raises(host.RtError) as e:
+        host.Scene.loads(text)
+    assert e.value.code == getattr(abi, code)
+
+
+def test_missing_file(host, abi):
+    with pytest.raises(host.RtError) as e:
+        host.Scene.load("/nonexistent/scene.json")
+    assert e.value.code == abi.RT_ERR_IO and "Unable to read config file." in str(e.value)
+
+
+def test_unknown_fields_ignored_and_int_floats(host):
+    """serde ignores unknown fields and accepts integer literals for f64 fields."""
+    t = CFG_DEFAULT_SKY.replace('"radius":0.5', '"radius":2,"extra":[1,{"a":null}]')
+    assert host.Scene.loads(t).c.spheres[0].radius == 2.0
+
+
+@pytest.mark.parametrize("name", ["earth", "moon", "beach"])
+def test_jpeg_decoder_close_to_libjpeg(host, name):
+    """materials.rs:213-219: texel values are decoder-specific (unpinned by the reference);
+    ours stay within a few levels of libjpeg (PIL) incl. 4:2:0 fancy upsampling (beach)."""
+    from PIL import Image
+    a = host.jpeg_decode(f"scenes/data/{name}.jpg").astype(int)
+    b = np.asarray(Image.open(f"scenes/data/{name}.jpg").convert("RGB")).astype(int)
+    assert a.shape == b.shape
+    d = np.abs(a - b)
+    assert d.max() <= 4 and d.mean() < 0.1
+
+
+def test_png_write_roundtrip(host, tmp_path):
+    """raytracer.rs:33-42 write_image: RGB8 PNG, lossless."""
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    p = str(tmp_path / "x.png")
+    host.png_write(p, img)
+    back = Image.open(p)
+    assert back.mode == "RGB" and back.size == (53, 37) and np.array_equal(np.asarray(back), img)

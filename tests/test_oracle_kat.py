@@ -1,0 +1,158 @@
+"""Pin the CPU oracle against every known-answer test the reference holds for the hot path
+(SURVEY.md §8c).  Each test cites the reference test it replays (paths relative to
+/root/reference/raytracer/src/).  The oracle is test infrastructure; see oracle/rt_oracle.h."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from conftest import dvec
+
+
+def test_philox_random123_kat(oracle, abi):
+    """Philox4x32-10 known answers (Random123 kat_vectors)."""
+    L = oracle.lib(abi)
+    pi = [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]
+    cases = [([0] * 4, [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+             ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+             (pi, [0xa4093822, 0x299f31d0], [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in cases:
+        out = (C.c_uint32 * 4)()
+        L.rt_oracle_philox4x32_10((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+        assert list(out) == want
+
+
+def test_sphere_hit(oracle, abi):
+    """sphere.rs:82-88 test_sphere_hit: t == 4.0 exactly."""
+    out = (C.c_double * 10)()
+    hit = oracle.lib(abi).rt_oracle_sphere_hit(dvec(0, 0, 0), 1.0, dvec(0, 0, -5), dvec(0, 0, 1), 0.0, math.inf, out)
+    assert hit == 1 and out[0] == 4.0
+    assert list(out[1:4]) == [0.0, 0.0, -1.0] and list(out[4:7]) == [0.0, 0.0, -1.0] and out[7] == 1.0
+
+
+def test_sphere_hit_inside_and_negative_radius(oracle, abi):
+    """sphere.rs:57-68: second root from inside; negative radius flips the outward normal
+    (hollow glass, data/test_scene.json:137)."""
+    L = oracle.lib(abi)
+    out = (C.c_double * 10)()
+    assert L.rt_oracle_sphere_hit(dvec(0, 0, 0), 1.0, dvec(0, 0, 0), dvec(0, 0, 1), 0.001, math.inf, out) == 1
+    assert out[0] == 1.0 and out[7] == 0.0 and list(out[4:7]) == [-0.0, -0.0, -1.0]
+    assert L.rt_oracle_sphere_hit(dvec(0, 0, 0), -1.0, dvec(0, 0, -5), dvec(0, 0, 1), 0.001, math.inf, out) == 1
+    assert out[0] == 4.0 and out[7] == 0.0  # normal (p-c)/r points along +z: same side as the ray
+    assert L.rt_oracle_sphere_hit(dvec(0, 0, 0), 1.0, dvec(0, 5, -5), dvec(0, 0, 1), 0.001, math.inf, out) == 0
+    # strict inequalities: root == t_max is rejected (sphere.rs:58)
+    assert L.rt_oracle_sphere_hit(dvec(0, 0, 0), 1.0, dvec(0, 0, -5), dvec(0, 0, 1), 0.001, 4.0, out) == 0
+
+
+def test_refract(oracle, abi):
+    """materials.rs:158-165 test_refract."""
+    out = (C.c_double * 3)()
+    oracle.lib(abi).rt_oracle_refract(dvec(1, 1, 0), dvec(-1, 0, 0), 1.0, out)
+    assert list(out) == [0.0, 1.0, 0.0]
+
+
+def test_reflectance(oracle, abi):
+    """materials.rs:168-174 test_reflectance."""
+    assert oracle.lib(abi).rt_oracle_reflectance(0.0, 1.5) == 1.0
+
+
+def test_reflect(oracle, abi):
+    """materials.rs:111-113 reflect = v - 2(v.n)n."""
+    out = (C.c_double * 3)()
+    oracle.lib(abi).rt_oracle_reflect(dvec(1, -1, 0), dvec(0, 1, 0), out)
+    assert list(out) == [1.0, 1.0, 0.0]
+
+
+def test_ray_color_sky(oracle, abi, host):
+    """raytracer.rs:168-189 test_ray_color: empty world, dir (1,0,0), default sky ->
+    Srgb(0.75, 0.85, 1.0), exact f32 equality."""
+    cam = host.camera_derive([0, 0, -3], [0, 0, 0], [0, 1, 0], 20.0, 1.333)
+    sc = abi.RtScene(abi_version=abi.RT_ABI_VERSION, width=80, height=60, samples_per_pixel=1, max_depth=2,
+                     sky_mode=abi.RT_SKY_GRADIENT)
+    for i in range(3):
+        sc.cam_origin[i] = cam["origin"][i]; sc.cam_lower_left[i] = cam["lower_left_corner"][i]
+        sc.cam_horizontal[i] = cam["horizontal"][i]; sc.cam_vertical[i] = cam["vertical"][i]
+    out = (C.c_float * 3)()
+    oracle.lib(abi).rt_oracle_ray_color(C.byref(sc), dvec(0, 0, 0), dvec(1, 0, 0), 2, 2, 0, 0, out)
+    assert list(out) == [np.float32(0.75), np.float32(0.85), np.float32(1.0)]
+    sc.sky_mode = abi.RT_SKY_NONE  # config.rs: sky null -> black (raytracer.rs:138-140)
+    oracle.lib(abi).rt_oracle_ray_color(C.byref(sc), dvec(0, 0, 0), dvec(1, 0, 0), 2, 2, 0, 0, out)
+    assert list(out) == [0.0, 0.0, 0.0]
+    sc.sky_mode = abi.RT_SKY_GRADIENT  # depth 0 -> black (raytracer.rs:80-82)
+    oracle.lib(abi).rt_oracle_ray_color(C.byref(sc), dvec(0, 0, 0), dvec(1, 0, 0), 2, 0, 0, 0, out)
+    assert list(out) == [0.0, 0.0, 0.0]
+
+
+def test_camera(oracle, abi, host):
+    """camera.rs:88-103 test_camera, :106-122 test_camera_get_ray (`(800/600) as f64` == 1.0)."""
+    out = (C.c_double * 13)()
+    oracle.lib(abi).rt_oracle_camera_new(dvec(0, 0, 0), dvec(0, 0, -1), dvec(0, 1, 0), 90.0, 800.0 / 600.0, out)
+    assert list(out[0:3]) == [0, 0, 0]
+    assert out[3] == pytest.approx(-(1.0 + 1.0 / 3.0), abs=1e-6)
+    assert out[4] == pytest.approx(-1.0, abs=1e-6) and out[5] == pytest.approx(-1.0, abs=1e-6)
+    # product host code computes the identical camera (bitwise)
+    assert host.camera_derive([0, 0, 0], [0, 0, -1], [0, 1, 0], 90.0, 800.0 / 600.0)["lower_left_corner"] == list(out[3:6])
+
+    cam = (C.c_double * 13)()
+    oracle.lib(abi).rt_oracle_camera_new(dvec(-4, 4, 1), dvec(0, 0, -1), dvec(0, 1, 0), 160.0, 1.0, cam)
+    sc = abi.RtScene(abi_version=abi.RT_ABI_VERSION, width=1, height=1)
+    for i in range(3):
+        sc.cam_origin[i] = cam[i]; sc.cam_lower_left[i] = cam[3 + i]; sc.cam_horizontal[i] = cam[6 + i]; sc.cam_vertical[i] = cam[9 + i]
+    ray = (C.c_double * 6)()
+    oracle.lib(abi).rt_oracle_get_ray(C.byref(sc), 0.5, 0.5, ray)
+    assert list(ray[0:3]) == [-4.0, 4.0, 1.0]
+    assert ray[3] == pytest.approx(2.0 / 3.0, abs=1e-6)
+    assert ray[4] == pytest.approx(-2.0 / 3.0, abs=1e-6)
+    assert ray[5] == pytest.approx(-1.0 / 3.0, abs=1e-6)
+    assert cam[12] == pytest.approx(6.0)  # focal_length = |look_from - look_at|
+
+
+def test_find_lights(oracle, abi, host):
+    """raytracer.rs:232-248 test_find_lights + object order preserved."""
+    sph = (abi.RtSphere * 3)()
+    sph[0].kind = abi.RT_MAT_LIGHT; sph[1].kind = abi.RT_MAT_LAMBERTIAN; sph[2].kind = abi.RT_MAT_LIGHT
+    out = (C.c_uint32 * 3)()
+    assert oracle.lib(abi).rt_oracle_find_lights(sph, 2, out, 3) == 1
+    assert oracle.lib(abi).rt_oracle_find_lights(sph, 3, out, 3) == 2 and list(out[:2]) == [0, 2]
+    assert host.lib().rt_find_lights(sph, 3, out, 3) == 2 and list(out[:2]) == [0, 2]
+
+
+def test_draw_ranges(oracle, abi):
+    """point3d.rs:259-264 test_random (bounds) + gen::<f64>() in [0,1)."""
+    L = oracle.lib(abi)
+    u = (C.c_double * 2)(); r = (C.c_double * 3)()
+    us, rs = [], []
+    for i in range(2000):
+        L.rt_oracle_draws(7, i, i * 3, i % 5, i % 3, u, r)
+        us += list(u); rs += list(r)
+    us, rs = np.array(us), np.array(rs)
+    assert us.min() >= 0.0 and us.max() < 1.0 and rs.min() >= -1.0 and rs.max() < 1.0
+    assert abs(us.mean() - 0.5) < 0.02 and abs(rs.mean()) < 0.04 and abs(rs.std() - 1 / math.sqrt(3)) < 0.02
+    # counter-based: same address, same draw; different seed, different draw
+    L.rt_oracle_draws(7, 1, 2, 3, 4, u, r); a = list(u) + list(r)
+    L.rt_oracle_draws(7, 1, 2, 3, 4, u, r); assert a == list(u) + list(r)
+    L.rt_oracle_draws(8, 1, 2, 3, 4, u, r); assert a != list(u) + list(r)
+
+
+def test_f32_to_u8(oracle, abi):
+    """raytracer.rs:213 into_format(): round-half-even(min(x*255,255)), negatives -> 0."""
+    f = oracle.lib(abi).rt_oracle_f32_to_u8
+    assert [f(0.0), f(1.0), f(2.0), f(-1.0), f(0.5), f(1.5 / 255), f(2.5 / 255), f(0.999)] == [0, 255, 255, 0, 128, 2, 2, 255]
+
+
+def test_texture_albedo(oracle, abi, host):
+    """materials.rs:236-254 get_albedo: nearest texel, h_offset wrap, width/height from JSON."""
+    px = host.jpeg_decode("scenes/data/earth.jpg")
+    assert px.shape == (1024, 2048, 3)  # config.rs:145 / sphere.rs:120 pin 2048x1024
+    flat = np.ascontiguousarray(px).reshape(-1)
+    tex = abi.RtTexture(flat.ctypes.data_as(C.POINTER(C.c_uint8)), flat.size, 2048, 1024)
+    s = abi.RtSphere(kind=abi.RT_MAT_TEXTURE, tex_w=2048, tex_h=1024, h_offset=0.75)
+    out = (C.c_float * 3)()
+    for u, v in ((0.1, 0.2), (0.5, 0.5), (0.3, 0.99), (0.0, 0.0), (0.26, 1.0)):
+        oracle.lib(abi).rt_oracle_texture_albedo(C.byref(s), C.byref(tex), u, v, out)
+        rot = u + 0.75
+        rot = rot - 1.0 if rot > 1.0 else rot
+        x, y = int(math.floor(rot * 2048)), int(math.floor((1.0 - v) * 1023))
+        want = px[y, x].astype(np.float32) / np.float32(255.0)
+        assert list(out) == list(want)
