@@ -48,6 +48,11 @@ struct CullPair {  // 32 B
   float cx[2], cy[2], cz[2], R[2];
 };
 
+#ifndef RT_CULL_CHUNK
+#define RT_CULL_CHUNK 4
+#endif
+constexpr uint32_t CULL_CHUNK = RT_CULL_CHUNK;  // pairs per scan chunk; the table is padded to this
+
 struct DevScene {
   uint32_t width, height, spp, max_depth;
   uint32_t sky_mode, n_spheres, n_lights, n_pairs;
@@ -132,7 +137,14 @@ struct RngAddr {
   uint32_t pixel, sample, k0, k1;
 };
 RT_HD U4 rng(const RngAddr& a, uint32_t node, uint32_t slot) {
-  return philox4x32_10(a.pixel, a.sample, node, slot, a.k0, a.k1);
+  uint32_t k0 = a.k0, k1 = a.k1;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the key is wave-uniform; without this the compiler hoists all 20 round keys out of the
+  // path loop and pins 20 SGPRs for the whole kernel (they are 18 s_adds to recompute)
+  k0 = __builtin_amdgcn_readfirstlane(k0); k1 = __builtin_amdgcn_readfirstlane(k1);
+  asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
+  return philox4x32_10(a.pixel, a.sample, node, slot, k0, k1);
 }
 // point3d.rs:22-38
 RT_HD V3 random_in_unit_sphere(const RngAddr& a, uint32_t node) {

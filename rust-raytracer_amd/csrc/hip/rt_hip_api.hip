@@ -132,7 +132,7 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
 
 extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) {
   if (!s || !key) return fail(RT_ERR_INVALID, "null argument");
-  if (!std::strcmp(key, "variant")) { if (value < 0 || value > 1) return fail(RT_ERR_INVALID, "variant must be 0 or 1"); s->variant = (int)value; return RT_OK; }
+  if (!std::strcmp(key, "variant")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "variant must be 0, 1 or 2"); s->variant = (int)value; return RT_OK; }
   if (!std::strcmp(key, "samples_per_pixel")) { s->host.samples_per_pixel = s->dev.spp = (uint32_t)value; return RT_OK; }
   if (!std::strcmp(key, "max_depth")) { s->host.max_depth = s->dev.max_depth = (uint32_t)value; return RT_OK; }
   if (!std::strcmp(key, "seed")) { s->host.seed = (uint64_t)value; s->dev.seed_lo = (uint32_t)value; s->dev.seed_hi = (uint32_t)((uint64_t)value >> 32); return RT_OK; }
@@ -161,9 +161,11 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   RT_HIP_TRY(hipEventRecord(s->ev_start, stream));
   if (s->has_lights) {
     if (s->variant == 1) hipLaunchKernelGGL((rtk::rt_megakernel<true, 1>), grid, block, 0, stream, ka);
+    else if (s->variant == 2) hipLaunchKernelGGL((rtk::rt_megakernel<true, 2>), grid, block, 0, stream, ka);
     else hipLaunchKernelGGL((rtk::rt_megakernel<true, 0>), grid, block, 0, stream, ka);
   } else {
     if (s->variant == 1) hipLaunchKernelGGL((rtk::rt_megakernel<false, 1>), grid, block, 0, stream, ka);
+    else if (s->variant == 2) hipLaunchKernelGGL((rtk::rt_megakernel<false, 2>), grid, block, 0, stream, ka);
     else hipLaunchKernelGGL((rtk::rt_megakernel<false, 0>), grid, block, 0, stream, ka);
   }
   RT_HIP_TRY(hipGetLastError());

@@ -32,6 +32,12 @@ struct KArgs {
   uint32_t local_rows, tile_rows, first_tile, tile_stride;
 };
 
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_ATTR
+#else
+#define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
+#endif
+
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
 constexpr int TILE_W = 16, TILE_H = 16;  // block tile; wave tile is 8x8
@@ -45,7 +51,7 @@ __device__ __forceinline__ f32x2 splat(float x) { return f32x2{x, x}; }
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 template <bool HL, int VARIANT>
-__global__ __launch_bounds__(BLOCK) void rt_megakernel(const KArgs ka) {
+__global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs ka) {
   const DevScene& sc = ka.sc;
   __shared__ uint16_t lds_cand[WAVES][CAND_SLOTS][64];
 
@@ -113,22 +119,52 @@ __global__ __launch_bounds__(BLOCK) void rt_megakernel(const KArgs ka) {
       const f32x2 ox = splat(rf.ox), oy = splat(rf.oy), oz = splat(rf.oz);
       const f32x2 dx = splat(rf.dx), dy = splat(rf.dy), dz = splat(rf.dz);
       const f32x2 Ko = splat(rf.Ko), Am1 = splat(CULL_A - 1.0f);
-      for (uint32_t base = 0; base < n_pairs; base += SCAN_CHUNK) {
-        if (__any(count > (uint32_t)(CAND_SLOTS - 2 * SCAN_CHUNK))) confirm();
+      // one pair = two spheres in 12 packed-f32 instructions; cp = 8 wave-uniform floats (SGPRs)
+      auto test_pair = [&](const float* cp, uint32_t pi) {
+        const f32x2 ocx = ox - f32x2{cp[0], cp[1]};
+        const f32x2 ocy = oy - f32x2{cp[2], cp[3]};
+        const f32x2 ocz = oz - f32x2{cp[4], cp[5]};
+        const f32x2 b = pk_fma(ocz, dz, pk_fma(ocy, dy, ocx * dx));
+        const f32x2 q = pk_fma(ocz, ocz, pk_fma(ocy, ocy, ocx * ocx));
+        const f32x2 t = pk_fma(q, Am1, f32x2{cp[6], cp[7]} + Ko);
+        const f32x2 disc = pk_fma(b, b, t);
+        const bool p0 = !(disc.x < 0.0f), p1 = !(disc.y < 0.0f);
+        if (alive && (p0 || p1)) {  // one branch per pair; survivors are rare (~2 of 484 per lane)
+          if (p0 && 2u * pi < n_spheres) { my_cand[count * 64u] = (uint16_t)(2u * pi); count++; }
+          if (p1 && 2u * pi + 1u < n_spheres) { my_cand[count * 64u] = (uint16_t)(2u * pi + 1u); count++; }
+        }
+      };
+      if constexpr (VARIANT == 0) {
+        // software-pipelined scan: the s_loads of chunk k+1 are issued after the first pair of
+        // chunk k, so their latency hides behind three pairs of VALU work (the table is padded
+        // by one chunk, rt_tables.h, so the last prefetch stays in bounds)
+        const uint32_t n_chunks = (n_pairs + CULL_CHUNK - 1u) / CULL_CHUNK;
+        float cur[8 * CULL_CHUNK], nxt[8 * CULL_CHUNK];
 #pragma unroll
-        for (int u = 0; u < SCAN_CHUNK; ++u) {
-          const uint32_t pi = base + u;
-          if (pi >= n_pairs) break;
-          const CullPtrK cp = cull + (size_t)pi * 8u;  // {cx0,cx1,cy0,cy1,cz0,cz1,R0,R1}
-          const f32x2 ocx = ox - f32x2{cp[0], cp[1]};
-          const f32x2 ocy = oy - f32x2{cp[2], cp[3]};
-          const f32x2 ocz = oz - f32x2{cp[4], cp[5]};
-          const f32x2 b = pk_fma(ocz, dz, pk_fma(ocy, dy, ocx * dx));
-          const f32x2 q = pk_fma(ocz, ocz, pk_fma(ocy, ocy, ocx * ocx));
-          const f32x2 t = pk_fma(q, Am1, f32x2{cp[6], cp[7]} + Ko);
-          const f32x2 disc = pk_fma(b, b, t);
-          if (alive && !(disc.x < 0.0f)) { my_cand[count * 64u] = (uint16_t)(2u * pi); count++; }
-          if (alive && !(disc.y < 0.0f) && 2u * pi + 1u < n_spheres) { my_cand[count * 64u] = (uint16_t)(2u * pi + 1u); count++; }
+        for (int j = 0; j < 8 * (int)CULL_CHUNK; ++j) cur[j] = cull[j];
+        for (uint32_t ch = 0; ch < n_chunks; ++ch) {
+          if (__any(count > (uint32_t)(CAND_SLOTS - 2 * (int)CULL_CHUNK))) confirm();
+          test_pair(cur, ch * CULL_CHUNK);
+          const CullPtrK np = cull + (size_t)(ch + 1u) * (8u * CULL_CHUNK);
+#pragma unroll
+          for (int j = 0; j < 8 * (int)CULL_CHUNK; ++j) nxt[j] = np[j];
+#pragma unroll
+          for (int u = 1; u < (int)CULL_CHUNK; ++u) test_pair(cur + 8 * u, ch * CULL_CHUNK + u);
+#pragma unroll
+          for (int j = 0; j < 8 * (int)CULL_CHUNK; ++j) cur[j] = nxt[j];
+        }
+      } else {  // VARIANT 2: the first, unpipelined form (kept for A/B timing)
+        for (uint32_t base = 0; base < n_pairs; base += SCAN_CHUNK) {
+          if (__any(count > (uint32_t)(CAND_SLOTS - 2 * SCAN_CHUNK))) confirm();
+#pragma unroll
+          for (int u = 0; u < SCAN_CHUNK; ++u) {
+            const uint32_t pi = base + u;
+            if (pi >= n_pairs) break;
+            float cp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cp[j] = cull[(size_t)pi * 8u + j];
+            test_pair(cp, pi);
+          }
         }
       }
       confirm();

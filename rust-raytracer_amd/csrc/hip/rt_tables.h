@@ -16,6 +16,7 @@ struct HostTables {
   std::vector<uint32_t> lights;
   std::vector<uint64_t> tex_off;  // per RtTexture, byte offset in the blob
   uint64_t tex_bytes = 0;
+  uint32_t n_pairs = 0;           // real pairs (cull.size() includes chunk padding)
   bool simple_colour = true;  // no lights and every albedo in [0,1]
 };
 
@@ -37,7 +38,14 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
   const uint32_t n = sc.n_spheres;
   t.geom.resize(n);
   t.mat.resize(n);
-  t.cull.assign((n + 1) / 2, CullPair{});
+  // pairs, padded to a whole number of CULL_CHUNK-pair chunks plus one chunk of slack so the
+  // scan may prefetch one chunk past the end; padding entries can never pass (R = -inf)
+  const uint32_t n_pairs = (n + 1) / 2;
+  const uint32_t padded = (n_pairs + CULL_CHUNK - 1) / CULL_CHUNK * CULL_CHUNK + CULL_CHUNK;
+  CullPair never;
+  for (int k = 0; k < 2; ++k) { never.cx[k] = never.cy[k] = never.cz[k] = 0.0f; never.R[k] = -INFINITY; }
+  t.cull.assign(padded, never);
+  t.n_pairs = n_pairs;
   t.lights.clear();
   t.simple_colour = true;
   for (uint32_t i = 0; i < n; ++i) {
@@ -62,7 +70,7 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
     CullPair& cp = t.cull[i / 2];
     build_cull_entry(s, &cp.cx[i & 1], &cp.cy[i & 1], &cp.cz[i & 1], &cp.R[i & 1]);
   }
-  if (n & 1) {  // pad: a sphere that can never pass (R = -inf); index n is also guarded at append
+  if (n & 1) {  // odd count: the second half of the last real pair can never pass either
     CullPair& cp = t.cull[n / 2];
     cp.cx[1] = cp.cx[0]; cp.cy[1] = cp.cy[0]; cp.cz[1] = cp.cz[0]; cp.R[1] = -INFINITY;
   }
@@ -74,7 +82,7 @@ inline void fill_dev_scene(const RtScene& sc, const HostTables& t, DevScene& d) 
   std::memset(&d, 0, sizeof d);
   d.width = sc.width; d.height = sc.height; d.spp = sc.samples_per_pixel; d.max_depth = sc.max_depth;
   d.sky_mode = sc.sky_mode; d.n_spheres = sc.n_spheres; d.n_lights = (uint32_t)t.lights.size();
-  d.n_pairs = (uint32_t)t.cull.size();
+  d.n_pairs = t.n_pairs;
   d.seed_lo = (uint32_t)sc.seed; d.seed_hi = (uint32_t)(sc.seed >> 32);
   for (int i = 0; i < 3; ++i) {
     d.cam_origin[i] = sc.cam_origin[i]; d.cam_ll[i] = sc.cam_lower_left[i];

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Within-process interleaved A/B of megakernel builds (cdna guide §5.4 rule 24).
+
+    python tools/ab_bench.py build          # here (no GPU): compile the variant .so files into build/ab/
+    python tools/ab_bench.py run [--rounds R] [--scene S]   # on the GPU box
+
+Every variant must render the identical image (checked against the first one); prints one
+JSON line per variant with the median/min kernel time of the headline frame."""
+import ctypes as C
+import json
+import os
+import statistics
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+AB = os.path.join(ROOT, "build", "ab")
+SRC = os.path.join(ROOT, "rust-raytracer_amd", "csrc", "hip", "rt_hip_api.hip")
+BASE = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# name -> (extra compile flags, runtime variant id)
+VARIANTS = {
+    "w2_ch4": ([], 0),
+    "w3_ch4": (["-DRT_WAVES_PER_EU=3"], 0),
+    "w4_ch4": (["-DRT_WAVES_PER_EU=4"], 0),
+    "w4_ch2": (["-DRT_WAVES_PER_EU=4", "-DRT_CULL_CHUNK=2"], 0),
+    "w4_nopipe": (["-DRT_WAVES_PER_EU=4"], 2),
+    "w5_ch2": (["-DRT_WAVES_PER_EU=5", "-DRT_CULL_CHUNK=2"], 0),
+}
+
+
+def build():
+    os.makedirs(AB, exist_ok=True)
+    for name, (flags, _) in VARIANTS.items():
+        out = os.path.join(AB, f"librt_hip_{name}.so")
+        cmd = BASE + flags + [SRC, "-o", out]
+        print("+", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+
+def bind(path, abi):
+    L = C.CDLL(path)
+    L.rt_hip_scene_create.argtypes = [C.POINTER(abi.RtScene), C.c_int, C.POINTER(C.c_void_p)]
+    L.rt_hip_scene_destroy.argtypes = [C.c_void_p]
+    L.rt_hip_scene_destroy.restype = None
+    L.rt_hip_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rt_hip_wait.argtypes = [C.c_void_p, C.POINTER(abi.RtStats)]
+    L.rt_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.rt_hip_last_error.restype = C.c_char_p
+    return L
+
+
+def run(rounds, scene_path, only):
+    import numpy as np
+    import torch
+    os.chdir(ROOT)
+    pkg = graft.load_package()
+    abi = pkg.abi
+    sc = pkg.host.Scene.load(scene_path)
+    h, w = sc.c.height, sc.c.width
+    rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    libs, ref = {}, None
+    for name, (_, variant) in VARIANTS.items():
+        if only and name not in only:
+            continue
+        path = os.path.join(AB, f"librt_hip_{name}.so")
+        if not os.path.exists(path):
+            continue
+        L = bind(path, abi)
+        hs = C.c_void_p()
+        assert L.rt_hip_scene_create(sc.ptr, 0, C.byref(hs)) == 0, L.rt_hip_last_error()
+        if variant:
+            assert L.rt_hip_set_option(hs, b"variant", variant) == 0
+        libs[name] = (L, hs, [])
+    st = abi.RtStats()
+    for r in range(rounds + 1):  # round 0 = warm-up + image check
+        for name, (L, hs, times) in libs.items():
+            assert L.rt_hip_render(hs, None, rgb.data_ptr(), None, stream) == 0, L.rt_hip_last_error()
+            assert L.rt_hip_wait(hs, C.byref(st)) == 0
+            if r == 0:
+                img = rgb.cpu().numpy()
+                if ref is None:
+                    ref = img
+                assert np.array_equal(img, ref), f"{name}: image differs from the first variant"
+            else:
+                times.append(st.kernel_ms)
+    samples = w * h * sc.c.samples_per_pixel
+    for name, (L, hs, times) in libs.items():
+        med = statistics.median(times)
+        print(json.dumps({"variant": name, "kernel_ms_median": round(med, 3), "kernel_ms_min": round(min(times), 3),
+                          "msamples_per_s": round(samples / med / 1e3, 1), "rounds": rounds,
+                          "exact_per_segment": round(st.exact_tests / max(1, st.segments), 3)}), flush=True)
+        L.rt_hip_scene_destroy(hs)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        build()
+    else:
+        import argparse
+        ap = argparse.ArgumentParser()
+        ap.add_argument("cmd")
+        ap.add_argument("--rounds", type=int, default=5)
+        ap.add_argument("--scene", default="scenes/cfg2_cover_1200x800_spp128.json")
+        ap.add_argument("--only", nargs="*", default=None)
+        a = ap.parse_args()
+        run(a.rounds, a.scene, a.only)
