@@ -213,6 +213,11 @@ RT_HD double exact_root(V3 o, V3 d, double a, const SphereGeom& g, double t_min,
   V3 oc = sub(o, v3(g.cx, g.cy, g.cz));
   double half_b = dot(oc, d);
   double c = length_squared(oc) - g.r * g.r;
+  // Exact shortcut (no tolerance involved): origin outside the sphere (c > 0) and the centre
+  // behind the ray (half_b > 0).  Then a*c >= 0, so sqrtd <= sqrt(fl(half_b^2)) == half_b and
+  // both roots (-half_b -/+ sqrtd)/a are <= 0 < t_min: Sphere::hit rejects.  Half of the cull
+  // survivors of a bounced ray are of this kind; this skips their sqrt and two divisions.
+  if (c > 0.0 && half_b > 0.0) return -1.0;
   double discriminant = (half_b * half_b) - (a * c);
   if (discriminant >= 0.0) {
     double sqrtd = sqrt(discriminant);
@@ -409,7 +414,7 @@ struct Lane {
   uint32_t s;     // current sample
   uint32_t in_light;  // 1 while the current ray is a nested light ray
   Fwd fwd;
-  float acc[3];   // pixel_colors (raytracer.rs:197)
+  float val[3];   // radiance of the sample that just finished (valid when lane_shade returned true)
   RngAddr ra;
   LightState<HAS_LIGHTS> ls;
   // counters
@@ -433,13 +438,29 @@ RT_HD void lane_begin_sample(const DevScene& sc, Lane<HL>& L, uint32_t px, uint3
   fwd_init(L.fwd);
 }
 
-// the sample's radiance is known: fold it through the forward map and accumulate (:203-205)
+// the sample's radiance is known: fold the leaf colour through the forward map.  The caller
+// adds L.val to the pixel (raytracer.rs:203-205) and picks the lane's next sample.
 template <bool HL>
 RT_HD void lane_finish_sample(Lane<HL>& L, Rgb leaf) {
-  L.acc[0] += fwd_eval1(L.fwd, 0, leaf.r);
-  L.acc[1] += fwd_eval1(L.fwd, 1, leaf.g);
-  L.acc[2] += fwd_eval1(L.fwd, 2, leaf.b);
-  L.s += 1;
+  L.val[0] = fwd_eval1(L.fwd, 0, leaf.r);
+  L.val[1] = fwd_eval1(L.fwd, 1, leaf.g);
+  L.val[2] = fwd_eval1(L.fwd, 2, leaf.b);
+}
+
+// Pooled-sample mode: lanes of a wave take (pixel, sample) items from a shared counter, so
+// several lanes add samples of the same pixel in an order the reference does not have.  To
+// stay deterministic the pixel sum is kept in exact 2^-40 fixed point (integer adds are
+// associative): independent of the schedule, of tiling and of the GPU count.  It differs from
+// the reference's sequential f32 sum only by that sum's own rounding (a few 1e-7 relative).
+constexpr double FIX_SCALE = 1099511627776.0;  // 2^40; sample values are in [0,1]
+RT_HD unsigned long long sample_to_fixed(float v) {
+  double x = (double)v;
+  if (!(x > 0.0)) return 0ull;
+  if (x > 1.0) x = 1.0;  // every sample is clamp01'ed at the root level already
+  return (unsigned long long)(x * FIX_SCALE + 0.5);
+}
+RT_HD float fixed_to_mean(unsigned long long sum, uint32_t spp) {
+  return (float)(((double)sum * (1.0 / FIX_SCALE)) / (double)spp);
 }
 
 // Continue the camera path after its hit at level k has been fully evaluated:
@@ -483,7 +504,7 @@ RT_HD bool lane_light_return(const DevScene& sc, Lane<true>& L, Rgb tc) {
 #endif
 
 // Consume the closest hit (idx < 0: miss) of the lane's current ray.  Returns true when the
-// lane's current sample finished (L.s was advanced; the caller starts the next sample).
+// lane's current sample finished (its radiance is in L.val; the caller starts the next one).
 template <bool HL>
 RT_HD bool lane_shade(const DevScene& sc, Lane<HL>& L, int idx, double t) {
   if (idx < 0) {  // raytracer.rs:133-163

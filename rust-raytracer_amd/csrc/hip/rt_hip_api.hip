@@ -40,6 +40,7 @@ struct RtHipScene {
   bool launched = false;
   uint32_t last_rows = 0;
   int variant = 0;
+  int pool = 1;            // 1: pooled samples + exact fixed-point pixel sums; 0: reference f32 order
   std::chrono::steady_clock::time_point t_launch;
 };
 
@@ -133,6 +134,7 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
 extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) {
   if (!s || !key) return fail(RT_ERR_INVALID, "null argument");
   if (!std::strcmp(key, "variant")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "variant must be 0, 1 or 2"); s->variant = (int)value; return RT_OK; }
+  if (!std::strcmp(key, "pool")) { s->pool = value != 0; return RT_OK; }
   if (!std::strcmp(key, "samples_per_pixel")) { s->host.samples_per_pixel = s->dev.spp = (uint32_t)value; return RT_OK; }
   if (!std::strcmp(key, "max_depth")) { s->host.max_depth = s->dev.max_depth = (uint32_t)value; return RT_OK; }
   if (!std::strcmp(key, "seed")) { s->host.seed = (uint64_t)value; s->dev.seed_lo = (uint32_t)value; s->dev.seed_hi = (uint32_t)((uint64_t)value >> 32); return RT_OK; }
@@ -140,7 +142,8 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
 }
 
 extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb8, void* d_linear, void* stream_) {
-  if (!s || !d_rgb8) return fail(RT_ERR_INVALID, "null argument");
+  if (!s) return fail(RT_ERR_INVALID, "null argument");
+  if (!d_rgb8 && rt_tiles_local_rows(s->host.height, tiles) != 0) return fail(RT_ERR_INVALID, "null framebuffer");
   hipStream_t stream = (hipStream_t)stream_;
   RT_HIP_TRY(hipSetDevice(s->device));
   rtk::KArgs ka;
@@ -159,15 +162,22 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   const uint32_t tiles_y = (ka.local_rows + rtk::TILE_H - 1) / rtk::TILE_H;
   const dim3 grid(tiles_x * tiles_y), block(rtk::BLOCK);
   RT_HIP_TRY(hipEventRecord(s->ev_start, stream));
-  if (s->has_lights) {
-    if (s->variant == 1) hipLaunchKernelGGL((rtk::rt_megakernel<true, 1>), grid, block, 0, stream, ka);
-    else if (s->variant == 2) hipLaunchKernelGGL((rtk::rt_megakernel<true, 2>), grid, block, 0, stream, ka);
-    else hipLaunchKernelGGL((rtk::rt_megakernel<true, 0>), grid, block, 0, stream, ka);
-  } else {
-    if (s->variant == 1) hipLaunchKernelGGL((rtk::rt_megakernel<false, 1>), grid, block, 0, stream, ka);
-    else if (s->variant == 2) hipLaunchKernelGGL((rtk::rt_megakernel<false, 2>), grid, block, 0, stream, ka);
-    else hipLaunchKernelGGL((rtk::rt_megakernel<false, 0>), grid, block, 0, stream, ka);
-  }
+  const bool geom_lds = s->host.n_spheres <= rtk::LDS_GEOM_MAX_SPHERES && s->variant != 1;
+  const size_t lds_bytes = rtk::LDS_GEOM_OFF + (geom_lds ? (size_t)s->host.n_spheres * sizeof(rtc::SphereGeom) : 0);
+  const bool pool = s->pool != 0;
+#define RT_LAUNCH(HL, V, G, P) hipLaunchKernelGGL((rtk::rt_megakernel<HL, V, G, P>), grid, block, lds_bytes, stream, ka)
+#define RT_LAUNCH_P(HL, V, G) do { if (pool) RT_LAUNCH(HL, V, G, true); else RT_LAUNCH(HL, V, G, false); } while (0)
+#define RT_LAUNCH_V(HL, G)                                     \
+  do {                                                         \
+    if (s->variant == 1) RT_LAUNCH_P(HL, 1, false);            \
+    else if (s->variant == 2) RT_LAUNCH_P(HL, 2, G);           \
+    else RT_LAUNCH_P(HL, 0, G);                                \
+  } while (0)
+  if (s->has_lights) { if (geom_lds) RT_LAUNCH_V(true, true); else RT_LAUNCH_V(true, false); }
+  else { if (geom_lds) RT_LAUNCH_V(false, true); else RT_LAUNCH_V(false, false); }
+#undef RT_LAUNCH_V
+#undef RT_LAUNCH_P
+#undef RT_LAUNCH
   RT_HIP_TRY(hipGetLastError());
   RT_HIP_TRY(hipEventRecord(s->ev_stop, stream));
   s->launched = true;

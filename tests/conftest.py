@@ -63,6 +63,8 @@ def hostsim(abi):
                                  C.POINTER(abi.RtStats), C.c_int]
     L.hostsim_cull_disc.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(abi.RtSphere)]
     L.hostsim_cull_disc.restype = C.c_float
+    L.hostsim_exact_root.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(abi.RtSphere), C.c_double, C.c_double]
+    L.hostsim_exact_root.restype = C.c_double
 
     def render(scene_ptr, tiles=None, mode=1):
         sc = scene_ptr.contents

@@ -15,7 +15,8 @@ using namespace rtc;
 namespace {
 template <bool HL>
 void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, const RtRowTiles* tiles, uint8_t* rgb8,
-                 float* linear, RtStats* stats, int use_cull) {
+                 float* linear, RtStats* stats, int use_cull_flags) {
+  const int use_cull = use_cull_flags & 15;
   const uint32_t rows = rt_tiles_local_rows(sc.height, tiles);
   uint64_t segs = 0, exact = 0, oob = 0, cull_false_reject = 0;
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : segs, exact, oob, cull_false_reject)
@@ -24,6 +25,8 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
     for (uint32_t x = 0; x < sc.width; ++x) {
       Lane<HL> L;
       std::memset(&L, 0, sizeof L);
+      float acc[3] = {0.f, 0.f, 0.f};                 // accum 0: the reference's sequential f32 sum
+      unsigned long long facc[3] = {0ull, 0ull, 0ull};  // accum 1: exact fixed point (pooled-sample kernels)
       L.ra.pixel = y * sc.width + x; L.ra.k0 = ds.seed_lo; L.ra.k1 = ds.seed_hi;
       bool need_new = true;
       for (;;) {
@@ -52,10 +55,14 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
           if (r >= 0.0) { closest = r; best = (int)i; }
         }
         need_new = lane_shade(ds, L, best, closest);
+        if (need_new) {
+          for (int k = 0; k < 3; ++k) { acc[k] += L.val[k]; facc[k] += sample_to_fixed(L.val[k]); }
+          L.s += 1;
+        }
       }
       float scale = 1.0f / (float)sc.samples_per_pixel;
       for (int k = 0; k < 3; ++k) {
-        float lin = scale * L.acc[k];
+        float lin = (use_cull_flags & 16) ? fixed_to_mean(facc[k], sc.samples_per_pixel) : scale * acc[k];
         size_t o = ((size_t)lr * sc.width + x) * 3 + k;
         if (linear) linear[o] = lin;
         if (rgb8) rgb8[o] = f32_to_u8(sqrtf(lin));
@@ -73,6 +80,7 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
 
 // use_cull: 0 = exact test for every sphere, 1 = product behaviour (cull + confirm),
 //           2 = audit (stats->kernel_ms returns the number of false rejects; must be 0)
+//           +16 = accumulate pixels in exact fixed point (the pooled-sample kernels' rule)
 extern "C" int hostsim_render(const RtScene* scene, const RtRowTiles* tiles, uint8_t* rgb8, float* linear,
                               RtStats* stats, int use_cull) {
   HostTables t;
@@ -94,4 +102,11 @@ extern "C" float hostsim_cull_disc(const double o[3], const double d[3], const R
   build_cull_entry(*s, &cx, &cy, &cz, &R);
   RayF32 rf = make_ray_f32(v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]));
   return cull_disc(rf, cx, cy, cz, R);
+}
+
+// the kernel's exact root selection for one sphere (rt_core.h exact_root), for property tests
+extern "C" double hostsim_exact_root(const double o[3], const double d[3], const RtSphere* s, double t_min, double t_max) {
+  SphereGeom g{s->center[0], s->center[1], s->center[2], s->radius};
+  V3 dd = v3(d[0], d[1], d[2]);
+  return exact_root(v3(o[0], o[1], o[2]), dd, length_squared(dd), g, t_min, t_max);
 }

@@ -94,6 +94,35 @@ def test_cull_margin_adversarial(hostsim, oracle, abi):
     assert n_hit > n_checked // 10
 
 
+def test_exact_root_equals_sphere_hit(hostsim, oracle, abi):
+    """the kernel's root selection (incl. its exact behind-the-ray shortcut) returns exactly the
+    t that the oracle's Sphere::hit accepts, for origins inside/outside/behind and any t_max"""
+    rng = np.random.default_rng(99)
+    L = oracle.lib(abi)
+    out = (C.c_double * 10)()
+    hits = 0
+    for trial in range(30000):
+        c = rng.standard_normal(3) * 10.0 ** rng.uniform(-1, 2)
+        r = 10.0 ** rng.uniform(-2, 2) * (1 if trial % 5 else -1)
+        o = c + rng.standard_normal(3) * abs(r) * 10.0 ** rng.uniform(-1, 1)
+        if trial % 4 == 0:  # start exactly on the surface-ish (bounced rays)
+            n = rng.standard_normal(3); n /= np.linalg.norm(n)
+            o = c + n * abs(r) * (1 + rng.uniform(-1e-12, 1e-12))
+        d = rng.standard_normal(3) * 10.0 ** rng.uniform(-2, 2)
+        t_max = math.inf if trial % 3 else 10.0 ** rng.uniform(-2, 2)
+        s = abi.RtSphere(radius=r)
+        for i in range(3):
+            s.center[i] = c[i]
+        hit = L.rt_oracle_sphere_hit(dvec(*c), r, dvec(*o), dvec(*d), 0.001, t_max, out)
+        got = hostsim.hostsim_exact_root(dvec(*o), dvec(*d), C.byref(s), 0.001, min(t_max, 1.7976931348623157e308))
+        if hit:
+            hits += 1
+            assert got == out[0], (trial, got, out[0])
+        else:
+            assert got < 0.0, (trial, got)
+    assert hits > 5000
+
+
 def test_row_tiles_are_bit_identical(hostsim, oracle, abi, load_scene):
     """RNG is addressed by global pixel index: any tiling reproduces the full frame exactly."""
     sc = load_scene("cover", 40, 27, 2, 50)

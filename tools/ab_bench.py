@@ -20,14 +20,16 @@ import __graft_entry__ as graft  # noqa: E402
 AB = os.path.join(ROOT, "build", "ab")
 SRC = os.path.join(ROOT, "rust-raytracer_amd", "csrc", "hip", "rt_hip_api.hip")
 BASE = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
-# name -> (extra compile flags, runtime variant id)
+# name -> (extra compile flags, runtime options)
 VARIANTS = {
-    "w2_ch4": ([], 0),
-    "w3_ch4": (["-DRT_WAVES_PER_EU=3"], 0),
-    "w4_ch4": (["-DRT_WAVES_PER_EU=4"], 0),
-    "w4_ch2": (["-DRT_WAVES_PER_EU=4", "-DRT_CULL_CHUNK=2"], 0),
-    "w4_nopipe": (["-DRT_WAVES_PER_EU=4"], 2),
-    "w5_ch2": (["-DRT_WAVES_PER_EU=5", "-DRT_CULL_CHUNK=2"], 0),
+    "w2_ch4_pool": ([], {}),
+    "w4_ch4_pool": (["-DRT_WAVES_PER_EU=4"], {}),
+    "w4_ch4_nopool": (["-DRT_WAVES_PER_EU=4"], {"pool": 0}),
+    "w3_ch4_pool": (["-DRT_WAVES_PER_EU=3"], {}),
+    "w4_ch2_pool": (["-DRT_WAVES_PER_EU=4", "-DRT_CULL_CHUNK=2"], {}),
+    "w4_nopipe_pool": (["-DRT_WAVES_PER_EU=4"], {"variant": 2}),
+    "w5_ch2_pool": (["-DRT_WAVES_PER_EU=5", "-DRT_CULL_CHUNK=2"], {}),
+    "w2_nopipe_nopool": ([], {"variant": 2, "pool": 0}),
 }
 
 
@@ -62,8 +64,8 @@ def run(rounds, scene_path, only):
     h, w = sc.c.height, sc.c.width
     rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
-    libs, ref = {}, None
-    for name, (_, variant) in VARIANTS.items():
+    libs, ref = {}, {}
+    for name, (_, opts) in VARIANTS.items():
         if only and name not in only:
             continue
         path = os.path.join(AB, f"librt_hip_{name}.so")
@@ -72,23 +74,22 @@ def run(rounds, scene_path, only):
         L = bind(path, abi)
         hs = C.c_void_p()
         assert L.rt_hip_scene_create(sc.ptr, 0, C.byref(hs)) == 0, L.rt_hip_last_error()
-        if variant:
-            assert L.rt_hip_set_option(hs, b"variant", variant) == 0
-        libs[name] = (L, hs, [])
+        for k, v in opts.items():
+            assert L.rt_hip_set_option(hs, k.encode(), v) == 0
+        libs[name] = (L, hs, [], opts.get("pool", 1))
     st = abi.RtStats()
     for r in range(rounds + 1):  # round 0 = warm-up + image check
-        for name, (L, hs, times) in libs.items():
+        for name, (L, hs, times, pool) in libs.items():
             assert L.rt_hip_render(hs, None, rgb.data_ptr(), None, stream) == 0, L.rt_hip_last_error()
             assert L.rt_hip_wait(hs, C.byref(st)) == 0
             if r == 0:
                 img = rgb.cpu().numpy()
-                if ref is None:
-                    ref = img
-                assert np.array_equal(img, ref), f"{name}: image differs from the first variant"
+                ref.setdefault(pool, img)  # pooled and per-pixel accumulation each have their own bits
+                assert np.array_equal(img, ref[pool]), f"{name}: image differs from the first variant of its accumulation mode"
             else:
                 times.append(st.kernel_ms)
     samples = w * h * sc.c.samples_per_pixel
-    for name, (L, hs, times) in libs.items():
+    for name, (L, hs, times, pool) in libs.items():
         med = statistics.median(times)
         print(json.dumps({"variant": name, "kernel_ms_median": round(med, 3), "kernel_ms_min": round(min(times), 3),
                           "msamples_per_s": round(samples / med / 1e3, 1), "rounds": rounds,
