@@ -6,7 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CXXFLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra"]
-HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+# RT_WAVES_PER_EU=4: cap the megakernel at 128 VGPRs (4 waves/SIMD); measured best of 2/3/4/5 (profiles/r01_run2_ab.log)
+HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-DRT_WAVES_PER_EU=4"]
 
 
 def _newer(target, sources):
