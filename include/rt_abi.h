@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1u
+#define RT_ABI_VERSION 2u
 
 /* Nested light-ray recursion (raytracer.rs:103-110 calls ray_color(.., 2, 1), which can
  * itself trigger light sampling again) is unbounded in the reference.  Oracle and kernel
@@ -119,6 +119,7 @@ typedef struct RtStats {
   uint64_t tex_oob;      /* texture fetches the reference would have panicked on            */
   double kernel_ms;      /* device time of the render kernel(s)                             */
   double frame_ms;       /* wall time of the whole call                                     */
+  uint64_t grid_steps;   /* cells entered by the grid walks of hit_world (0: no grid)       */
 } RtStats;
 
 /* rows this call renders (its packed RGB8 output is rows*width*3 bytes) */
@@ -187,7 +188,10 @@ int rt_hip_render(RtHipScene*, const RtRowTiles* tiles, void* d_rgb8, void* d_li
 /* Block until the last rt_hip_render on this scene finished; fill counters and the HIP-event
  * duration of its kernel (events are recorded on the stream the kernel was launched on). */
 int rt_hip_wait(RtHipScene*, RtStats* stats);
-/* variant selection for A/B benchmarking (0 = default); see DESIGN.md */
+/* Tunables / A-B arms.  Keys: "variant" 0 = grid walk (default), 1 = the
+ * reference's brute force (exact test on every sphere), 2 = round-1 f32 cull-scan kernel;
+ * "chunk_spp" samples of a pixel per work item (0 = automatic); "samples_per_pixel",
+ * "max_depth", "seed" override the scene's values. */
 int rt_hip_set_option(RtHipScene*, const char* key, int64_t value);
 /* Convenience = the drop-in for render()'s parallel loop: host buffers in, host RGB8 out.
  * Blocking; uploads, renders the whole frame on device 0, downloads. */

@@ -499,6 +499,7 @@ int rt_oracle_render(const RtScene* scene, const RtRowTiles* tiles, uint8_t* rgb
     stats->tex_oob = tex_oob;
     stats->kernel_ms = t1 - t0;
     stats->frame_ms = t1 - t0;
+    stats->grid_steps = 0; /* the reference has no acceleration structure (raytracer.rs:52-57) */
   }
   return RT_OK;
 }

@@ -1,7 +1,7 @@
 """ctypes mirror of include/rt_abi.h (plain C ABI; no torch types cross this boundary)."""
 import ctypes as C
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 RT_MAX_LIGHT_NEST = 8
 RT_OK, RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP = 0, -1, -2, -3
 RT_ERR_IO, RT_ERR_PARSE, RT_ERR_TEXTURE, RT_ERR_PNG, RT_ERR_UNSUPPORTED = -4, -5, -6, -7, -8
@@ -38,7 +38,7 @@ class RtRowTiles(C.Structure):
 class RtStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("exact_tests", C.c_uint64), ("tex_oob", C.c_uint64),
-                ("kernel_ms", C.c_double), ("frame_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("frame_ms", C.c_double), ("grid_steps", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -22,9 +22,13 @@
 
 #if defined(__HIPCC__)
 #define RT_HD __host__ __device__ __forceinline__
+// cold paths (texture lookups): a real call, so that their constants (atan2's polynomial) are
+// not hoisted into registers that stay live across the whole path loop
+#define RT_HD_COLD __host__ __device__ __attribute__((noinline))
 #else
 #include <cmath>
 #define RT_HD inline
+#define RT_HD_COLD inline
 #endif
 
 namespace rtc {
@@ -53,6 +57,34 @@ struct CullPair {  // 32 B
 #endif
 constexpr uint32_t CULL_CHUNK = RT_CULL_CHUNK;  // pairs per scan chunk; the table is padded to this
 
+// Material fields every hit needs (24 B; the LDS copy of the material table).  Texture
+// parameters stay in the 64 B SphereMat and are fetched only when a Texture sphere is hit.
+struct MatCore {
+  float albedo[3];
+  uint32_t kind;
+  double fuzz_or_ior;
+};
+
+// Uniform grid over the scene's ordinary spheres (rt_tables.h builds it).  Oversized spheres
+// (the r = 1000 ground of cover_scene.json) are kept out of it in the `large` list, which
+// every ray tests.  Coordinates inside the walk are in CELL UNITS: x_cell = (x - gmin) * inv_cell.
+struct GridDesc {
+  double gmin[3];
+  double inv_cell[3];
+  uint32_t n[3];      // cells per axis; n[0] == 0: no grid (every sphere is in `large`)
+  uint32_t n_large;
+  uint32_t n_cells, n_items;
+};
+constexpr uint32_t GRID_MAX_AXIS = 256;        // cells per axis (bounds the f32 error of the walk)
+constexpr uint32_t CELL_COUNT_SHIFT = 20;      // cell word = first item | (item count << 20)
+constexpr uint32_t CELL_START_MASK = (1u << CELL_COUNT_SHIFT) - 1u;
+constexpr uint32_t CELL_MAX_COUNT = 4095;
+// A sphere is registered in every cell its bounding box, grown by GRID_MARGIN cells, overlaps.
+// The f32 walk is off by at most 6u(n+3) < 1e-4 cells (u = 2^-24, n <= 256; DESIGN.md "Grid
+// walk"), 20x less than the margin, so every cell a true hit point lies in is visited or
+// neighbours a visited cell that lists the sphere as well.
+constexpr float GRID_MARGIN = 0.001953125f;    // 2^-9 cells
+
 struct DevScene {
   uint32_t width, height, spp, max_depth;
   uint32_t sky_mode, n_spheres, n_lights, n_pairs;
@@ -66,6 +98,11 @@ struct DevScene {
   const uint8_t* tex;      // all textures back to back, RGB8
   const uint8_t* sky;      // sky texture RGB8
   uint64_t sky_w, sky_h;
+  GridDesc grid;
+  const uint32_t* cell_word;   // [n_cells] first item | count << 20
+  const uint16_t* cell_items;  // [n_items] sphere indices, object order inside a cell
+  const uint32_t* large;       // [n_large] sphere indices, object order
+  const MatCore* matc;         // [n_spheres]
 };
 
 // ------------------------------------------------------------------ point3d.rs
@@ -231,6 +268,165 @@ RT_HD double exact_root(V3 o, V3 d, double a, const SphereGeom& g, double t_min,
 constexpr double T_MIN = 0.001;                     // raytracer.rs:83
 constexpr double T_MAX = 1.7976931348623157e308;    // f64::MAX
 
+// Order-free form of the closest-hit scan (raytracer.rs:52-57).  The reference walks the
+// spheres in object order and accepts sphere i iff its first root f_i in (t_min, inf) is
+// < closest-so-far (sphere.rs:57-58: the far root is tried only when the near one is outside
+// (t_min, t_max), and far >= near, so a far root is accepted only when near <= t_min).  The
+// scan therefore returns the lexicographic minimum of (f_i, i).  Testing spheres in ANY order
+// with "root < closest, or root == closest and i < best" reaches the same (t, sphere).
+RT_HD bool exact_hit_any_order(V3 o, V3 d, double a, const SphereGeom& g, uint32_t idx, double& closest, int& best) {
+  V3 oc = sub(o, v3(g.cx, g.cy, g.cz));
+  double half_b = dot(oc, d);
+  double c = length_squared(oc) - g.r * g.r;
+  if (c > 0.0 && half_b > 0.0) return false;  // exact shortcut, see exact_root
+  double discriminant = (half_b * half_b) - (a * c);
+  if (discriminant >= 0.0) {
+    const bool tie_ok = best >= 0 && idx < (uint32_t)best;
+    double sqrtd = sqrt(discriminant);
+    double root = ((-half_b) - sqrtd) / a;
+    if (!(root > T_MIN && (root < closest || (tie_ok && root == closest)))) {
+      root = ((-half_b) + sqrtd) / a;
+      if (!(root > T_MIN && (root < closest || (tie_ok && root == closest)))) return false;
+    }
+    closest = root; best = (int)idx;
+    return true;
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------ grid walk (hit_world, raytracer.rs:44-59)
+// 3D-DDA over GridDesc in f32 cell units.  It only decides WHICH spheres get the exact f64
+// test; it can visit too many cells but never too few (DESIGN.md "Grid walk").
+struct GridWalk {
+  float inv[3];  // 1 / direction (cell units), clamped to +-1e30
+  float c[3];    // -origin * inv, so the crossing of plane x = b is t = fma(b, inv, c)
+  float b[3];    // next boundary plane per axis (an integer)
+  int lin;       // linear index of the current cell
+  double t0;     // the walk's ray is re-originated at t0 (grid entry): t_ray = t0 + t_walk
+};
+enum { GRID_MISS = 0, GRID_WALK = 1, GRID_FALLBACK = 2 };
+
+RT_HD float rt_rcpf(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);  // 1 ulp; the walk's margins budget 3 ulp
+#else
+  return 1.0f / x;
+#endif
+}
+RT_HD float rt_clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }  // NaN stays NaN
+RT_HD double rt_mind(double a, double b) { return a < b ? a : b; }
+RT_HD double rt_maxd(double a, double b) { return a > b ? a : b; }
+
+// Prepare the walk of ray o + t*d.  GRID_MISS: the ray cannot touch any gridded sphere.
+// GRID_FALLBACK: numerically unsafe (non-finite input, or entry too far away for f32): the
+// caller tests every sphere exactly instead.
+RT_HD int grid_begin(const GridDesc& G, V3 o, V3 d, GridWalk& w) {
+  const double ol[3] = {(o.x - G.gmin[0]) * G.inv_cell[0], (o.y - G.gmin[1]) * G.inv_cell[1], (o.z - G.gmin[2]) * G.inv_cell[2]};
+  const double dl[3] = {d.x * G.inv_cell[0], d.y * G.inv_cell[1], d.z * G.inv_cell[2]};
+  double tn = 0.0, tf = T_MAX;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    w.inv[k] = rt_clampf(rt_rcpf((float)dl[k]), -1e30f, 1e30f);
+    const double invd = (double)w.inv[k];
+    const double t1 = (0.0 - ol[k]) * invd, t2 = ((double)G.n[k] - ol[k]) * invd;
+    tn = rt_maxd(tn, rt_mind(t1, t2));
+    tf = rt_mind(tf, rt_maxd(t1, t2));
+  }
+  // the slab parameters carry the f32 reciprocal's relative error (< 4e-7): decide with 2^-12 slack
+  const double slack = 1.0 / 4096.0;
+  if (tf + fabs(tf) * slack < tn - tn * slack) return GRID_MISS;
+  w.t0 = tn - tn * slack;  // never later than the true entry; >= 0
+  bool sane = true;
+  int cell[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double op = ol[k] + w.t0 * dl[k];
+    sane = sane && op >= -2.0 && op <= (double)G.n[k] + 2.0;
+    const float of = (float)op;
+    int i = (int)floorf(of);
+    i = i < 0 ? 0 : (i > (int)G.n[k] - 1 ? (int)G.n[k] - 1 : i);
+    cell[k] = i;
+    w.b[k] = (float)(i + (w.inv[k] > 0.0f ? 1 : 0));
+    w.c[k] = -of * w.inv[k];
+  }
+  if (!sane) return GRID_FALLBACK;
+  w.lin = cell[0] + (int)G.n[0] * (cell[1] + (int)G.n[1] * cell[2]);
+  return GRID_WALK;
+}
+// Move to the next cell along the ray; false when the walk leaves the grid.  One axis moves
+// by one cell per call, so a walk ends after at most n[0]+n[1]+n[2] steps whatever the
+// arithmetic does (NaN compares false and falls through to the z axis).
+RT_HD bool grid_step(const GridDesc& G, GridWalk& w) {
+  const float tx = __builtin_fmaf(w.b[0], w.inv[0], w.c[0]);
+  const float ty = __builtin_fmaf(w.b[1], w.inv[1], w.c[1]);
+  const float tz = __builtin_fmaf(w.b[2], w.inv[2], w.c[2]);
+  const bool sx = tx <= ty && tx <= tz;
+  const bool sy = !sx && ty <= tz;
+  const bool px = w.inv[0] > 0.0f, py = w.inv[1] > 0.0f, pz = w.inv[2] > 0.0f;
+  const int nx = (int)G.n[0], nxy = (int)(G.n[0] * G.n[1]);
+  bool out;
+  if (sx) {
+    w.b[0] += px ? 1.0f : -1.0f; w.lin += px ? 1 : -1;
+    out = w.b[0] == (px ? (float)(G.n[0] + 1u) : -1.0f);
+  } else if (sy) {
+    w.b[1] += py ? 1.0f : -1.0f; w.lin += py ? nx : -nx;
+    out = w.b[1] == (py ? (float)(G.n[1] + 1u) : -1.0f);
+  } else {
+    w.b[2] += pz ? 1.0f : -1.0f; w.lin += pz ? nxy : -nxy;
+    out = w.b[2] == (pz ? (float)(G.n[2] + 1u) : -1.0f);
+  }
+  return !out;
+}
+// True when the closest hit found so far lies inside the current cell with GRID_MARGIN to
+// spare from every exit face: no sphere listed only in later cells can be closer.
+RT_HD bool grid_done(const GridWalk& w, double closest) {
+  float tc = (float)(closest - w.t0);
+  tc = tc + fabsf(tc) * 2.384185791015625e-07f;  // round up past the conversion (2^-22)
+  bool done = true;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float pull = w.inv[k] > 0.0f ? -GRID_MARGIN : GRID_MARGIN;
+    done = done && tc < __builtin_fmaf(w.b[k] + pull, w.inv[k], w.c[k]);
+  }
+  return done;
+}
+
+// hit_world through the grid for ONE ray — the per-lane reference form of what the megakernel
+// does with 64 lanes in lock-step (rt_kernel.hip); tests/hostsim runs this one on the CPU.
+template <class Tables>
+RT_HD void hit_world_grid(const DevScene& sc, const Tables& tb, V3 o, V3 d, double a, double& closest, int& best,
+                          uint32_t& n_exact, uint32_t& n_steps) {
+  const GridDesc& G = sc.grid;
+  for (uint32_t i = 0; i < G.n_large; ++i) {
+    const uint32_t idx = sc.large[i];
+    n_exact++;
+    exact_hit_any_order(o, d, a, tb.geom(idx), idx, closest, best);
+  }
+  if (G.n[0] == 0u) return;
+  GridWalk w;
+  const int mode = grid_begin(G, o, d, w);
+  if (mode == GRID_MISS) return;
+  if (mode == GRID_FALLBACK) {
+    for (uint32_t idx = 0; idx < sc.n_spheres; ++idx) { n_exact++; exact_hit_any_order(o, d, a, tb.geom(idx), idx, closest, best); }
+    return;
+  }
+  uint32_t last = 0xFFFFFFFFu;
+  for (;;) {
+    const uint32_t word = sc.cell_word[w.lin];
+    const uint32_t first = word & CELL_START_MASK, count = word >> CELL_COUNT_SHIFT;
+    for (uint32_t k = 0; k < count; ++k) {
+      const uint32_t idx = sc.cell_items[first + k];
+      if (idx == last) continue;  // the sphere tested last (large spheres span consecutive cells)
+      last = idx;
+      n_exact++;
+      exact_hit_any_order(o, d, a, tb.geom(idx), idx, closest, best);
+    }
+    if (best >= 0 && grid_done(w, closest)) return;
+    n_steps++;
+    if (!grid_step(G, w)) return;
+  }
+}
+
 // ------------------------------------------------------------------ materials.rs
 RT_HD V3 reflect(V3 v, V3 n) { return sub(v, muls(n, 2.0 * dot(v, n))); }  // :111-113
 RT_HD V3 refract(V3 uv, V3 n, double etai_over_etat) {                     // :144-149
@@ -276,20 +472,31 @@ RT_HD Rgb texture_albedo(const DevScene& sc, const SphereMat& m, double u, doubl
 //                                              [lo', hi'] = sorted {G(0), G(1)}
 // (G is monotone, so G(clamp01(z)) = clamp(G(z), G(0), G(1))).  Exact in real arithmetic for
 // any sign of a; in f32 the products associate outermost-first instead of innermost-first.
-struct Fwd {
+// SIMPLE scenes (no lights, every albedo in [0,1]; rt_tables.h decides): L is always 0 and the
+// clamps never bind, so the map degenerates to G(x) = q*x — three floats instead of twelve,
+// with bit-identical results (p stays +0, lo = 0, hi = previous q >= q*x).
+template <bool SIMPLE>
+struct FwdT {
   float p[3], q[3], lo[3], hi[3];
 };
-RT_HD void fwd_init(Fwd& f) {
+template <>
+struct FwdT<true> {
+  float q[3];
+};
+typedef FwdT<false> Fwd;
+RT_HD void fwd_init(FwdT<false>& f) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) { f.p[i] = 0.0f; f.q[i] = 1.0f; f.lo[i] = -3.4028234663852886e38f; f.hi[i] = 3.4028234663852886e38f; }
 }
-RT_HD float fwd_eval1(const Fwd& f, int i, float x) {
+RT_HD void fwd_init(FwdT<true>& f) { f.q[0] = f.q[1] = f.q[2] = 1.0f; }
+RT_HD float fwd_eval1(const FwdT<false>& f, int i, float x) {
   float y = f.p[i] + f.q[i] * x;
   y = y < f.lo[i] ? f.lo[i] : y;
   y = y > f.hi[i] ? f.hi[i] : y;
   return y;
 }
-RT_HD void fwd_compose(Fwd& f, const float L[3], const float a[3]) {
+RT_HD float fwd_eval1(const FwdT<true>& f, int i, float x) { return 0.0f + f.q[i] * x; }
+RT_HD void fwd_compose(FwdT<false>& f, const float L[3], const float a[3]) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     float g0 = fwd_eval1(f, i, 0.0f), g1 = fwd_eval1(f, i, 1.0f);
@@ -298,6 +505,10 @@ RT_HD void fwd_compose(Fwd& f, const float L[3], const float a[3]) {
     f.lo[i] = g0 < g1 ? g0 : g1;
     f.hi[i] = g0 < g1 ? g1 : g0;
   }
+}
+RT_HD void fwd_compose(FwdT<true>& f, const float*, const float a[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) f.q[i] = f.q[i] * a[i];
 }
 
 // raytracer.rs:134-160: colour of a ray that left the scene
@@ -316,6 +527,16 @@ RT_HD Rgb sky_color(const DevScene& sc, V3 d, uint32_t& tex_oob) {
   return rgb(0.7f * (float)px[0] / 255.0f, 0.7f * (float)px[1] / 255.0f, 0.7f * (float)px[2] / 255.0f);
 }
 
+// ------------------------------------------------------------------ table access
+// Where a lane reads the per-sphere records from: the HBM tables (this struct; also what
+// tests/hostsim uses) or the workgroup's LDS copies (rt_kernel.hip::LdsTables).
+struct GlobalTables {
+  const SphereGeom* g;
+  const MatCore* m;
+  RT_HD SphereGeom geom(uint32_t i) const { return g[i]; }
+  RT_HD MatCore mat(uint32_t i) const { return m[i]; }
+};
+
 // ------------------------------------------------------------------ scatter (materials.rs:44-54)
 enum { SCATTER_ABSORBED = 0, SCATTER_EMIT = 1, SCATTER_RAY = 2 };
 struct Surface {  // what Sphere::hit records for the accepted root (sphere.rs:59-75)
@@ -332,13 +553,13 @@ RT_HD Surface surface_at(V3 o, V3 d, double t, const SphereGeom& g) {
 }
 // sphere.rs:35-43, evaluated only when the closest hit is a Texture (a pure function of the
 // accepted hit, so skipping it for the other candidates changes nothing)
-RT_HD void sphere_uv(V3 point, const SphereGeom& g, double& u, double& v) {
+RT_HD_COLD void sphere_uv(V3 point, const SphereGeom& g, double& u, double& v) {
   V3 n = unit_vector(sub(point, v3(g.cx, g.cy, g.cz)));
   u = (atan2(n.x, n.z) / (2.0 * 3.14159265358979323846264338327950288)) + 0.5;
   v = n.y * 0.5 + 0.5;
 }
 RT_HD int scatter(const DevScene& sc, const RngAddr& ra, uint32_t node, V3 in_dir, const Surface& h,
-                  const SphereGeom& g, const SphereMat& m, V3& out_dir, float att[3], uint32_t& tex_oob) {
+                  const SphereGeom& g, const MatCore& m, uint32_t idx, V3& out_dir, float att[3], uint32_t& tex_oob) {
   switch (m.kind) {
     case RT_MAT_LIGHT:  // :65-69
       att[0] = att[1] = att[2] = 1.0f;
@@ -352,7 +573,7 @@ RT_HD int scatter(const DevScene& sc, const RngAddr& ra, uint32_t node, V3 in_di
       if (m.kind == RT_MAT_TEXTURE) {
         double u, v;
         sphere_uv(h.point, g, u, v);
-        Rgb a = texture_albedo(sc, m, u, v, tex_oob);
+        Rgb a = texture_albedo(sc, sc.mat[idx], u, v, tex_oob);
         att[0] = a.r; att[1] = a.g; att[2] = a.b;
       } else {
         att[0] = m.albedo[0]; att[1] = m.albedo[1]; att[2] = m.albedo[2];
@@ -406,14 +627,15 @@ struct LightState<true> {
   int top;
 };
 
-template <bool HAS_LIGHTS>
+template <bool HAS_LIGHTS, bool SIMPLE = false>
 struct Lane {
+  static constexpr bool kLights = HAS_LIGHTS;
   V3 o, d;        // current ray
   uint32_t node;  // RNG node of the current ray
   uint32_t k;     // camera-path segment index of the current (or suspended) camera ray
   uint32_t s;     // current sample
   uint32_t in_light;  // 1 while the current ray is a nested light ray
-  Fwd fwd;
+  FwdT<SIMPLE> fwd;
   float val[3];   // radiance of the sample that just finished (valid when lane_shade returned true)
   RngAddr ra;
   LightState<HAS_LIGHTS> ls;
@@ -422,8 +644,8 @@ struct Lane {
 };
 
 // raytracer.rs:199-201 + camera.rs:79-84
-template <bool HL>
-RT_HD void lane_begin_sample(const DevScene& sc, Lane<HL>& L, uint32_t px, uint32_t py) {
+template <class LaneT>
+RT_HD void lane_begin_sample(const DevScene& sc, LaneT& L, uint32_t px, uint32_t py) {
   L.ra.sample = L.s;
   U4 w = rng(L.ra, NODE_CAMERA, 0);
   double u = ((double)px + u01_53(w.x, w.y)) / ((double)sc.width - 1.0);
@@ -440,8 +662,8 @@ RT_HD void lane_begin_sample(const DevScene& sc, Lane<HL>& L, uint32_t px, uint3
 
 // the sample's radiance is known: fold the leaf colour through the forward map.  The caller
 // adds L.val to the pixel (raytracer.rs:203-205) and picks the lane's next sample.
-template <bool HL>
-RT_HD void lane_finish_sample(Lane<HL>& L, Rgb leaf) {
+template <class LaneT>
+RT_HD void lane_finish_sample(LaneT& L, Rgb leaf) {
   L.val[0] = fwd_eval1(L.fwd, 0, leaf.r);
   L.val[1] = fwd_eval1(L.fwd, 1, leaf.g);
   L.val[2] = fwd_eval1(L.fwd, 2, leaf.b);
@@ -466,8 +688,8 @@ RT_HD float fixed_to_mean(unsigned long long sum, uint32_t spp) {
 // Continue the camera path after its hit at level k has been fully evaluated:
 // compose clamp(light + albedo*child) and step to the scattered ray.  Returns true when the
 // sample finished (depth exhausted: the child is ray_color(.., depth 0) = black, :80-82).
-template <bool HL>
-RT_HD bool lane_continue_main(const DevScene& sc, Lane<HL>& L, V3 point, V3 out_dir, const float light[3], const float att[3]) {
+template <class LaneT>
+RT_HD bool lane_continue_main(const DevScene& sc, LaneT& L, V3 point, V3 out_dir, const float light[3], const float att[3]) {
   fwd_compose(L.fwd, light, att);
   L.k += 1;
   if (L.k >= sc.max_depth) { lane_finish_sample(L, rgb(0.0f, 0.0f, 0.0f)); return true; }
@@ -475,23 +697,24 @@ RT_HD bool lane_continue_main(const DevScene& sc, Lane<HL>& L, V3 point, V3 out_
   return false;
 }
 
-#if 1
 // aim the current ray at light j of frame `top` (raytracer.rs:104-106)
-RT_HD void lane_aim_light(const DevScene& sc, Lane<true>& L) {
+template <class Tables>
+RT_HD void lane_aim_light(const DevScene& sc, const Tables& tb, Lane<true>& L) {
   LightFrame& f = L.ls.fr[L.ls.top];
-  const SphereGeom& lg = sc.geom[sc.lights[f.j]];
+  const SphereGeom lg = tb.geom(sc.lights[f.j]);
   L.o = f.P;
   L.d = sub(v3(lg.cx, lg.cy, lg.cz), f.P);
   L.node = child_node(f.node, f.j);
   L.in_light = 1;
 }
 // a nested light ray produced colour tc: hand it to its parent activation(s) (:107-113)
-RT_HD bool lane_light_return(const DevScene& sc, Lane<true>& L, Rgb tc) {
+template <class Tables>
+RT_HD bool lane_light_return(const DevScene& sc, const Tables& tb, Lane<true>& L, Rgb tc) {
   for (;;) {
     LightFrame& f = L.ls.fr[L.ls.top];
     f.acc[0] += f.a[0] * tc.r; f.acc[1] += f.a[1] * tc.g; f.acc[2] += f.a[2] * tc.b;
     f.j += 1;
-    if (f.j < sc.n_lights) { lane_aim_light(sc, L); return false; }
+    if (f.j < sc.n_lights) { lane_aim_light(sc, tb, L); return false; }
     float nl = (float)sc.n_lights;
     float light[3] = {f.acc[0] / nl, f.acc[1] / nl, f.acc[2] / nl};
     if (L.ls.top == 0)  // back on the camera path: clamp(light + albedo*child), child = scattered ray
@@ -501,33 +724,33 @@ RT_HD bool lane_light_return(const DevScene& sc, Lane<true>& L, Rgb tc) {
     L.ls.top -= 1;
   }
 }
-#endif
 
 // Consume the closest hit (idx < 0: miss) of the lane's current ray.  Returns true when the
 // lane's current sample finished (its radiance is in L.val; the caller starts the next one).
-template <bool HL>
-RT_HD bool lane_shade(const DevScene& sc, Lane<HL>& L, int idx, double t) {
+template <class LaneT, class Tables>
+RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, double t) {
+  constexpr bool HL = LaneT::kLights;
   if (idx < 0) {  // raytracer.rs:133-163
     Rgb sky = sky_color(sc, L.d, L.n_tex_oob);
     if constexpr (HL) {
-      if (L.in_light) return lane_light_return(sc, L, sky);
+      if (L.in_light) return lane_light_return(sc, tb, L, sky);
     }
     lane_finish_sample(L, sky);
     return true;
   }
-  const SphereGeom g = sc.geom[idx];
-  const SphereMat m = sc.mat[idx];
+  const SphereGeom g = tb.geom((uint32_t)idx);
+  const MatCore m = tb.mat((uint32_t)idx);
   Surface h = surface_at(L.o, L.d, t, g);
   V3 out_dir = v3(0, 0, 0);
   float att[3];
-  int st = scatter(sc, L.ra, L.node, L.d, h, g, m, out_dir, att, L.n_tex_oob);
+  int st = scatter(sc, L.ra, L.node, L.d, h, g, m, (uint32_t)idx, out_dir, att, L.n_tex_oob);
   const float zero3[3] = {0.0f, 0.0f, 0.0f};
 
   if constexpr (HL) {
     if (L.in_light) {
       // nested activation ray_color(light_ray, 2, 1) at nesting level top+1
-      if (st == SCATTER_EMIT) return lane_light_return(sc, L, rgb(att[0], att[1], att[2]));  // :124
-      if (st == SCATTER_ABSORBED) return lane_light_return(sc, L, rgb(0.f, 0.f, 0.f));        // :127-131
+      if (st == SCATTER_EMIT) return lane_light_return(sc, tb, L, rgb(att[0], att[1], att[2]));  // :124
+      if (st == SCATTER_ABSORBED) return lane_light_return(sc, tb, L, rgb(0.f, 0.f, 0.f));        // :127-131
       const uint32_t level = (uint32_t)L.ls.top + 1u;
       if (level < RT_MAX_LIGHT_NEST) {
         double prob = m.kind == RT_MAT_GLASS ? 0.05 : 0.1;
@@ -537,12 +760,12 @@ RT_HD bool lane_shade(const DevScene& sc, Lane<HL>& L, int idx, double t) {
           LightFrame& f = L.ls.fr[L.ls.top];
           f.P = h.point; f.a[0] = att[0]; f.a[1] = att[1]; f.a[2] = att[2];
           f.acc[0] = f.acc[1] = f.acc[2] = 0.0f; f.j = 0; f.node = L.node;
-          lane_aim_light(sc, L);
+          lane_aim_light(sc, tb, L);
           return false;
         }
       }
       // no light sampling: clamp(0 + albedo * black)
-      return lane_light_return(sc, L, rgb(clamp01(0.0f + att[0] * 0.0f), clamp01(0.0f + att[1] * 0.0f), clamp01(0.0f + att[2] * 0.0f)));
+      return lane_light_return(sc, tb, L, rgb(clamp01(0.0f + att[0] * 0.0f), clamp01(0.0f + att[1] * 0.0f), clamp01(0.0f + att[2] * 0.0f)));
     }
   }
 
@@ -559,7 +782,7 @@ RT_HD bool lane_shade(const DevScene& sc, Lane<HL>& L, int idx, double t) {
         f.P = h.point; f.a[0] = att[0]; f.a[1] = att[1]; f.a[2] = att[2];
         f.acc[0] = f.acc[1] = f.acc[2] = 0.0f; f.j = 0; f.node = L.node;
         L.ls.saved_d = out_dir;
-        lane_aim_light(sc, L);
+        lane_aim_light(sc, tb, L);
         return false;
       }
     }

@@ -8,9 +8,11 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rt_kernel.hip"
+#include "rt_kernel_scan.hip"
 #include "rt_tables.h"
 
 namespace {
@@ -31,10 +33,18 @@ struct RtHipScene {
   int device = 0;
   RtScene host{};          // scalar fields only (pointers are not kept)
   rtc::DevScene dev{};     // device pointers filled in
-  bool has_lights = false;
+  bool has_lights = false, simple_colour = false;
   void* d_geom = nullptr; void* d_mat = nullptr; void* d_cull = nullptr; void* d_lights = nullptr;
   void* d_tex = nullptr; void* d_sky = nullptr;
-  unsigned long long* d_counters = nullptr;
+  void* d_matc = nullptr; void* d_cell_word = nullptr; void* d_cell_items = nullptr; void* d_large = nullptr;
+  void* d_all = nullptr;   // 0..n-1: the `large` list of the brute-force arm (variant 1)
+  rtc::GridDesc grid{};    // the product grid (variant 0)
+  unsigned long long* d_counters = nullptr;  // 4 counters + the work-queue cursor
+  unsigned long long* d_accum = nullptr;     // fixed-point pixel sums (pixels split over work items)
+  size_t accum_bytes = 0;
+  int num_cus = 0;
+  int chunk_spp = 0;       // 0 = automatic
+  bool resolve_launched = false;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   hipStream_t last_stream = nullptr;
   bool launched = false;
@@ -70,7 +80,8 @@ extern "C" int rt_hip_device_count(void) {
 extern "C" void rt_hip_scene_destroy(RtHipScene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  for (void* p : {s->d_geom, s->d_mat, s->d_cull, s->d_lights, s->d_tex, s->d_sky, (void*)s->d_counters})
+  for (void* p : {s->d_geom, s->d_mat, s->d_cull, s->d_lights, s->d_tex, s->d_sky, (void*)s->d_counters, s->d_matc,
+                  s->d_cell_word, s->d_cell_items, s->d_large, s->d_all, (void*)s->d_accum})
     if (p) (void)hipFree(p);
   if (s->ev_start) (void)hipEventDestroy(s->ev_start);
   if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
@@ -103,13 +114,29 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   s->host = *scene;
   s->host.spheres = nullptr; s->host.textures = nullptr; s->host.sky_rgb8 = nullptr;
   s->has_lights = !t.lights.empty();
+  s->simple_colour = t.simple_colour;
+  s->grid = t.grid;
   rtc::fill_dev_scene(*scene, t, s->dev);
+  {
+    hipDeviceProp_t prop;
+    RT_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    s->num_cus = prop.multiProcessorCount;
+  }
   int rc;
   auto bail = [&](int code) { rt_hip_scene_destroy(s); return code; };
   if ((rc = upload(&s->d_geom, t.geom)) != RT_OK) return bail(rc);
   if ((rc = upload(&s->d_mat, t.mat)) != RT_OK) return bail(rc);
   if ((rc = upload(&s->d_cull, t.cull)) != RT_OK) return bail(rc);
   if ((rc = upload(&s->d_lights, t.lights)) != RT_OK) return bail(rc);
+  if ((rc = upload(&s->d_matc, t.matc)) != RT_OK) return bail(rc);
+  if ((rc = upload(&s->d_cell_word, t.cell_word)) != RT_OK) return bail(rc);
+  if ((rc = upload(&s->d_cell_items, t.cell_items)) != RT_OK) return bail(rc);
+  if ((rc = upload(&s->d_large, t.large)) != RT_OK) return bail(rc);
+  {
+    std::vector<uint32_t> all(scene->n_spheres);
+    for (uint32_t i = 0; i < scene->n_spheres; ++i) all[i] = i;
+    if ((rc = upload(&s->d_all, all)) != RT_OK) return bail(rc);
+  }
   {
     std::vector<uint8_t> blob(t.tex_bytes);
     for (uint32_t i = 0; i < scene->n_textures; ++i)
@@ -121,12 +148,14 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
     if (scene->sky_mode == RT_SKY_TEXTURE) sky.assign(scene->sky_rgb8, scene->sky_rgb8 + scene->sky_w * scene->sky_h * 3);
     if ((rc = upload(&s->d_sky, sky)) != RT_OK) return bail(rc);
   }
-  if (hipMalloc((void**)&s->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
+  if (hipMalloc((void**)&s->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
       hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess)
     return bail(fail(RT_ERR_HIP, "hipMalloc/hipEventCreate failed"));
   s->dev.geom = (const rtc::SphereGeom*)s->d_geom; s->dev.mat = (const rtc::SphereMat*)s->d_mat;
   s->dev.cull = (const rtc::CullPair*)s->d_cull; s->dev.lights = (const uint32_t*)s->d_lights;
   s->dev.tex = (const uint8_t*)s->d_tex; s->dev.sky = (const uint8_t*)s->d_sky;
+  s->dev.matc = (const rtc::MatCore*)s->d_matc; s->dev.cell_word = (const uint32_t*)s->d_cell_word;
+  s->dev.cell_items = (const uint16_t*)s->d_cell_items; s->dev.large = (const uint32_t*)s->d_large;
   *out = s;
   return RT_OK;
 }
@@ -135,50 +164,133 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
   if (!s || !key) return fail(RT_ERR_INVALID, "null argument");
   if (!std::strcmp(key, "variant")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "variant must be 0, 1 or 2"); s->variant = (int)value; return RT_OK; }
   if (!std::strcmp(key, "pool")) { s->pool = value != 0; return RT_OK; }
+  if (!std::strcmp(key, "chunk_spp")) { if (value < 0) return fail(RT_ERR_INVALID, "chunk_spp must be >= 0"); s->chunk_spp = (int)value; return RT_OK; }
   if (!std::strcmp(key, "samples_per_pixel")) { s->host.samples_per_pixel = s->dev.spp = (uint32_t)value; return RT_OK; }
   if (!std::strcmp(key, "max_depth")) { s->host.max_depth = s->dev.max_depth = (uint32_t)value; return RT_OK; }
   if (!std::strcmp(key, "seed")) { s->host.seed = (uint64_t)value; s->dev.seed_lo = (uint32_t)value; s->dev.seed_hi = (uint32_t)((uint64_t)value >> 32); return RT_OK; }
   return fail(RT_ERR_INVALID, std::string("unknown option ") + key);
 }
 
-extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb8, void* d_linear, void* stream_) {
-  if (!s) return fail(RT_ERR_INVALID, "null argument");
-  if (!d_rgb8 && rt_tiles_local_rows(s->host.height, tiles) != 0) return fail(RT_ERR_INVALID, "null framebuffer");
-  hipStream_t stream = (hipStream_t)stream_;
-  RT_HIP_TRY(hipSetDevice(s->device));
-  rtk::KArgs ka;
+namespace {
+// legacy arm (variant 2): the round-1 cull-scan kernel, one workgroup per 16x16 tile
+int launch_scan(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb8, void* d_linear, hipStream_t stream, uint32_t local_rows) {
+  rtk_scan::KArgs ka;
   ka.sc = s->dev;
   ka.out_rgb8 = (uint8_t*)d_rgb8; ka.out_linear = (float*)d_linear; ka.counters = s->d_counters;
-  ka.local_rows = rt_tiles_local_rows(s->host.height, tiles);
+  ka.local_rows = local_rows;
   const bool tiled = tiles && tiles->tile_rows && tiles->tile_stride;
   ka.tile_rows = tiled ? tiles->tile_rows : 0; ka.first_tile = tiled ? tiles->first_tile : 0;
   ka.tile_stride = tiled ? tiles->tile_stride : 0;
-  s->last_rows = ka.local_rows;
-  s->last_stream = stream;
-  s->t_launch = std::chrono::steady_clock::now();
-  RT_HIP_TRY(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned long long), stream));
-  if (ka.local_rows == 0) { s->launched = false; return RT_OK; }
-  const uint32_t tiles_x = (s->host.width + rtk::TILE_W - 1) / rtk::TILE_W;
-  const uint32_t tiles_y = (ka.local_rows + rtk::TILE_H - 1) / rtk::TILE_H;
-  const dim3 grid(tiles_x * tiles_y), block(rtk::BLOCK);
-  RT_HIP_TRY(hipEventRecord(s->ev_start, stream));
-  const bool geom_lds = s->host.n_spheres <= rtk::LDS_GEOM_MAX_SPHERES && s->variant != 1;
-  const size_t lds_bytes = rtk::LDS_GEOM_OFF + (geom_lds ? (size_t)s->host.n_spheres * sizeof(rtc::SphereGeom) : 0);
-  const bool pool = s->pool != 0;
-#define RT_LAUNCH(HL, V, G, P) hipLaunchKernelGGL((rtk::rt_megakernel<HL, V, G, P>), grid, block, lds_bytes, stream, ka)
-#define RT_LAUNCH_P(HL, V, G) do { if (pool) RT_LAUNCH(HL, V, G, true); else RT_LAUNCH(HL, V, G, false); } while (0)
-#define RT_LAUNCH_V(HL, G)                                     \
-  do {                                                         \
-    if (s->variant == 1) RT_LAUNCH_P(HL, 1, false);            \
-    else if (s->variant == 2) RT_LAUNCH_P(HL, 2, G);           \
-    else RT_LAUNCH_P(HL, 0, G);                                \
-  } while (0)
-  if (s->has_lights) { if (geom_lds) RT_LAUNCH_V(true, true); else RT_LAUNCH_V(true, false); }
-  else { if (geom_lds) RT_LAUNCH_V(false, true); else RT_LAUNCH_V(false, false); }
-#undef RT_LAUNCH_V
+  const uint32_t tiles_x = (s->host.width + rtk_scan::TILE_W - 1) / rtk_scan::TILE_W;
+  const uint32_t tiles_y = (local_rows + rtk_scan::TILE_H - 1) / rtk_scan::TILE_H;
+  const dim3 grid(tiles_x * tiles_y), block(rtk_scan::BLOCK);
+  const bool geom_lds = s->host.n_spheres <= rtk_scan::LDS_GEOM_MAX_SPHERES;
+  const size_t lds_bytes = rtk_scan::LDS_GEOM_OFF + (geom_lds ? (size_t)s->host.n_spheres * sizeof(rtc::SphereGeom) : 0);
+#define RT_LAUNCH(HL, G, P) hipLaunchKernelGGL((rtk_scan::rt_megakernel<HL, 0, G, P>), grid, block, lds_bytes, stream, ka)
+#define RT_LAUNCH_P(HL, G) do { if (s->pool) RT_LAUNCH(HL, G, true); else RT_LAUNCH(HL, G, false); } while (0)
+  if (s->has_lights) { if (geom_lds) RT_LAUNCH_P(true, true); else RT_LAUNCH_P(true, false); }
+  else { if (geom_lds) RT_LAUNCH_P(false, true); else RT_LAUNCH_P(false, false); }
 #undef RT_LAUNCH_P
 #undef RT_LAUNCH
+  return RT_OK;
+}
+
+template <bool HL, bool SIMPLE, bool LDS>
+int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka, size_t lds_bytes, uint32_t n_items, hipStream_t stream) {
+  auto kern = rtk::rt_megakernel<HL, SIMPLE, LDS>;
+  if (lds_bytes > 48 * 1024) RT_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  int per_cu = 0;
+  RT_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, rtk::BLOCK, lds_bytes));
+  if (per_cu < 1) return fail(RT_ERR_HIP, "megakernel does not fit on a CU");
+  // persistent: exactly the resident set, never more workgroups than there are wave-sized items
+  uint32_t wgs = (uint32_t)per_cu * (uint32_t)s->num_cus;
+  const uint32_t need = (n_items + rtk::WAVES - 1) / rtk::WAVES;
+  if (wgs > need) wgs = need;
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(rtk::BLOCK), lds_bytes, stream, ka);
+  return RT_OK;
+}
+}  // namespace
+
+extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb8, void* d_linear, void* stream_) {
+  if (!s) return fail(RT_ERR_INVALID, "null argument");
+  const uint32_t local_rows = rt_tiles_local_rows(s->host.height, tiles);
+  if (!d_rgb8 && local_rows != 0) return fail(RT_ERR_INVALID, "null framebuffer");
+  hipStream_t stream = (hipStream_t)stream_;
+  RT_HIP_TRY(hipSetDevice(s->device));
+  s->last_rows = local_rows;
+  s->last_stream = stream;
+  s->t_launch = std::chrono::steady_clock::now();
+  RT_HIP_TRY(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), stream));
+  if (local_rows == 0) { s->launched = false; return RT_OK; }
+  if (s->variant == 2) {
+    RT_HIP_TRY(hipEventRecord(s->ev_start, stream));
+    int rc = launch_scan(s, tiles, d_rgb8, d_linear, stream, local_rows);
+    if (rc != RT_OK) return rc;
+    RT_HIP_TRY(hipGetLastError());
+    RT_HIP_TRY(hipEventRecord(s->ev_stop, stream));
+    s->launched = true;
+    return RT_OK;
+  }
+
+  rtk::KArgs ka;
+  ka.sc = s->dev;
+  if (s->variant == 1) {  // brute-force arm: no grid, every sphere in the `large` list (object order)
+    std::memset(&ka.sc.grid, 0, sizeof ka.sc.grid);
+    ka.sc.grid.n_large = s->host.n_spheres;
+    ka.sc.large = (const uint32_t*)s->d_all;
+  }
+  ka.out_rgb8 = (uint8_t*)d_rgb8; ka.out_linear = (float*)d_linear; ka.counters = s->d_counters;
+  ka.queue = (uint32_t*)(s->d_counters + 4);
+  ka.local_rows = local_rows;
+  const bool tiled = tiles && tiles->tile_rows && tiles->tile_stride;
+  ka.tile_rows = tiled ? tiles->tile_rows : 0; ka.first_tile = tiled ? tiles->first_tile : 0;
+  ka.tile_stride = tiled ? tiles->tile_stride : 0;
+  ka.tiles_x = (s->host.width + rtk::TILE - 1) / rtk::TILE;
+  ka.n_tiles = ka.tiles_x * ((local_rows + rtk::TILE - 1) / rtk::TILE);
+  // Work items: split a pixel's samples into chunks until the frame has ~16 items per resident
+  // wave (so the last items finishing cost a few % of the frame), but not below 8 samples.
+  const uint32_t spp = s->host.samples_per_pixel;
+  uint32_t chunk_spp = (uint32_t)s->chunk_spp;
+  if (chunk_spp == 0) {
+    const uint64_t target_items = (uint64_t)s->num_cus * 16u * 16u;
+    uint64_t chunks = (target_items + ka.n_tiles - 1) / ka.n_tiles;
+    if (chunks < 1) chunks = 1;
+    chunk_spp = (uint32_t)((spp + chunks - 1) / chunks);
+    if (chunk_spp < 8) chunk_spp = 8;
+  }
+  if (chunk_spp > spp || spp == 0) chunk_spp = spp ? spp : 1;
+  ka.chunk_spp = chunk_spp;
+  ka.n_chunks = spp ? (spp + chunk_spp - 1) / chunk_spp : 1;
+  const size_t n_pixels = (size_t)local_rows * s->host.width;
+  ka.accum = nullptr;
+  if (ka.n_chunks > 1) {
+    const size_t need = n_pixels * 3 * sizeof(unsigned long long);
+    if (need > s->accum_bytes) {
+      if (s->d_accum) { RT_HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(s->d_accum); s->d_accum = nullptr; s->accum_bytes = 0; }
+      RT_HIP_TRY(hipMalloc((void**)&s->d_accum, need));
+      s->accum_bytes = need;
+    }
+    ka.accum = s->d_accum;
+  }
+  const uint32_t n_items = ka.n_tiles * ka.n_chunks;
+  const rtc::GridDesc& G = ka.sc.grid;
+  const rtk::LdsLayout with_tables = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true);
+  const bool lds_tables = with_tables.total <= 64u * 1024u;  // two 512-thread workgroups per CU keep 160 KB LDS
+  const size_t lds_bytes = lds_tables ? with_tables.total : rtk::lds_layout(0, 0, 0, false).total;
+
+  RT_HIP_TRY(hipEventRecord(s->ev_start, stream));
+  if (ka.accum) RT_HIP_TRY(hipMemsetAsync(ka.accum, 0, n_pixels * 3 * sizeof(unsigned long long), stream));
+  int rc;
+  if (s->has_lights) rc = lds_tables ? launch_grid_t<true, false, true>(s, ka, lds_bytes, n_items, stream) : launch_grid_t<true, false, false>(s, ka, lds_bytes, n_items, stream);
+  else if (s->simple_colour) rc = lds_tables ? launch_grid_t<false, true, true>(s, ka, lds_bytes, n_items, stream) : launch_grid_t<false, true, false>(s, ka, lds_bytes, n_items, stream);
+  else rc = lds_tables ? launch_grid_t<false, false, true>(s, ka, lds_bytes, n_items, stream) : launch_grid_t<false, false, false>(s, ka, lds_bytes, n_items, stream);
+  if (rc != RT_OK) return rc;
   RT_HIP_TRY(hipGetLastError());
+  if (ka.accum) {
+    hipLaunchKernelGGL(rtk::rt_resolve, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream, ka.accum, ka.out_rgb8, ka.out_linear,
+                       (uint32_t)n_pixels, spp);
+    RT_HIP_TRY(hipGetLastError());
+  }
   RT_HIP_TRY(hipEventRecord(s->ev_stop, stream));
   s->launched = true;
   return RT_OK;
@@ -190,7 +302,7 @@ extern "C" int rt_hip_wait(RtHipScene* s, RtStats* stats) {
   RT_HIP_TRY(hipStreamSynchronize(s->last_stream));
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
-    unsigned long long c[4] = {0, 0, 0, 0};
+    unsigned long long c[4] = {0, 0, 0, 0};  // segments, exact tests, tex_oob, grid steps
     RT_HIP_TRY(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
     float ms = 0.f;
     if (s->launched) RT_HIP_TRY(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
@@ -199,6 +311,7 @@ extern "C" int rt_hip_wait(RtHipScene* s, RtStats* stats) {
     stats->sphere_tests = c[0] * (uint64_t)s->host.n_spheres;
     stats->exact_tests = c[1];
     stats->tex_oob = c[2];
+    stats->grid_steps = c[3];
     stats->kernel_ms = ms;
     stats->frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s->t_launch).count();
   }

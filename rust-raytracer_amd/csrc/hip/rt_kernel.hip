@@ -1,20 +1,25 @@
 // rt_kernel.hip — the gfx950 megakernel: render_line + ray_color + hit_world of the reference
-// (raytracer/src/raytracer.rs:191-218, 71-165, 44-59) as ONE launch.
+// (raytracer/src/raytracer.rs:191-218, 71-165, 44-59) as ONE persistent launch.
 //
 // Shape (CDNA4-first):
-//   * one work-item per pixel, 256-thread workgroups = four 8x8-pixel wave tiles;
-//   * each lane walks ITS samples as a state machine: one loop iteration = one ray segment
-//     (camera-path segment or nested light ray).  A lane whose path ended starts its next
-//     sample immediately, so all 64 lanes enter the sphere scan together every iteration —
-//     the bounce loop has no per-sample divergence, only an end-of-pixel tail;
-//   * hit_world = (a) packed-f32 conservative cull over ALL spheres, two spheres per
-//     v_pk_* instruction, the sphere table broadcast through the scalar cache into SGPRs
-//     (wave-uniform index -> s_load, zero VGPRs / zero LDS bandwidth for the table);
-//     (b) survivors are appended to a per-lane candidate list in LDS; (c) each lane then
-//     runs the reference's exact f64 Sphere::hit on ITS OWN candidates, in object order,
-//     so accepted hits are bit-identical to the CPU oracle;
-//   * Philox4x32-10 per lane, addressed by (pixel, sample, node, slot);
-//   * RGB8 framebuffer written once per pixel.
+//   * persistent workgroups (one resident set per CU) pull work items from a global queue.
+//     Item = (8x8-pixel wave tile, chunk of samples); items are small (a few thousand
+//     samples), so the frame has no tail even though paths differ 50x in length;
+//   * the scene tables a ray touches per segment — f64 sphere geometry, material cores, the
+//     uniform grid's cell words and item lists — are staged ONCE per workgroup into LDS and
+//     gathered from there by lane (ds_read_b64), never from HBM;
+//   * inside an item the wave's 64 x chunk samples form one pool: a lane that finishes a
+//     sample takes the next (pixel, sample) by ballot + prefix rank, so all 64 lanes enter
+//     hit_world together every iteration (active-ray compaction without moving any state);
+//   * hit_world = `large` spheres (the ground) tested by every lane through scalar loads, then
+//     a per-lane 3D-DDA through the uniform grid (f32, conservative) whose cells list the
+//     spheres that get the reference's exact f64 Sphere::hit.  The closest hit is the
+//     lexicographic minimum of (t, object index), i.e. bit-identical to the reference's
+//     object-order scan (rt_core.h exact_hit_any_order);
+//   * pixel sums are exact 2^-40 fixed point: in LDS per item, then (when a pixel's samples are
+//     split over several items) u64 atomics into an HBM accumulator that a trivial epilogue
+//     kernel turns into RGB8.  Order-free, hence bit-reproducible for any schedule / GPU count;
+//   * Philox4x32-10 per lane, addressed by (pixel, sample, node, slot).
 #include <hip/hip_runtime.h>
 
 #include "rt_core.h"
@@ -22,253 +27,286 @@
 namespace rtk {
 using namespace rtc;
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 struct KArgs {
   DevScene sc;
   uint8_t* out_rgb8;
   float* out_linear;
-  unsigned long long* counters;  // [0] segments, [1] exact tests, [2] tex_oob
+  unsigned long long* counters;  // [0] segments, [1] exact tests, [2] tex_oob, [3] grid steps
+  unsigned long long* accum;     // [local pixel][3] fixed-point sums; used when n_chunks > 1
+  uint32_t* queue;               // work-item cursor (zeroed before the launch)
   uint32_t local_rows, tile_rows, first_tile, tile_stride;
+  uint32_t tiles_x, n_tiles, n_chunks, chunk_spp;
 };
 
+#ifndef RT_BLOCK
+#define RT_BLOCK 512
+#endif
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_ATTR
 #else
 #define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
 #endif
 
-constexpr int BLOCK = 256;
+constexpr int BLOCK = RT_BLOCK;
 constexpr int WAVES = BLOCK / 64;
-constexpr int TILE_W = 16, TILE_H = 16;  // block tile; wave tile is 8x8
-constexpr int CAND_SLOTS = 32;           // per-lane candidate capacity between flushes
-constexpr int SCAN_CHUNK = 8;            // pairs per chunk (16 spheres); flush if count > SLOTS-16
+constexpr int TILE = 8;  // wave tile = 8x8 pixels
 
-// constant-address-space views: a wave-uniform index into these becomes s_load_dwordx8
-typedef const float __attribute__((address_space(4))) * CullPtrK;  // 8 floats per CullPair
+// constant-address-space views: a wave-uniform index into these becomes an s_load
+typedef const double __attribute__((address_space(4))) * F64PtrK;
+typedef const uint32_t __attribute__((address_space(4))) * U32PtrK;
 
-__device__ __forceinline__ f32x2 splat(float x) { return f32x2{x, x}; }
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// ---- dynamic LDS layout: [pixel sums: WAVES x 64 x 3 u64][geom][matc][cell words][cell items]
+struct LdsLayout {
+  uint32_t geom_off, matc_off, cell_off, item_off, total;
+};
+__host__ __device__ inline LdsLayout lds_layout(uint32_t n_spheres, uint32_t n_cells, uint32_t n_items, bool tables) {
+  LdsLayout l;
+  uint32_t o = WAVES * 64u * 3u * (uint32_t)sizeof(unsigned long long);
+  l.geom_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(SphereGeom);
+  l.matc_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(MatCore);
+  l.cell_off = o; if (tables) o += n_cells * 4u;
+  l.item_off = o; if (tables) o += (n_items * 2u + 7u) & ~7u;
+  l.total = o;
+  return l;
+}
 
-// dynamic LDS: [candidate lists: WAVES x CAND_SLOTS x 64 u16][pooled pixel sums: WAVES x 64 x 3 u64]
-//              [f64 sphere geometry, if it fits]
-constexpr uint32_t LDS_CAND_BYTES = WAVES * CAND_SLOTS * 64 * sizeof(uint16_t);
-constexpr uint32_t LDS_ACC_BYTES = WAVES * 64 * 3 * sizeof(unsigned long long);
-constexpr uint32_t LDS_GEOM_OFF = LDS_CAND_BYTES + LDS_ACC_BYTES;
-constexpr uint32_t LDS_GEOM_MAX_SPHERES = 1280;  // 40 KB of {cx,cy,cz,r} f64 (<= 64 KB dynamic LDS in total); larger scenes gather it from L2
+struct LdsTables {  // per-lane gathers from the workgroup's LDS copies
+  const double* g;
+  const MatCore* m;
+  __device__ __forceinline__ SphereGeom geom(uint32_t i) const {
+    const double* p = g + 4u * i;
+    SphereGeom r; r.cx = p[0]; r.cy = p[1]; r.cz = p[2]; r.r = p[3];
+    return r;
+  }
+  __device__ __forceinline__ MatCore mat(uint32_t i) const { return m[i]; }
+};
 
-// POOL = false: lane l owns pixel l of the wave tile and adds its samples in order, in f32 —
-//               the reference's summation order (raytracer.rs:203-205).
-// POOL = true : the wave's 64 x spp samples form one pool; a lane that finishes a sample takes
-//               the next (pixel, sample) item (ballot + prefix rank on a wave-uniform counter),
-//               so no lane idles while a neighbour pixel still has work — only the last few
-//               iterations of a tile run with idle lanes.  Pixel sums are exact fixed point in
-//               LDS (ds_add_u64), hence order-independent and bit-reproducible (rt_core.h).
-template <bool HL, int VARIANT, bool GEOM_LDS, bool POOL>
+template <bool HL, bool SIMPLE, bool LDS_TABLES>
 __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs ka) {
   const DevScene& sc = ka.sc;
+  const GridDesc& G = sc.grid;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  uint16_t(*lds_cand)[CAND_SLOTS][64] = reinterpret_cast<uint16_t(*)[CAND_SLOTS][64]>(lds_raw);
-  const SphereGeom* lds_geom = reinterpret_cast<const SphereGeom*>(lds_raw + LDS_GEOM_OFF);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  unsigned long long* const wave_acc = reinterpret_cast<unsigned long long*>(lds_raw + LDS_CAND_BYTES) + wave * 192u;
-  if constexpr (POOL) { wave_acc[lane * 3u] = 0ull; wave_acc[lane * 3u + 1u] = 0ull; wave_acc[lane * 3u + 2u] = 0ull; }
-  if constexpr (GEOM_LDS) {
-    // stage the exact-test table once per workgroup: the confirm step gathers it per lane
-    double* dst = reinterpret_cast<double*>(lds_raw + LDS_GEOM_OFF);
-    const double* src = reinterpret_cast<const double*>(sc.geom);
-    for (uint32_t i = threadIdx.x; i < sc.n_spheres * 4u; i += BLOCK) dst[i] = src[i];
+  unsigned long long* const wave_acc = reinterpret_cast<unsigned long long*>(lds_raw) + wave * 192u;
+  const LdsLayout lay = lds_layout(sc.n_spheres, G.n_cells, G.n_items, LDS_TABLES);
+
+  if constexpr (LDS_TABLES) {  // stage the tables once per (persistent) workgroup
+    {
+      double* dst = reinterpret_cast<double*>(lds_raw + lay.geom_off);
+      const double* src = reinterpret_cast<const double*>(sc.geom);
+      for (uint32_t i = threadIdx.x; i < sc.n_spheres * 4u; i += BLOCK) dst[i] = src[i];
+    }
+    {
+      double* dst = reinterpret_cast<double*>(lds_raw + lay.matc_off);
+      const double* src = reinterpret_cast<const double*>(sc.matc);
+      for (uint32_t i = threadIdx.x; i < sc.n_spheres * 3u; i += BLOCK) dst[i] = src[i];
+    }
+    {
+      uint32_t* dst = reinterpret_cast<uint32_t*>(lds_raw + lay.cell_off);
+      for (uint32_t i = threadIdx.x; i < G.n_cells; i += BLOCK) dst[i] = sc.cell_word[i];
+    }
+    {
+      uint16_t* dst = reinterpret_cast<uint16_t*>(lds_raw + lay.item_off);
+      for (uint32_t i = threadIdx.x; i < G.n_items; i += BLOCK) dst[i] = sc.cell_items[i];
+    }
+    __syncthreads();
   }
-  if constexpr (GEOM_LDS || POOL) __syncthreads();
+  using Tables = typename std::conditional<LDS_TABLES, LdsTables, GlobalTables>::type;
+  Tables tb;
+  const uint32_t* cell_word;
+  const uint16_t* cell_items;
+  if constexpr (LDS_TABLES) {
+    tb.g = reinterpret_cast<const double*>(lds_raw + lay.geom_off);
+    tb.m = reinterpret_cast<const MatCore*>(lds_raw + lay.matc_off);
+    cell_word = reinterpret_cast<const uint32_t*>(lds_raw + lay.cell_off);
+    cell_items = reinterpret_cast<const uint16_t*>(lds_raw + lay.item_off);
+  } else {
+    tb.g = sc.geom; tb.m = sc.matc;
+    cell_word = sc.cell_word; cell_items = sc.cell_items;
+  }
+  const F64PtrK geom_k = (F64PtrK)(uintptr_t)sc.geom;
+  const U32PtrK large_k = (U32PtrK)(uintptr_t)sc.large;
+  const uint32_t n_large = G.n_large;
+  const bool has_grid = G.n[0] != 0u;
 
-  const uint32_t tiles_x = (sc.width + TILE_W - 1) / TILE_W;
-  const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
-  const uint32_t px = bx * TILE_W + (wave & 1u) * 8u + (lane & 7u);
-  const uint32_t lr = by * TILE_H + (wave >> 1) * 8u + (lane >> 3);  // local (packed) row
-  const bool pixel_valid = px < sc.width && lr < ka.local_rows;
-  uint32_t py = lr;  // global scanline (raytracer.rs:255: band index, 0 = top)
-  if (ka.tile_rows != 0u) py = (ka.first_tile + (lr / ka.tile_rows) * ka.tile_stride) * ka.tile_rows + lr % ka.tile_rows;
-  // max_depth == 0: ray_color returns black before tracing anything (raytracer.rs:80-82)
-  bool alive = (POOL || pixel_valid) && sc.max_depth != 0u && sc.spp != 0u;
-
-  Lane<HL> L;
+  typedef Lane<HL, SIMPLE> LaneT;
+  LaneT L;
   L.s = 0; L.k = 0; L.node = 0; L.in_light = 0;
   L.val[0] = L.val[1] = L.val[2] = 0.0f;
   L.n_segments = L.n_exact = L.n_tex_oob = 0;
-  L.ra.pixel = py * sc.width + px; L.ra.sample = 0; L.ra.k0 = sc.seed_lo; L.ra.k1 = sc.seed_hi;
+  L.ra.pixel = 0; L.ra.sample = 0; L.ra.k0 = sc.seed_lo; L.ra.k1 = sc.seed_hi;
   L.o = v3(0, 0, 0); L.d = v3(0, 0, 1);
   fwd_init(L.fwd);
   if constexpr (HL) L.ls.top = 0;
-  float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;  // !POOL: pixel_colors (raytracer.rs:197)
-  uint32_t cur_p = lane;                         // POOL: tile pixel slot of the current sample
-  uint32_t next_w = 0;                           // POOL: wave-uniform cursor into the sample pool
-  const uint32_t total_w = 64u * sc.spp;         // item w = (pixel slot w & 63, sample w >> 6)
-  bool has_ray = false;                          // lane holds a live path this iteration
+  uint32_t cnt_segments = 0, cnt_exact = 0, cnt_steps = 0;  // wave-uniform (SGPR) counters
 
-  uint16_t* const my_cand = &lds_cand[wave][0][0] + lane;
-  const CullPtrK cull = (CullPtrK)(uintptr_t)sc.cull;
-  const uint32_t n_pairs = sc.n_pairs, n_spheres = sc.n_spheres;
-  bool need_new = true;
+  const uint32_t n_items = ka.n_tiles * ka.n_chunks;
+  auto fetch_item = [&]() -> uint32_t {
+    uint32_t v = 0;
+    if (lane == 0) v = atomicAdd(ka.queue, 1u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+  };
 
-  for (;;) {
-    if constexpr (POOL) {
-      const bool want = alive && need_new;
-      const unsigned long long m = __ballot(want);
-      if (m) {  // hand out the next items of the pool: item = cursor + rank among the asking lanes
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        const uint32_t w = next_w + rank;
-        next_w += (uint32_t)__builtin_popcountll(m);
-        uint32_t p = w & 63u;
-        const uint32_t p_px = __shfl(px, (int)p), p_py = __shfl(py, (int)p);
-        const int p_ok = __shfl((int)pixel_valid, (int)p);
-        if (want) {
-          if (w >= total_w) { alive = false; has_ray = false; }
-          else if (!p_ok) { has_ray = false; }  // slot outside the image: ask again next iteration
-          else {
-            cur_p = p; L.s = w >> 6; L.ra.pixel = p_py * sc.width + p_px;
-            lane_begin_sample(sc, L, p_px, p_py);
-            need_new = false; has_ray = true;
+  for (uint32_t item = fetch_item(); item < n_items; item = fetch_item()) {
+    // chunk-major order: the last items of the frame are spread over the whole image
+    const uint32_t chunk = item / ka.n_tiles, tile = item - chunk * ka.n_tiles;
+    const uint32_t by = tile / ka.tiles_x, bx = tile - by * ka.tiles_x;
+    const uint32_t px = bx * TILE + (lane & 7u);
+    const uint32_t lr = by * TILE + (lane >> 3);  // local (packed) row
+    const bool pixel_valid = px < sc.width && lr < ka.local_rows;
+    uint32_t py = lr;  // global scanline (raytracer.rs:255: band index, 0 = top)
+    if (ka.tile_rows != 0u) py = (ka.first_tile + (lr / ka.tile_rows) * ka.tile_stride) * ka.tile_rows + lr % ka.tile_rows;
+    const uint32_t s_begin = chunk * ka.chunk_spp;
+    const uint32_t s_count = sc.spp - s_begin < ka.chunk_spp ? sc.spp - s_begin : ka.chunk_spp;
+    const uint32_t total_w = 64u * s_count;  // pool item w = (pixel slot w & 63, sample s_begin + (w >> 6))
+    wave_acc[lane * 3u] = 0ull; wave_acc[lane * 3u + 1u] = 0ull; wave_acc[lane * 3u + 2u] = 0ull;
+
+    // max_depth == 0: ray_color returns black before tracing anything (raytracer.rs:80-82)
+    bool alive = sc.max_depth != 0u;
+    bool need_new = true, has_ray = false;
+    uint32_t cur_p = lane, next_w = 0;
+
+    for (;;) {
+      // ---------------------------------------------------------- refill from the sample pool
+      {
+        const bool want = alive && need_new;
+        const unsigned long long m = __ballot(want);
+        if (m) {
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          const uint32_t w = next_w + rank;
+          next_w += (uint32_t)__builtin_popcountll(m);
+          const uint32_t p = w & 63u;
+          const uint32_t p_py = (uint32_t)__shfl((int)py, (int)p);
+          const int p_ok = __shfl((int)pixel_valid, (int)p);
+          if (want) {
+            if (w >= total_w) { alive = false; has_ray = false; }
+            else if (!p_ok) { has_ray = false; }  // slot outside the image: ask again next iteration
+            else {
+              const uint32_t p_px = bx * TILE + (p & 7u);
+              cur_p = p; L.s = s_begin + (w >> 6); L.ra.pixel = p_py * sc.width + p_px;
+              lane_begin_sample(sc, L, p_px, p_py);
+              need_new = false; has_ray = true;
+            }
           }
         }
       }
-    } else {
-      if (alive && need_new) {
-        if (L.s >= sc.spp) alive = false;
-        else { lane_begin_sample(sc, L, px, py); need_new = false; }
-      }
-      has_ray = alive;
-    }
-    if (!__any(alive)) break;
+      if (!__any(alive)) break;
 
-    // ------------------------------------------------------------ hit_world (raytracer.rs:44-59)
-    const double a = length_squared(L.d);
-    double closest = T_MAX;
-    int best = -1;
-    uint32_t count = 0;
+      // ---------------------------------------------------------- hit_world (raytracer.rs:44-59)
+      const double a = length_squared(L.d);
+      double closest = T_MAX;
+      int best = -1;
+      cnt_segments += (uint32_t)__builtin_popcountll(__ballot(has_ray));
 
-    auto confirm = [&]() {  // exact Sphere::hit on this lane's own candidates, object order
-      for (uint32_t c = 0; __any(c < count); ++c) {
-        if (c < count) {
-          const uint32_t idx = my_cand[c * 64u];
-          const SphereGeom g = GEOM_LDS ? lds_geom[idx] : sc.geom[idx];
-          const double r = exact_root(L.o, L.d, a, g, T_MIN, closest);
-          L.n_exact++;
-          if (r >= 0.0) { closest = r; best = (int)idx; }
-        }
+      // (1) spheres outside the grid: every lane tests them; the record is wave-uniform -> SGPRs
+      for (uint32_t i = 0; i < n_large; ++i) {
+        const uint32_t idx = large_k[i];
+        const F64PtrK gp = geom_k + (size_t)idx * 4u;
+        SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
+        if (has_ray) exact_hit_any_order(L.o, L.d, a, g, idx, closest, best);
       }
-      count = 0;
-    };
+      cnt_exact += n_large * (uint32_t)__builtin_popcountll(__ballot(has_ray));
 
-    if constexpr (VARIANT == 1) {
-      // validation variant: the reference's brute force, exact test on every sphere
-      for (uint32_t i = 0; i < n_spheres; ++i) {
-        if (has_ray) {
-          const double r = exact_root(L.o, L.d, a, sc.geom[i], T_MIN, closest);
-          L.n_exact++;
-          if (r >= 0.0) { closest = r; best = (int)i; }
-        }
-      }
-    } else {
-      const RayF32 rf = make_ray_f32(L.o, L.d);
-      const f32x2 ox = splat(rf.ox), oy = splat(rf.oy), oz = splat(rf.oz);
-      const f32x2 dx = splat(rf.dx), dy = splat(rf.dy), dz = splat(rf.dz);
-      const f32x2 Ko = splat(rf.Ko), Am1 = splat(CULL_A - 1.0f);
-      // one pair = two spheres in 12 packed-f32 instructions; cp = 8 wave-uniform floats (SGPRs)
-      auto test_pair = [&](const float* cp, uint32_t pi) {
-        const f32x2 ocx = ox - f32x2{cp[0], cp[1]};
-        const f32x2 ocy = oy - f32x2{cp[2], cp[3]};
-        const f32x2 ocz = oz - f32x2{cp[4], cp[5]};
-        const f32x2 b = pk_fma(ocz, dz, pk_fma(ocy, dy, ocx * dx));
-        const f32x2 q = pk_fma(ocz, ocz, pk_fma(ocy, ocy, ocx * ocx));
-        const f32x2 t = pk_fma(q, Am1, f32x2{cp[6], cp[7]} + Ko);
-        const f32x2 disc = pk_fma(b, b, t);
-        const bool p0 = !(disc.x < 0.0f), p1 = !(disc.y < 0.0f);
-        if (has_ray && (p0 || p1)) {  // one branch per pair; survivors are rare (~2 of 484 per lane)
-          if (p0 && 2u * pi < n_spheres) { my_cand[count * 64u] = (uint16_t)(2u * pi); count++; }
-          if (p1 && 2u * pi + 1u < n_spheres) { my_cand[count * 64u] = (uint16_t)(2u * pi + 1u); count++; }
-        }
-      };
-      if constexpr (VARIANT == 0) {
-        // software-pipelined scan: the s_loads of chunk k+1 are issued after the first pair of
-        // chunk k, so their latency hides behind three pairs of VALU work (the table is padded
-        // by one chunk, rt_tables.h, so the last prefetch stays in bounds)
-        const uint32_t n_chunks = (n_pairs + CULL_CHUNK - 1u) / CULL_CHUNK;
-        float cur[8 * CULL_CHUNK], nxt[8 * CULL_CHUNK];
-#pragma unroll
-        for (int j = 0; j < 8 * (int)CULL_CHUNK; ++j) cur[j] = cull[j];
-        for (uint32_t ch = 0; ch < n_chunks; ++ch) {
-          if (__any(count > (uint32_t)(CAND_SLOTS - 2 * (int)CULL_CHUNK))) confirm();
-          test_pair(cur, ch * CULL_CHUNK);
-          const CullPtrK np = cull + (size_t)(ch + 1u) * (8u * CULL_CHUNK);
-#pragma unroll
-          for (int j = 0; j < 8 * (int)CULL_CHUNK; ++j) nxt[j] = np[j];
-#pragma unroll
-          for (int u = 1; u < (int)CULL_CHUNK; ++u) test_pair(cur + 8 * u, ch * CULL_CHUNK + u);
-#pragma unroll
-          for (int j = 0; j < 8 * (int)CULL_CHUNK; ++j) cur[j] = nxt[j];
-        }
-      } else {  // VARIANT 2: the first, unpipelined form (kept for A/B timing)
-        for (uint32_t base = 0; base < n_pairs; base += SCAN_CHUNK) {
-          if (__any(count > (uint32_t)(CAND_SLOTS - 2 * SCAN_CHUNK))) confirm();
-#pragma unroll
-          for (int u = 0; u < SCAN_CHUNK; ++u) {
-            const uint32_t pi = base + u;
-            if (pi >= n_pairs) break;
-            float cp[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) cp[j] = cull[(size_t)pi * 8u + j];
-            test_pair(cp, pi);
+      // (2) per-lane DDA through the grid; each lane tests the spheres its own cells list
+      if (has_grid) {
+        GridWalk w;
+        const int mode = has_ray ? grid_begin(G, L.o, L.d, w) : GRID_MISS;
+        bool walking = mode == GRID_WALK;
+        if (__any(mode == GRID_FALLBACK)) {  // numerically unsafe ray: the reference's full scan for that lane
+          for (uint32_t idx = 0; idx < sc.n_spheres; ++idx) {
+            const F64PtrK gp = geom_k + (size_t)idx * 4u;
+            SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
+            if (mode == GRID_FALLBACK) exact_hit_any_order(L.o, L.d, a, g, idx, closest, best);
           }
+          cnt_exact += sc.n_spheres * (uint32_t)__builtin_popcountll(__ballot(mode == GRID_FALLBACK));
+        }
+        uint32_t it = 0, end = 0, last = 0xFFFFFFFFu;
+        if (walking) {
+          const uint32_t word = cell_word[w.lin];
+          it = word & CELL_START_MASK; end = it + (word >> CELL_COUNT_SHIFT);
+        }
+        for (;;) {
+          // (a) lanes whose cell is exhausted move on until they stand in a cell with spheres
+          for (;;) {
+            const unsigned long long mv = __ballot(walking && it == end);
+            if (!mv) break;
+            cnt_steps += (uint32_t)__builtin_popcountll(mv);
+            if (walking && it == end) {
+              if ((best >= 0 && grid_done(w, closest)) || !grid_step(G, w)) walking = false;
+              else {
+                const uint32_t word = cell_word[w.lin];
+                it = word & CELL_START_MASK; end = it + (word >> CELL_COUNT_SHIFT);
+              }
+            }
+          }
+          const unsigned long long mt = __ballot(walking);
+          if (!mt) break;
+          // (b) one exact Sphere::hit per walking lane
+          if (walking) {
+            const uint32_t idx = cell_items[it];
+            it++;
+            if (idx != last) {  // a sphere spanning consecutive cells is not re-tested
+              last = idx;
+              exact_hit_any_order(L.o, L.d, a, tb.geom(idx), idx, closest, best);
+            }
+          }
+          cnt_exact += (uint32_t)__builtin_popcountll(mt);
         }
       }
-      confirm();
-    }
 
-    // ------------------------------------------------------------ ray_color body
-    if (has_ray) {
-      L.n_segments++;
-      need_new = lane_shade(sc, L, best, closest);
-      if (need_new) {  // sample finished: add it to its pixel (raytracer.rs:203-205)
-        if constexpr (POOL) {
+      // ---------------------------------------------------------- ray_color body
+      if (has_ray) {
+        need_new = lane_shade(sc, tb, L, best, closest);
+        if (need_new) {  // sample finished: add it to its pixel (raytracer.rs:203-205)
           atomicAdd(&wave_acc[cur_p * 3u], sample_to_fixed(L.val[0]));
           atomicAdd(&wave_acc[cur_p * 3u + 1u], sample_to_fixed(L.val[1]));
           atomicAdd(&wave_acc[cur_p * 3u + 2u], sample_to_fixed(L.val[2]));
-        } else {
-          acc0 += L.val[0]; acc1 += L.val[1]; acc2 += L.val[2];
-          L.s += 1;
+        }
+      }
+    }
+
+    // ------------------------------------------------------------ item done: flush the pixel sums
+    if (pixel_valid) {
+      const size_t o = ((size_t)lr * sc.width + px) * 3;
+      if (ka.n_chunks == 1u) {  // raytracer.rs:207-216: mean, sqrt gamma, f32 -> u8, store
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float lin = fixed_to_mean(wave_acc[lane * 3u + k], sc.spp);
+          if (ka.out_linear) ka.out_linear[o + k] = lin;
+          ka.out_rgb8[o + k] = f32_to_u8(__builtin_sqrtf(lin));
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const unsigned long long v = wave_acc[lane * 3u + k];
+          if (v) atomicAdd(&ka.accum[o + k], v);
         }
       }
     }
   }
 
-  // raytracer.rs:207-216: mean, sqrt gamma, f32 -> u8, store
-  if constexpr (POOL) __syncthreads();
-  if (pixel_valid) {
-    float lin[3];
-    if constexpr (POOL) {
-      lin[0] = fixed_to_mean(wave_acc[lane * 3u], sc.spp); lin[1] = fixed_to_mean(wave_acc[lane * 3u + 1u], sc.spp);
-      lin[2] = fixed_to_mean(wave_acc[lane * 3u + 2u], sc.spp);
-    } else {
-      const float scale = 1.0f / (float)sc.spp;
-      lin[0] = scale * acc0; lin[1] = scale * acc1; lin[2] = scale * acc2;
-    }
-    const size_t o = ((size_t)lr * sc.width + px) * 3;
+  // counters: one atomic per wave (tex_oob is per lane and almost always zero)
+  unsigned long long c2 = L.n_tex_oob;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (ka.out_linear) ka.out_linear[o + k] = lin[k];
-      ka.out_rgb8[o + k] = f32_to_u8(__builtin_sqrtf(lin[k]));
-    }
-  }
-
-  // counters: wave reduction, one atomic per wave
-  unsigned long long c0 = L.n_segments, c1 = L.n_exact, c2 = L.n_tex_oob;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    c0 += __shfl_down(c0, off); c1 += __shfl_down(c1, off); c2 += __shfl_down(c2, off);
-  }
+  for (int off = 32; off > 0; off >>= 1) c2 += __shfl_down(c2, off);
   if (lane == 0) {
-    atomicAdd(&ka.counters[0], c0); atomicAdd(&ka.counters[1], c1);
+    atomicAdd(&ka.counters[0], (unsigned long long)cnt_segments);
+    atomicAdd(&ka.counters[1], (unsigned long long)cnt_exact);
     if (c2) atomicAdd(&ka.counters[2], c2);
+    atomicAdd(&ka.counters[3], (unsigned long long)cnt_steps);
+  }
+}
+
+// Epilogue when a pixel's samples were split over several work items: fixed-point sums ->
+// mean, sqrt gamma, RGB8 (raytracer.rs:207-216).  One thread per pixel channel triple.
+__global__ void rt_resolve(const unsigned long long* accum, uint8_t* out_rgb8, float* out_linear, uint32_t n_pixels, uint32_t spp) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pixels) return;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float lin = fixed_to_mean(accum[(size_t)i * 3 + k], spp);
+    if (out_linear) out_linear[(size_t)i * 3 + k] = lin;
+    out_rgb8[(size_t)i * 3 + k] = f32_to_u8(__builtin_sqrtf(lin));
   }
 }
 

@@ -1,6 +1,9 @@
 // rt_tables.h — flatten an RtScene (include/rt_abi.h) into the HBM table layout of
 // rt_core.h::DevScene.  Plain host C++; used by rt_hip_api.hip (upload) and tests/hostsim.
 #pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -18,7 +21,147 @@ struct HostTables {
   uint64_t tex_bytes = 0;
   uint32_t n_pairs = 0;           // real pairs (cull.size() includes chunk padding)
   bool simple_colour = true;  // no lights and every albedo in [0,1]
+  // hit_world acceleration (GridDesc, rt_core.h)
+  std::vector<MatCore> matc;
+  GridDesc grid{};
+  std::vector<uint32_t> cell_word;
+  std::vector<uint16_t> cell_items;
+  std::vector<uint32_t> large;
 };
+
+// Grid construction knobs (development tunables; the defaults are what ships).
+struct GridParams {
+  double cells_per_sphere = 4.0;   // target cell count = this * gridded spheres
+  double large_radius_ratio = 16;  // |r| > ratio * median |r|  ->  `large` list
+  uint32_t large_cell_limit = 512; // a sphere covering more cells than this -> `large` list
+  uint32_t min_spheres = 24;       // fewer spheres than this: no grid, test them all
+};
+inline GridParams grid_params_from_env() {
+  GridParams p;
+  if (const char* e = std::getenv("RT_GRID_CELLS_PER_SPHERE")) p.cells_per_sphere = std::atof(e);
+  if (const char* e = std::getenv("RT_GRID_MIN_SPHERES")) p.min_spheres = (uint32_t)std::atoi(e);
+  if (const char* e = std::getenv("RT_GRID_LARGE_CELLS")) p.large_cell_limit = (uint32_t)std::atoi(e);
+  return p;
+}
+
+// Uniform grid over the ordinary spheres; see GridDesc / GRID_MARGIN in rt_core.h for what the
+// walk relies on: sphere i is listed in every cell its bounding box, grown by GRID_MARGIN
+// cells, overlaps (cells farther from the centre than the radius are dropped again).
+inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
+  const uint32_t n = sc.n_spheres;
+  GridDesc& G = t.grid;
+  std::memset(&G, 0, sizeof G);
+  t.cell_word.clear(); t.cell_items.clear(); t.large.clear();
+  auto all_large = [&]() {
+    std::memset(&G, 0, sizeof G);
+    t.cell_word.clear(); t.cell_items.clear(); t.large.resize(n);
+    for (uint32_t i = 0; i < n; ++i) t.large[i] = i;
+    G.n_large = n;
+  };
+  if (n < gp.min_spheres || n > 65535u) { all_large(); return; }
+  std::vector<uint8_t> is_large(n, 0);
+  std::vector<double> radii;
+  for (uint32_t i = 0; i < n; ++i) {
+    const RtSphere& s = sc.spheres[i];
+    const bool finite = std::isfinite(s.center[0]) && std::isfinite(s.center[1]) && std::isfinite(s.center[2]) && std::isfinite(s.radius);
+    if (!finite) is_large[i] = 1; else radii.push_back(std::fabs(s.radius));
+  }
+  if (radii.size() < gp.min_spheres) { all_large(); return; }
+  std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
+  const double r_med = radii[radii.size() / 2];
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  uint32_t n_grid = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const RtSphere& s = sc.spheres[i];
+    if (!is_large[i] && std::fabs(s.radius) > gp.large_radius_ratio * r_med) is_large[i] = 1;
+    if (is_large[i]) continue;
+    n_grid++;
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = std::min(lo[k], s.center[k] - std::fabs(s.radius));
+      hi[k] = std::max(hi[k], s.center[k] + std::fabs(s.radius));
+    }
+  }
+  if (n_grid < gp.min_spheres) { all_large(); return; }
+  double ext[3], vol = 1.0;
+  for (int k = 0; k < 3; ++k) {
+    const double pad = 1e-3 * (hi[k] - lo[k]) + 1e-9 * (std::fabs(lo[k]) + std::fabs(hi[k])) + 1e-12;
+    lo[k] -= pad; hi[k] += pad;
+    ext[k] = hi[k] - lo[k];
+    vol *= ext[k];
+  }
+  const double cell = std::cbrt(vol / std::max(1.0, gp.cells_per_sphere * n_grid));
+  for (int k = 0; k < 3; ++k) {
+    double c = std::ceil(ext[k] / cell);
+    if (!(c >= 1.0)) c = 1.0;
+    if (c > (double)GRID_MAX_AXIS) c = (double)GRID_MAX_AXIS;
+    G.n[k] = (uint32_t)c;
+    G.gmin[k] = lo[k];
+    G.inv_cell[k] = (double)G.n[k] / ext[k];
+  }
+  G.n_cells = G.n[0] * G.n[1] * G.n[2];
+  // cell range of each gridded sphere (bounding box grown by the walk's margin)
+  struct Range { int a[3], b[3]; };
+  std::vector<Range> rng(n);
+  const double m = (double)GRID_MARGIN;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (is_large[i]) continue;
+    const RtSphere& s = sc.spheres[i];
+    uint64_t cells = 1;
+    for (int k = 0; k < 3; ++k) {
+      const double r = std::fabs(s.radius);
+      double a = std::floor((s.center[k] - r - G.gmin[k]) * G.inv_cell[k] - m);
+      double b = std::floor((s.center[k] + r - G.gmin[k]) * G.inv_cell[k] + m);
+      a = std::max(a, 0.0); b = std::min(b, (double)G.n[k] - 1.0);
+      rng[i].a[k] = (int)a; rng[i].b[k] = (int)b;
+      cells *= (uint64_t)(b >= a ? (int)b - (int)a + 1 : 0);
+    }
+    if (cells > gp.large_cell_limit) is_large[i] = 1;
+  }
+  // does the cell (grown by the margin) come within |r| of the centre?  (world units, f64)
+  auto overlaps = [&](const RtSphere& s, int ix, int iy, int iz) {
+    const int idx[3] = {ix, iy, iz};
+    double d2 = 0.0;
+    for (int k = 0; k < 3; ++k) {
+      const double w = 1.0 / G.inv_cell[k];
+      const double c0 = G.gmin[k] + ((double)idx[k] - m) * w, c1 = G.gmin[k] + ((double)idx[k] + 1.0 + m) * w;
+      const double d = s.center[k] < c0 ? c0 - s.center[k] : (s.center[k] > c1 ? s.center[k] - c1 : 0.0);
+      d2 += d * d;
+    }
+    const double r = std::fabs(s.radius) * (1.0 + 1e-9);
+    return d2 <= r * r;
+  };
+  std::vector<uint32_t> count(G.n_cells, 0);
+  for (int pass = 0; pass < 2; ++pass) {
+    std::vector<uint32_t> cursor;
+    if (pass == 1) {
+      uint64_t total = 0;
+      t.cell_word.resize(G.n_cells);
+      cursor.resize(G.n_cells);
+      for (uint32_t c = 0; c < G.n_cells; ++c) {
+        if (count[c] > CELL_MAX_COUNT || total > CELL_START_MASK) { all_large(); return; }
+        t.cell_word[c] = (uint32_t)total | (count[c] << CELL_COUNT_SHIFT);
+        cursor[c] = (uint32_t)total;
+        total += count[c];
+      }
+      if (total > CELL_START_MASK) { all_large(); return; }
+      t.cell_items.resize(total);
+      G.n_items = (uint32_t)total;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+      if (is_large[i]) continue;
+      const RtSphere& s = sc.spheres[i];
+      for (int iz = rng[i].a[2]; iz <= rng[i].b[2]; ++iz)
+        for (int iy = rng[i].a[1]; iy <= rng[i].b[1]; ++iy)
+          for (int ix = rng[i].a[0]; ix <= rng[i].b[0]; ++ix) {
+            if (!overlaps(s, ix, iy, iz)) continue;
+            const uint32_t c = (uint32_t)ix + G.n[0] * ((uint32_t)iy + G.n[1] * (uint32_t)iz);
+            if (pass == 0) count[c]++; else t.cell_items[cursor[c]++] = (uint16_t)i;
+          }
+    }
+  }
+  for (uint32_t i = 0; i < n; ++i) if (is_large[i]) t.large.push_back(i);
+  G.n_large = (uint32_t)t.large.size();
+}
 
 // returns "" or a description of why the scene is invalid (RT_ERR_INVALID)
 inline std::string build_tables(const RtScene& sc, HostTables& t) {
@@ -38,6 +181,7 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
   const uint32_t n = sc.n_spheres;
   t.geom.resize(n);
   t.mat.resize(n);
+  t.matc.resize(n);
   // pairs, padded to a whole number of CULL_CHUNK-pair chunks plus one chunk of slack so the
   // scan may prefetch one chunk past the end; padding entries can never pass (R = -inf)
   const uint32_t n_pairs = (n + 1) / 2;
@@ -63,6 +207,10 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
       m.tex_nbytes = sc.textures[s.tex_id].nbytes;
     }
     t.mat[i] = m;
+    MatCore mc;
+    mc.albedo[0] = m.albedo[0]; mc.albedo[1] = m.albedo[1]; mc.albedo[2] = m.albedo[2];
+    mc.kind = m.kind; mc.fuzz_or_ior = m.fuzz_or_ior;
+    t.matc[i] = mc;
     if (s.kind == RT_MAT_LIGHT) t.lights.push_back(i);
     if (s.kind == RT_MAT_LAMBERTIAN || s.kind == RT_MAT_METAL)
       for (int c = 0; c < 3; ++c)
@@ -75,6 +223,7 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
     cp.cx[1] = cp.cx[0]; cp.cy[1] = cp.cy[0]; cp.cz[1] = cp.cz[0]; cp.R[1] = -INFINITY;
   }
   if (!t.lights.empty()) t.simple_colour = false;
+  build_grid(sc, t, grid_params_from_env());
   return "";
 }
 
@@ -89,6 +238,7 @@ inline void fill_dev_scene(const RtScene& sc, const HostTables& t, DevScene& d) 
     d.cam_h[i] = sc.cam_horizontal[i]; d.cam_v[i] = sc.cam_vertical[i];
   }
   d.sky_w = sc.sky_w; d.sky_h = sc.sky_h;
+  d.grid = t.grid;
 }
 
 }  // namespace rtc

@@ -54,8 +54,9 @@ def hostsim(abi):
     d = os.path.join(ROOT, "tests", "hostsim")
     so = os.path.join(d, "libhostsim.so")
     src = os.path.join(d, "hostsim.cpp")
-    core = os.path.join(ROOT, "rust-raytracer_amd", "csrc", "hip", "rt_core.h")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(core)):
+    deps = [src] + [os.path.join(ROOT, "rust-raytracer_amd", "csrc", "hip", f) for f in ("rt_core.h", "rt_tables.h")]
+    deps.append(os.path.join(ROOT, "include", "rt_abi.h"))
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mfma", "-fopenmp", "-Wno-unknown-pragmas",
                         "-shared", src, "-o", so], check=True)
     L = C.CDLL(so)
@@ -65,6 +66,8 @@ def hostsim(abi):
     L.hostsim_cull_disc.restype = C.c_float
     L.hostsim_exact_root.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(abi.RtSphere), C.c_double, C.c_double]
     L.hostsim_exact_root.restype = C.c_double
+    L.hostsim_grid_info.argtypes = [C.POINTER(abi.RtScene), C.POINTER(C.c_uint32)]
+    L.hostsim_hit_world.argtypes = [C.POINTER(abi.RtScene), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]
 
     def render(scene_ptr, tiles=None, mode=1):
         sc = scene_ptr.contents

@@ -18,8 +18,9 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
                  float* linear, RtStats* stats, int use_cull_flags) {
   const int use_cull = use_cull_flags & 15;
   const uint32_t rows = rt_tiles_local_rows(sc.height, tiles);
-  uint64_t segs = 0, exact = 0, oob = 0, cull_false_reject = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : segs, exact, oob, cull_false_reject)
+  uint64_t segs = 0, exact = 0, oob = 0, cull_false_reject = 0, steps = 0;
+  const GlobalTables tb{ds.geom, ds.matc};
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : segs, exact, oob, cull_false_reject, steps)
   for (uint32_t lr = 0; lr < rows; ++lr) {
     const uint32_t y = rt_tiles_global_row(tiles, lr);
     for (uint32_t x = 0; x < sc.width; ++x) {
@@ -40,6 +41,19 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
         const RayF32 rf = make_ray_f32(L.o, L.d);
         double closest = T_MAX; int best = -1;
         L.n_segments++;
+        if (use_cull == 3 || use_cull == 4) {  // the product's hit_world: `large` list + grid walk
+          uint32_t n_steps = 0;
+          hit_world_grid(ds, tb, L.o, L.d, a, closest, best, L.n_exact, n_steps);
+          steps += n_steps;
+          if (use_cull == 4) {  // audit: the reference's brute force must agree on (t, sphere), bit for bit
+            double c2 = T_MAX; int b2 = -1;
+            for (uint32_t i = 0; i < sc.n_spheres; ++i) {
+              double r = exact_root(L.o, L.d, a, t.geom[i], T_MIN, c2);
+              if (r >= 0.0) { c2 = r; b2 = (int)i; }
+            }
+            if (b2 != best || (b2 >= 0 && c2 != closest)) cull_false_reject++;
+          }
+        } else
         for (uint32_t i = 0; i < sc.n_spheres; ++i) {
           const CullPair& cp = t.cull[i / 2];
           bool pass = cull_pass(cull_disc(rf, cp.cx[i & 1], cp.cy[i & 1], cp.cz[i & 1], cp.R[i & 1]));
@@ -54,7 +68,7 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
           double r = exact_root(L.o, L.d, a, t.geom[i], T_MIN, closest);
           if (r >= 0.0) { closest = r; best = (int)i; }
         }
-        need_new = lane_shade(ds, L, best, closest);
+        need_new = lane_shade(ds, tb, L, best, closest);
         if (need_new) {
           for (int k = 0; k < 3; ++k) { acc[k] += L.val[k]; facc[k] += sample_to_fixed(L.val[k]); }
           L.s += 1;
@@ -73,13 +87,15 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
   if (stats) {
     stats->samples = (uint64_t)rows * sc.width * sc.samples_per_pixel;
     stats->segments = segs; stats->sphere_tests = segs * sc.n_spheres; stats->exact_tests = exact;
-    stats->tex_oob = oob; stats->kernel_ms = (double)cull_false_reject; stats->frame_ms = 0;
+    stats->tex_oob = oob; stats->kernel_ms = (double)cull_false_reject; stats->frame_ms = 0; stats->grid_steps = steps;
   }
 }
 }  // namespace
 
 // use_cull: 0 = exact test for every sphere, 1 = product behaviour (cull + confirm),
 //           2 = audit (stats->kernel_ms returns the number of false rejects; must be 0)
+//           3 = grid walk (the default kernel's hit_world); stats->grid_steps = DDA steps
+//           4 = grid walk audited against brute force per segment (stats->kernel_ms = mismatches)
 //           +16 = accumulate pixels in exact fixed point (the pooled-sample kernels' rule)
 extern "C" int hostsim_render(const RtScene* scene, const RtRowTiles* tiles, uint8_t* rgb8, float* linear,
                               RtStats* stats, int use_cull) {
@@ -92,6 +108,7 @@ extern "C" int hostsim_render(const RtScene* scene, const RtRowTiles* tiles, uin
     if (scene->textures[i].nbytes) std::memcpy(&blob[t.tex_off[i]], scene->textures[i].rgb8, scene->textures[i].nbytes);
   ds.geom = t.geom.data(); ds.mat = t.mat.data(); ds.cull = t.cull.data(); ds.lights = t.lights.data();
   ds.tex = blob.data(); ds.sky = scene->sky_rgb8;
+  ds.matc = t.matc.data(); ds.cell_word = t.cell_word.data(); ds.cell_items = t.cell_items.data(); ds.large = t.large.data();
   if (t.lights.empty()) render_rows<false>(*scene, t, ds, tiles, rgb8, linear, stats, use_cull);
   else render_rows<true>(*scene, t, ds, tiles, rgb8, linear, stats, use_cull);
   return RT_OK;
@@ -109,4 +126,36 @@ extern "C" double hostsim_exact_root(const double o[3], const double d[3], const
   SphereGeom g{s->center[0], s->center[1], s->center[2], s->radius};
   V3 dd = v3(d[0], d[1], d[2]);
   return exact_root(v3(o[0], o[1], o[2]), dd, length_squared(dd), g, t_min, t_max);
+}
+
+// grid layout of a scene (for tests): out = n[3], n_large, n_cells, n_items
+extern "C" int hostsim_grid_info(const RtScene* scene, uint32_t out[6]) {
+  HostTables t;
+  if (!scene || !build_tables(*scene, t).empty()) return RT_ERR_INVALID;
+  out[0] = t.grid.n[0]; out[1] = t.grid.n[1]; out[2] = t.grid.n[2];
+  out[3] = t.grid.n_large; out[4] = t.grid.n_cells; out[5] = t.grid.n_items;
+  return RT_OK;
+}
+
+// one ray against one scene through the grid and by brute force (adversarial tests):
+// out = {best_grid, best_brute}, t_out = {t_grid, t_brute}
+extern "C" int hostsim_hit_world(const RtScene* scene, const double o[3], const double d[3], int out[2], double t_out[2]) {
+  HostTables t;
+  if (!scene || !build_tables(*scene, t).empty()) return RT_ERR_INVALID;
+  DevScene ds;
+  fill_dev_scene(*scene, t, ds);
+  ds.geom = t.geom.data(); ds.matc = t.matc.data(); ds.cell_word = t.cell_word.data(); ds.cell_items = t.cell_items.data();
+  ds.large = t.large.data();
+  const GlobalTables tb{ds.geom, ds.matc};
+  V3 oo = v3(o[0], o[1], o[2]), dd = v3(d[0], d[1], d[2]);
+  const double a = length_squared(dd);
+  double c1 = T_MAX; int b1 = -1; uint32_t ne = 0, ns = 0;
+  hit_world_grid(ds, tb, oo, dd, a, c1, b1, ne, ns);
+  double c2 = T_MAX; int b2 = -1;
+  for (uint32_t i = 0; i < scene->n_spheres; ++i) {
+    double r = exact_root(oo, dd, a, t.geom[i], T_MIN, c2);
+    if (r >= 0.0) { c2 = r; b2 = (int)i; }
+  }
+  out[0] = b1; out[1] = b2; t_out[0] = c1; t_out[1] = c2;
+  return RT_OK;
 }

@@ -41,7 +41,9 @@ def test_core_matches_oracle(name, hostsim, oracle, abi, load_scene):
     scene, w, h, spp, depth, seed = CASES[name]
     sc = load_scene(scene, w, h, spp, depth, seed)
     o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
-    for mode in (1, 0):  # product behaviour (cull + exact confirm), then exact test on every sphere
+    images = []
+    # product behaviour (grid walk + exact test), round-1 kernel (cull + exact confirm), exact test on every sphere
+    for mode in (3, 1, 0):
         rgb, lin, st = hostsim.render(sc.ptr, None, mode)
         assert_parity(rgb, lin, o_rgb, o_lin, f"{name} mode {mode}")
         assert st["samples"] == o_st["samples"]
@@ -49,7 +51,27 @@ def test_core_matches_oracle(name, hostsim, oracle, abi, load_scene):
             assert st["segments"] <= o_st["segments"]
         else:
             assert st["segments"] == o_st["segments"]
+        images.append((rgb, lin))
     assert st["exact_tests"] == st["sphere_tests"]
+    for rgb, lin in images[1:]:  # hit_world variants pick the same (t, sphere) for every ray: identical bits
+        assert np.array_equal(rgb, images[0][0]) and np.array_equal(lin, images[0][1])
+
+
+def test_grid_walk_matches_brute_force_per_segment(hostsim, load_scene, host):
+    """audit mode 4: for EVERY ray segment of these renders, the grid walk and the reference's
+    object-order scan over all spheres (raytracer.rs:52-57) return the same (t, sphere) bits."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "scenes"))
+    import procedural
+    cases = [load_scene("cover", 150, 100, 4, 50), load_scene("test", 80, 60, 4, 8), load_scene("cover4k_tex", 64, 36, 2, 50),
+             host.Scene.loads(procedural.make_json(width=48, height=27, spp=2, half=50, seed=0))]
+    for sc in cases:
+        _, _, st = hostsim.render(sc.ptr, None, 4)
+        assert st["kernel_ms"] == 0.0, f"{st['kernel_ms']} segments where the grid walk disagrees with brute force"
+        if sc.c.n_spheres > 64:  # and it actually prunes
+            assert st["grid_steps"] > 0 and st["exact_tests"] < 0.05 * st["sphere_tests"]
+        else:
+            assert st["grid_steps"] == 0 and st["exact_tests"] == st["sphere_tests"]
 
 
 def test_cull_never_rejects_a_hit_in_scenes(hostsim, load_scene):
@@ -151,3 +173,89 @@ def test_degenerate_scenes(hostsim, oracle, abi, host):
                 o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
                 rgb, lin, st = hostsim.render(sc.ptr, None, 1)
                 assert_parity(rgb, lin, o_rgb, o_lin, f"depth {depth} sky {sky} objs {len(objs)}")
+
+
+def _random_scene(abi, rng, n, spread, r_lo, r_hi, big=None):
+    spheres = (abi.RtSphere * (n + (1 if big else 0)))()
+    for i in range(n):
+        c = rng.uniform(-spread, spread, 3)
+        spheres[i].center[:] = list(c)
+        spheres[i].radius = float(rng.uniform(r_lo, r_hi)) * (-1.0 if i % 11 == 0 else 1.0)
+        spheres[i].kind = abi.RT_MAT_LAMBERTIAN
+    if big:
+        spheres[n].center[:] = [0.0, -big - spread, 0.0]
+        spheres[n].radius = big
+    sc = abi.RtScene(abi_version=abi.RT_ABI_VERSION, width=4, height=4, samples_per_pixel=1, max_depth=2,
+                     spheres=spheres, n_spheres=len(spheres))
+    return sc, spheres
+
+
+def test_grid_walk_adversarial_rays(hostsim, abi):
+    """Random worlds (dense, sparse, flat, with a huge ground sphere, far from the origin) and
+    rays chosen to stress the walk: origins on sphere surfaces, grazing tangents, axis-parallel
+    and cell-boundary-aligned directions, origins far outside the grid.  The grid walk must
+    return exactly the brute-force (t, sphere) every time."""
+    rng = np.random.default_rng(77)
+    out = (C.c_int * 2)()
+    t_out = (C.c_double * 2)()
+    n_rays = n_hits = 0
+    worlds = [dict(n=200, spread=5.0, r_lo=0.05, r_hi=0.6, big=None), dict(n=600, spread=20.0, r_lo=0.1, r_hi=0.3, big=1000.0),
+              dict(n=80, spread=1.0, r_lo=0.2, r_hi=0.5, big=None), dict(n=300, spread=8.0, r_lo=0.01, r_hi=2.5, big=None)]
+    for wi, wd in enumerate(worlds):
+        sc, spheres = _random_scene(abi, rng, **wd)
+        if wi == 1:  # flat world: every centre near y = 0
+            for i in range(wd["n"]):
+                spheres[i].center[1] = float(rng.uniform(0.0, 0.3))
+        if wi == 3:  # far from the origin: large coordinates, small spheres
+            for i in range(wd["n"]):
+                for k in range(3):
+                    spheres[i].center[k] += 5000.0
+        info = (C.c_uint32 * 6)()
+        assert hostsim.hostsim_grid_info(C.byref(sc), info) == 0 and info[0] > 0, "world must be gridded"
+        n = wd["n"]
+        for trial in range(1500):
+            i = int(rng.integers(n))
+            c = np.array(spheres[i].center[:]); r = abs(spheres[i].radius)
+            kind = trial % 6
+            nrm = rng.standard_normal(3); nrm /= np.linalg.norm(nrm)
+            if kind == 0:    # leaves a sphere surface in a random direction (a bounced ray)
+                o = c + nrm * r; d = rng.standard_normal(3)
+            elif kind == 1:  # grazes sphere i: offset from the centre ~ r (1 +- tiny)
+                tdir = np.cross(nrm, rng.standard_normal(3)); tdir /= np.linalg.norm(tdir)
+                p = c + nrm * r * (1.0 + rng.choice([-1, 1]) * 10.0 ** rng.uniform(-15, -2))
+                o = p - tdir * rng.uniform(0.5, 30.0); d = tdir * rng.uniform(0.1, 3.0)
+            elif kind == 2:  # axis-parallel through the sphere's bounding box
+                ax = int(rng.integers(3)); d = np.zeros(3); d[ax] = rng.choice([-1.0, 1.0]) * rng.uniform(0.2, 2.0)
+                o = c + rng.uniform(-1.2, 1.2, 3) * r; o[ax] -= np.sign(d[ax]) * rng.uniform(1.0, 40.0)
+            elif kind == 3:  # from far outside the grid towards a sphere
+                o = c + nrm * 10.0 ** rng.uniform(1, 4.5); d = (c + rng.uniform(-1, 1, 3) * r * 1.5) - o
+            elif kind == 4:  # one direction component denormal / zero, the others diagonal
+                d = rng.choice([-1.0, 1.0], 3); d[int(rng.integers(3))] = rng.choice([0.0, -0.0, 1e-310, -1e-300, 1e-40])
+                o = c - d * rng.uniform(0.5, 10.0) + rng.uniform(-1, 1, 3) * r
+            else:            # starts inside a sphere
+                o = c + nrm * r * rng.uniform(0.0, 0.999); d = rng.standard_normal(3) * 10.0 ** rng.uniform(-3, 3)
+            assert hostsim.hostsim_hit_world(C.byref(sc), dvec(*o), dvec(*d), out, t_out) == 0
+            n_rays += 1
+            n_hits += out[1] >= 0
+            assert out[0] == out[1] and (out[0] < 0 or t_out[0] == t_out[1]), (wi, trial, kind, out[:], t_out[:])
+    assert n_hits > 0.3 * n_rays
+
+
+def test_any_order_hit_equals_object_order_scan(hostsim, abi):
+    """coincident and duplicated spheres: ties in t must go to the lowest object index
+    (raytracer.rs:52-57 keeps the first of equals), whatever order the cells list them in"""
+    rng = np.random.default_rng(5)
+    sc, spheres = _random_scene(abi, rng, 120, 4.0, 0.2, 0.5)
+    for i in range(0, 120, 3):  # exact duplicates and same-centre shells
+        spheres[i + 1].center[:] = spheres[i].center[:]
+        spheres[i + 1].radius = spheres[i].radius
+        spheres[i + 2].center[:] = spheres[i].center[:]
+    out = (C.c_int * 2)()
+    t_out = (C.c_double * 2)()
+    for trial in range(3000):
+        i = int(rng.integers(120))
+        c = np.array(spheres[i].center[:])
+        o = c + rng.standard_normal(3) * 6.0
+        d = (c + rng.standard_normal(3) * 0.2) - o
+        assert hostsim.hostsim_hit_world(C.byref(sc), dvec(*o), dvec(*d), out, t_out) == 0
+        assert out[0] == out[1] and (out[0] < 0 or t_out[0] == t_out[1]), (trial, out[:], t_out[:])

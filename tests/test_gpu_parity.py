@@ -37,9 +37,11 @@ def torch_cuda():
 def gpu_render(pkg, abi, torch_cuda):
     torch = torch_cuda
 
-    def _render(scene, tiles=None, variant=0, want_linear=True, pool=None):
-        """pool=None: the library default (pooled samples, exact fixed-point pixel sums);
-        pool=0: one lane per pixel, sequential f32 sums — the reference's order"""
+    def _render(scene, tiles=None, variant=0, want_linear=True, pool=None, chunk_spp=None):
+        """variant 0: the product kernel (grid walk, work queue, exact fixed-point pixel sums);
+        variant 1: same kernel, brute force over all spheres; variant 2: the round-1 cull-scan
+        kernel, where pool=0 selects one lane per pixel with sequential f32 sums (the
+        reference's summation order).  chunk_spp: samples of a pixel per work item."""
         sc = scene.c
         rows = abi.tiles_local_rows(sc.height, tiles)
         gs = pkg.hip.HipScene(scene.ptr, 0)
@@ -47,6 +49,8 @@ def gpu_render(pkg, abi, torch_cuda):
             gs.set_option("variant", variant)
         if pool is not None:
             gs.set_option("pool", pool)
+        if chunk_spp is not None:
+            gs.set_option("chunk_spp", chunk_spp)
         rgb = torch.zeros((rows, sc.width, 3), dtype=torch.uint8, device="cuda:0")
         lin = torch.zeros((rows, sc.width, 3), dtype=torch.float32, device="cuda:0") if want_linear else None
         gs.render(rgb.data_ptr(), lin.data_ptr() if want_linear else 0, tiles, torch.cuda.current_stream().cuda_stream)
@@ -86,20 +90,25 @@ def test_matches_oracle_and_golden(name, gpu_render, oracle, hostsim, abi, load_
     sc = load_scene(scene, w, h, spp, depth, seed)
     o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
-    # (1) reference summation order (one lane per pixel): the tight tolerance
-    rgb, lin, st = gpu_render(sc, pool=0)
+    # (1) round-1 kernel in the reference's summation order (one lane per pixel): the tight tolerance
+    rgb, lin, st = gpu_render(sc, variant=2, pool=0)
     err, flips = assert_parity(rgb, lin, o_rgb, o_lin, name + " vs oracle")
     if "tex" in name or name.startswith("test_"):
         # libm-vs-ocml atan2 can move a texel: allow isolated sample-level differences vs the frozen file
         assert np.abs(lin - g["linear"]).max() <= 0.05 and (rgb != g["rgb8"]).mean() < 1e-3
     else:
         assert_parity(rgb, lin, g["rgb8"], g["linear"], name + " vs golden")
-    # (2) the default pooled-sample kernel: same paths, exact fixed-point pixel sums
+    # (2) the product kernel: same paths (grid walk = the reference's closest hit), exact fixed-point pixel sums
     p_rgb, p_lin, p_st = gpu_render(sc)
-    p_err, p_flips = assert_parity(p_rgb, p_lin, o_rgb, o_lin, name + " pooled vs oracle", atol=pooled_atol(spp), flip_frac=5e-4)
-    h_rgb, h_lin, _ = hostsim.render(sc.ptr, None, 1 + 16)  # CPU build of the same per-lane code, fixed-point sums
+    p_err, p_flips = assert_parity(p_rgb, p_lin, o_rgb, o_lin, name + " product vs oracle", atol=pooled_atol(spp), flip_frac=5e-4)
+    h_rgb, h_lin, h_st = hostsim.render(sc.ptr, None, 3 + 16)  # CPU build of the same per-lane code, fixed-point sums
     if not ("tex" in name or name.startswith("test_")):    # integer sums are order-free: bit-exact without libm in the path
         assert np.array_equal(p_lin, h_lin) and np.array_equal(p_rgb, h_rgb)
+        assert p_st["exact_tests"] == h_st["exact_tests"] and p_st["grid_steps"] == h_st["grid_steps"]
+    # splitting a pixel's samples over several work items (HBM accumulator + epilogue) changes no bit
+    for cs in (1, 3, spp):
+        c_rgb, c_lin, c_st = gpu_render(sc, chunk_spp=cs)
+        assert np.array_equal(c_rgb, p_rgb) and np.array_equal(c_lin, p_lin) and c_st["segments"] == p_st["segments"]
     for s_ in (st, p_st):
         assert s_["samples"] == w * h * spp == o_st["samples"]
         if sc.lights():
@@ -107,22 +116,24 @@ def test_matches_oracle_and_golden(name, gpu_render, oracle, hostsim, abi, load_
         else:
             assert s_["segments"] == o_st["segments"] == int(g["segments"])
         assert s_["sphere_tests"] == s_["segments"] * sc.c.n_spheres and s_["tex_oob"] == 0
-    print(f"{name}: max|dlin|={err:.2e} (pooled {p_err:.2e}) rgb8 flips={flips} (pooled {p_flips}) exact/segment={st['exact_tests'] / max(1, st['segments']):.2f}")
+    print(f"{name}: max|dlin|={p_err:.2e} (round-1 kernel, f32 sums {err:.2e}) rgb8 flips={p_flips} ({flips}) "
+          f"exact/segment={p_st['exact_tests'] / max(1, p_st['segments']):.2f} steps/segment={p_st['grid_steps'] / max(1, p_st['segments']):.2f}")
 
 
 @pytest.mark.parametrize("scene,w,h,spp,depth", [("cover", 64, 48, 3, 50), ("test", 48, 36, 3, 8)])
-def test_cull_variant_equals_bruteforce_variant(gpu_render, load_scene, scene, w, h, spp, depth):
-    """variant 1 runs the reference's exact test on every sphere (no cull, no LDS lists):
-    both variants must produce the same bits."""
+def test_grid_variant_equals_bruteforce_variant(gpu_render, load_scene, scene, w, h, spp, depth):
+    """variant 1 runs the reference's exact test on every sphere (no grid), variant 2 is the
+    round-1 cull-scan kernel: all three must produce the same bits."""
     sc = load_scene(scene, w, h, spp, depth)
-    for pool in (0, 1):
-        a_rgb, a_lin, a_st = gpu_render(sc, variant=0, pool=pool)
-        b_rgb, b_lin, b_st = gpu_render(sc, variant=1, pool=pool)
-        c_rgb, c_lin, c_st = gpu_render(sc, variant=2, pool=pool)  # unpipelined scan
-        assert np.array_equal(a_rgb, b_rgb) and np.array_equal(a_lin, b_lin)
-        assert np.array_equal(a_rgb, c_rgb) and np.array_equal(a_lin, c_lin)
-        assert a_st["segments"] == b_st["segments"] == c_st["segments"]
-        assert b_st["exact_tests"] == b_st["sphere_tests"] > a_st["exact_tests"] == c_st["exact_tests"]
+    a_rgb, a_lin, a_st = gpu_render(sc, variant=0)
+    b_rgb, b_lin, b_st = gpu_render(sc, variant=1)
+    c_rgb, c_lin, c_st = gpu_render(sc, variant=2, pool=1)
+    assert np.array_equal(a_rgb, b_rgb) and np.array_equal(a_lin, b_lin)
+    assert np.array_equal(a_rgb, c_rgb) and np.array_equal(a_lin, c_lin)
+    assert a_st["segments"] == b_st["segments"] == c_st["segments"]
+    assert b_st["exact_tests"] == b_st["sphere_tests"] >= a_st["exact_tests"] and b_st["grid_steps"] == 0
+    if sc.c.n_spheres > 64:
+        assert a_st["grid_steps"] > 0 and a_st["exact_tests"] < 0.05 * a_st["sphere_tests"]
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])
@@ -151,9 +162,9 @@ def test_degenerate_scenes(gpu_render, oracle, abi, host):
             for objs in ("", lam, lam + "," + light, light + "," + lam + "," + light + "," + bright):
                 sc = host.Scene.loads(base % (depth, sky, objs))
                 o_rgb, o_lin, _ = oracle.render(abi, sc.ptr)
-                for pool in (0, 1):
-                    rgb, lin, _ = gpu_render(sc, pool=pool)
-                    assert_parity(rgb, lin, o_rgb, o_lin, f"depth {depth} sky {sky} objs {len(objs)} pool {pool}")
+                for variant, pool in ((0, None), (2, 0)):
+                    rgb, lin, _ = gpu_render(sc, variant=variant, pool=pool)
+                    assert_parity(rgb, lin, o_rgb, o_lin, f"depth {depth} sky {sky} objs {len(objs)} variant {variant}")
 
 
 def test_many_lights_nested_sampling(gpu_render, oracle, abi, host):
@@ -169,9 +180,9 @@ def test_many_lights_nested_sampling(gpu_render, oracle, abi, host):
     sc = host.Scene.loads(text)
     assert len(sc.lights()) == 3
     o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
-    for pool in (0, 1):
-        rgb, lin, st = gpu_render(sc, pool=pool)
-        assert_parity(rgb, lin, o_rgb, o_lin, f"3 lights pool {pool}", atol=pooled_atol(16) if pool else 2e-6)
+    for variant, pool in ((0, None), (2, 0)):
+        rgb, lin, st = gpu_render(sc, variant=variant, pool=pool)
+        assert_parity(rgb, lin, o_rgb, o_lin, f"3 lights variant {variant}", atol=2e-6 if variant else pooled_atol(16))
         assert o_lin.max() > 0.05 and st["segments"] > st["samples"]
 
 
@@ -181,10 +192,12 @@ def test_procedural_10k_spheres(gpu_render, oracle, abi, host):
     sc = host.Scene.loads(procedural.make_json(width=64, height=36, spp=2, half=50, seed=0))
     assert sc.c.n_spheres == 10001
     o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
-    for pool in (0, 1):
-        rgb, lin, st = gpu_render(sc, pool=pool)
-        assert_parity(rgb, lin, o_rgb, o_lin, f"10k spheres pool {pool}")
+    for variant, pool in ((0, None), (2, 0)):
+        rgb, lin, st = gpu_render(sc, variant=variant, pool=pool)
+        assert_parity(rgb, lin, o_rgb, o_lin, f"10k spheres variant {variant}")
         assert st["segments"] == o_st["segments"]
+        if variant == 0:  # the grid does its job: a handful of exact tests per segment instead of 10 001
+            assert st["grid_steps"] > 0 and st["exact_tests"] < 40 * st["segments"]
 
 
 def test_host_buffer_entry_point(pkg, gpu_render, load_scene):
@@ -237,7 +250,7 @@ def test_full_size_headline_config_properties(gpu_render, oracle, abi, load_scen
     s_rgb, s_lin, _ = gpu_render(sc, tiles=t)
     assert np.array_equal(s_rgb, rgb[rows]) and np.array_equal(s_lin, lin[rows])
     # exact scanlines vs the oracle at full spp (tile {1 row, first y, stride huge} = one row)
-    r_rgb, r_lin, r_st = gpu_render(sc, pool=0)  # reference summation order: tight tolerance
+    r_rgb, r_lin, r_st = gpu_render(sc, variant=2, pool=0)  # round-1 kernel, reference summation order: tight tolerance
     assert r_st["segments"] == st["segments"]
     for y in (5, 333, 640, 799):
         o_rgb, o_lin, _ = oracle.render(abi, sc.ptr, abi.RtRowTiles(1, y, 1 << 20))
