@@ -230,27 +230,30 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
           for (;;) {
             const unsigned long long mv = __ballot(walking && it == end);
             if (!mv) break;
-            cnt_steps += (uint32_t)__builtin_popcountll(mv);
+            bool stepped = false;
             if (walking && it == end) {
-              if ((best >= 0 && grid_done(w, closest)) || !grid_step(G, w)) walking = false;
+              stepped = !(best >= 0 && grid_done(w, closest));
+              if (!stepped || !grid_step(G, w)) walking = false;
               else {
                 const uint32_t word = cell_word[w.lin];
                 it = word & CELL_START_MASK; end = it + (word >> CELL_COUNT_SHIFT);
               }
             }
+            cnt_steps += (uint32_t)__builtin_popcountll(__ballot(stepped));
           }
           const unsigned long long mt = __ballot(walking);
           if (!mt) break;
           // (b) one exact Sphere::hit per walking lane
+          bool tested = false;
           if (walking) {
             const uint32_t idx = cell_items[it];
             it++;
             if (idx != last) {  // a sphere spanning consecutive cells is not re-tested
-              last = idx;
+              last = idx; tested = true;
               exact_hit_any_order(L.o, L.d, a, tb.geom(idx), idx, closest, best);
             }
           }
-          cnt_exact += (uint32_t)__builtin_popcountll(mt);
+          cnt_exact += (uint32_t)__builtin_popcountll(__ballot(tested));
         }
       }
 
