@@ -120,6 +120,10 @@ typedef struct RtStats {
   double kernel_ms;      /* device time of the render kernel(s)                             */
   double frame_ms;       /* wall time of the whole call                                     */
   uint64_t grid_steps;   /* cells entered by the grid walks of hit_world (0: no grid)       */
+  /* wave-level trip counts (diagnostics of SIMT efficiency; 0 from the CPU oracle):
+   * [0] iterations of the segment loop, [1] of the cell-step loop, [2] of the exact-test loop,
+   * [3] work items.  lane utilisation of hit_world = segments / (64 * wave_iters[0]) */
+  uint64_t wave_iters[4];
 } RtStats;
 
 /* rows this call renders (its packed RGB8 output is rows*width*3 bytes) */

@@ -492,6 +492,7 @@ int rt_oracle_render(const RtScene* scene, const RtRowTiles* tiles, uint8_t* rgb
   double t1 = now_ms();
   free(lights);
   if (stats) {
+    memset(stats, 0, sizeof *stats);
     stats->samples = (uint64_t)rows * scene->width * scene->samples_per_pixel;
     stats->segments = segments;
     stats->sphere_tests = segments * scene->n_spheres;

@@ -73,17 +73,30 @@ struct GridDesc {
   double inv_cell[3];
   uint32_t n[3];      // cells per axis; n[0] == 0: no grid (every sphere is in `large`)
   uint32_t n_large;
-  uint32_t n_cells, n_items;
+  uint32_t n_cells;   // PADDED table size (n[0]+2)*(n[1]+2)*(n[2]+2)
+  uint32_t n_items;
+  float pull;         // 8 * grid_walk_eps(max n): how far the crossing planes are pulled back
+  float pad;
 };
 constexpr uint32_t GRID_MAX_AXIS = 256;        // cells per axis (bounds the f32 error of the walk)
 constexpr uint32_t CELL_COUNT_SHIFT = 20;      // cell word = first item | (item count << 20)
 constexpr uint32_t CELL_START_MASK = (1u << CELL_COUNT_SHIFT) - 1u;
 constexpr uint32_t CELL_MAX_COUNT = 4095;
-// A sphere is registered in every cell its bounding box, grown by GRID_MARGIN cells, overlaps.
-// The f32 walk is off by at most 6u(n+3) < 1e-4 cells (u = 2^-24, n <= 256; DESIGN.md "Grid
-// walk"), 20x less than the margin, so every cell a true hit point lies in is visited or
-// neighbours a visited cell that lists the sphere as well.
-constexpr float GRID_MARGIN = 0.001953125f;    // 2^-9 cells
+// The cell table is padded by one layer of EXIT cells on every side: a walk that steps out of
+// the grid reads this word and stops — no per-axis range checks in the step.
+constexpr uint32_t CELL_EXIT = 0xFFFFFFFFu;
+// Margins, in cells (DESIGN.md "Grid walk").  The walk is an incremental f32 DDA whose crossing
+// times are off by at most eps(n) = n(n+1)u + 6u(n+3) cells of ray travel (u = 2^-24, n = the
+// largest cell count of an axis; < 4.1e-3 for n <= 256).  It runs on crossing planes pulled
+// back by GridDesc.pull = 8 eps towards the ray origin, so "closest hit before every crossing
+// time" means the hit point really lies inside the current cell.  A sphere is listed in every
+// cell its bounding box, grown by 2*pull > pull + eps, overlaps: every cell that contains a true
+// hit point is either visited or lies within that margin of a visited cell that lists the
+// sphere too.
+RT_HD double grid_walk_eps(uint32_t n_max) {
+  const double u = 5.9604644775390625e-08, n = (double)n_max;
+  return n * (n + 1.0) * u + 6.0 * u * (n + 3.0);
+}
 
 struct DevScene {
   uint32_t width, height, spp, max_depth;
@@ -295,20 +308,20 @@ RT_HD bool exact_hit_any_order(V3 o, V3 d, double a, const SphereGeom& g, uint32
 }
 
 // ------------------------------------------------------------------ grid walk (hit_world, raytracer.rs:44-59)
-// 3D-DDA over GridDesc in f32 cell units.  It only decides WHICH spheres get the exact f64
-// test; it can visit too many cells but never too few (DESIGN.md "Grid walk").
+// Incremental 3D-DDA over GridDesc in f32 cell units.  It only decides WHICH spheres get the
+// exact f64 test; it can visit too many cells but never too few (DESIGN.md "Grid walk").
 struct GridWalk {
-  float inv[3];  // 1 / direction (cell units), clamped to +-1e30
-  float c[3];    // -origin * inv, so the crossing of plane x = b is t = fma(b, inv, c)
-  float b[3];    // next boundary plane per axis (an integer)
-  int lin;       // linear index of the current cell
-  double t0;     // the walk's ray is re-originated at t0 (grid entry): t_ray = t0 + t_walk
+  float tmax[3];   // time at which the ray crosses the (pulled-back) exit plane of the current cell, per axis
+  float delta[3];  // time per cell, per axis (clamped to 1e30)
+  int dl[3];       // change of the linear (padded) cell index per step, per axis
+  int lin;         // linear index of the current cell in the padded table
+  double t0;       // the walk's clock starts at the grid entry: t_ray = t0 + t_walk
 };
 enum { GRID_MISS = 0, GRID_WALK = 1, GRID_FALLBACK = 2 };
 
 RT_HD float rt_rcpf(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __builtin_amdgcn_rcpf(x);  // 1 ulp; the walk's margins budget 3 ulp
+  return __builtin_amdgcn_rcpf(x);  // 1 ulp; the walk's margins budget several
 #else
   return 1.0f / x;
 #endif
@@ -316,6 +329,13 @@ RT_HD float rt_rcpf(float x) {
 RT_HD float rt_clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }  // NaN stays NaN
 RT_HD double rt_mind(double a, double b) { return a < b ? a : b; }
 RT_HD double rt_maxd(double a, double b) { return a > b ? a : b; }
+RT_HD float rt_min3f(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_fminf(__builtin_fminf(a, b), c);  // v_min3_f32
+#else
+  return fminf(fminf(a, b), c);
+#endif
+}
 
 // Prepare the walk of ray o + t*d.  GRID_MISS: the ray cannot touch any gridded sphere.
 // GRID_FALLBACK: numerically unsafe (non-finite input, or entry too far away for f32): the
@@ -323,11 +343,12 @@ RT_HD double rt_maxd(double a, double b) { return a > b ? a : b; }
 RT_HD int grid_begin(const GridDesc& G, V3 o, V3 d, GridWalk& w) {
   const double ol[3] = {(o.x - G.gmin[0]) * G.inv_cell[0], (o.y - G.gmin[1]) * G.inv_cell[1], (o.z - G.gmin[2]) * G.inv_cell[2]};
   const double dl[3] = {d.x * G.inv_cell[0], d.y * G.inv_cell[1], d.z * G.inv_cell[2]};
+  float inv[3];
   double tn = 0.0, tf = T_MAX;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    w.inv[k] = rt_clampf(rt_rcpf((float)dl[k]), -1e30f, 1e30f);
-    const double invd = (double)w.inv[k];
+    inv[k] = rt_clampf(rt_rcpf((float)dl[k]), -1e30f, 1e30f);
+    const double invd = (double)inv[k];
     const double t1 = (0.0 - ol[k]) * invd, t2 = ((double)G.n[k] - ol[k]) * invd;
     tn = rt_maxd(tn, rt_mind(t1, t2));
     tf = rt_mind(tf, rt_maxd(t1, t2));
@@ -337,58 +358,45 @@ RT_HD int grid_begin(const GridDesc& G, V3 o, V3 d, GridWalk& w) {
   if (tf + fabs(tf) * slack < tn - tn * slack) return GRID_MISS;
   w.t0 = tn - tn * slack;  // never later than the true entry; >= 0
   bool sane = true;
-  int cell[3];
+  int lin = 0, stride = 1;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const double op = ol[k] + w.t0 * dl[k];
     sane = sane && op >= -2.0 && op <= (double)G.n[k] + 2.0;
-    const float of = (float)op;
+    const float of = sane ? (float)op : 0.0f;
     int i = (int)floorf(of);
     i = i < 0 ? 0 : (i > (int)G.n[k] - 1 ? (int)G.n[k] - 1 : i);
-    cell[k] = i;
-    w.b[k] = (float)(i + (w.inv[k] > 0.0f ? 1 : 0));
-    w.c[k] = -of * w.inv[k];
+    const bool pos = inv[k] > 0.0f;
+    const float b = (float)(i + (pos ? 1 : 0));       // exit plane of cell i along this axis
+    w.delta[k] = fabsf(inv[k]);
+    w.tmax[k] = __builtin_fmaf(b - of, inv[k], -G.pull * w.delta[k]);
+    w.dl[k] = pos ? stride : -stride;
+    lin += (i + 1) * stride;                          // +1: the EXIT border
+    stride *= (int)G.n[k] + 2;
   }
   if (!sane) return GRID_FALLBACK;
-  w.lin = cell[0] + (int)G.n[0] * (cell[1] + (int)G.n[1] * cell[2]);
+  w.lin = lin;
   return GRID_WALK;
 }
-// Move to the next cell along the ray; false when the walk leaves the grid.  One axis moves
-// by one cell per call, so a walk ends after at most n[0]+n[1]+n[2] steps whatever the
-// arithmetic does (NaN compares false and falls through to the z axis).
-RT_HD bool grid_step(const GridDesc& G, GridWalk& w) {
-  const float tx = __builtin_fmaf(w.b[0], w.inv[0], w.c[0]);
-  const float ty = __builtin_fmaf(w.b[1], w.inv[1], w.c[1]);
-  const float tz = __builtin_fmaf(w.b[2], w.inv[2], w.c[2]);
-  const bool sx = tx <= ty && tx <= tz;
-  const bool sy = !sx && ty <= tz;
-  const bool px = w.inv[0] > 0.0f, py = w.inv[1] > 0.0f, pz = w.inv[2] > 0.0f;
-  const int nx = (int)G.n[0], nxy = (int)(G.n[0] * G.n[1]);
-  bool out;
-  if (sx) {
-    w.b[0] += px ? 1.0f : -1.0f; w.lin += px ? 1 : -1;
-    out = w.b[0] == (px ? (float)(G.n[0] + 1u) : -1.0f);
-  } else if (sy) {
-    w.b[1] += py ? 1.0f : -1.0f; w.lin += py ? nx : -nx;
-    out = w.b[1] == (py ? (float)(G.n[1] + 1u) : -1.0f);
-  } else {
-    w.b[2] += pz ? 1.0f : -1.0f; w.lin += pz ? nxy : -nxy;
-    out = w.b[2] == (pz ? (float)(G.n[2] + 1u) : -1.0f);
-  }
-  return !out;
+// Move to the next cell along the ray (the caller reads its cell word; CELL_EXIT ends the walk).
+// One axis moves by one cell per call and the table has an EXIT border, so a walk ends after
+// at most n[0]+n[1]+n[2]+3 steps whatever the arithmetic does (NaN falls through to the z axis).
+RT_HD void grid_step(GridWalk& w) {
+  const float tmin = rt_min3f(w.tmax[0], w.tmax[1], w.tmax[2]);
+  const bool sx = w.tmax[0] == tmin;
+  const bool sy = !sx && w.tmax[1] == tmin;
+  const bool sz = !sx && !sy;
+  w.tmax[0] += sx ? w.delta[0] : 0.0f;
+  w.tmax[1] += sy ? w.delta[1] : 0.0f;
+  w.tmax[2] += sz ? w.delta[2] : 0.0f;
+  w.lin += sx ? w.dl[0] : (sy ? w.dl[1] : w.dl[2]);
 }
-// True when the closest hit found so far lies inside the current cell with GRID_MARGIN to
-// spare from every exit face: no sphere listed only in later cells can be closer.
+// True when the closest hit found so far lies inside the current cell, at least GridDesc.pull cells
+// before every exit face: no sphere listed only in later cells can be closer.
 RT_HD bool grid_done(const GridWalk& w, double closest) {
   float tc = (float)(closest - w.t0);
   tc = tc + fabsf(tc) * 2.384185791015625e-07f;  // round up past the conversion (2^-22)
-  bool done = true;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float pull = w.inv[k] > 0.0f ? -GRID_MARGIN : GRID_MARGIN;
-    done = done && tc < __builtin_fmaf(w.b[k] + pull, w.inv[k], w.c[k]);
-  }
-  return done;
+  return tc < rt_min3f(w.tmax[0], w.tmax[1], w.tmax[2]);
 }
 
 // hit_world through the grid for ONE ray — the per-lane reference form of what the megakernel
@@ -413,6 +421,7 @@ RT_HD void hit_world_grid(const DevScene& sc, const Tables& tb, V3 o, V3 d, doub
   uint32_t last = 0xFFFFFFFFu;
   for (;;) {
     const uint32_t word = sc.cell_word[w.lin];
+    if (word == CELL_EXIT) return;
     const uint32_t first = word & CELL_START_MASK, count = word >> CELL_COUNT_SHIFT;
     for (uint32_t k = 0; k < count; ++k) {
       const uint32_t idx = sc.cell_items[first + k];
@@ -423,7 +432,7 @@ RT_HD void hit_world_grid(const DevScene& sc, const Tables& tb, V3 o, V3 d, doub
     }
     if (best >= 0 && grid_done(w, closest)) return;
     n_steps++;
-    if (!grid_step(G, w)) return;
+    grid_step(w);
   }
 }
 

@@ -31,7 +31,7 @@ struct KArgs {
   DevScene sc;
   uint8_t* out_rgb8;
   float* out_linear;
-  unsigned long long* counters;  // [0] segments, [1] exact tests, [2] tex_oob, [3] grid steps
+  unsigned long long* counters;  // [0] segments, [1] exact tests, [2] tex_oob, [3] grid steps, [4..7] wave trip counts
   unsigned long long* accum;     // [local pixel][3] fixed-point sums; used when n_chunks > 1
   uint32_t* queue;               // work-item cursor (zeroed before the launch)
   uint32_t local_rows, tile_rows, first_tile, tile_stride;
@@ -139,6 +139,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   fwd_init(L.fwd);
   if constexpr (HL) L.ls.top = 0;
   uint32_t cnt_segments = 0, cnt_exact = 0, cnt_steps = 0;  // wave-uniform (SGPR) counters
+  uint32_t cnt_w_iter = 0, cnt_w_step = 0, cnt_w_test = 0, cnt_items = 0;
 
   const uint32_t n_items = ka.n_tiles * ka.n_chunks;
   auto fetch_item = [&]() -> uint32_t {
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     const uint32_t s_count = sc.spp - s_begin < ka.chunk_spp ? sc.spp - s_begin : ka.chunk_spp;
     const uint32_t total_w = 64u * s_count;  // pool item w = (pixel slot w & 63, sample s_begin + (w >> 6))
     wave_acc[lane * 3u] = 0ull; wave_acc[lane * 3u + 1u] = 0ull; wave_acc[lane * 3u + 2u] = 0ull;
+    cnt_items++;
 
     // max_depth == 0: ray_color returns black before tracing anything (raytracer.rs:80-82)
     bool alive = sc.max_depth != 0u;
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         }
       }
       if (!__any(alive)) break;
+      cnt_w_iter++;
 
       // ---------------------------------------------------------- hit_world (raytracer.rs:44-59)
       const double a = length_squared(L.d);
@@ -228,21 +231,24 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         for (;;) {
           // (a) lanes whose cell is exhausted move on until they stand in a cell with spheres
           for (;;) {
-            const unsigned long long mv = __ballot(walking && it == end);
-            if (!mv) break;
+            const bool moving = walking && it == end;
+            if (!__any(moving)) break;
+            cnt_w_step++;
             bool stepped = false;
-            if (walking && it == end) {
+            if (moving) {
               stepped = !(best >= 0 && grid_done(w, closest));
-              if (!stepped || !grid_step(G, w)) walking = false;
-              else {
+              if (stepped) {
+                grid_step(w);
                 const uint32_t word = cell_word[w.lin];
                 it = word & CELL_START_MASK; end = it + (word >> CELL_COUNT_SHIFT);
-              }
+                if (word == CELL_EXIT) { walking = false; end = it; }
+              } else walking = false;
             }
             cnt_steps += (uint32_t)__builtin_popcountll(__ballot(stepped));
           }
           const unsigned long long mt = __ballot(walking);
           if (!mt) break;
+          cnt_w_test++;
           // (b) one exact Sphere::hit per walking lane
           bool tested = false;
           if (walking) {
@@ -297,6 +303,10 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     atomicAdd(&ka.counters[1], (unsigned long long)cnt_exact);
     if (c2) atomicAdd(&ka.counters[2], c2);
     atomicAdd(&ka.counters[3], (unsigned long long)cnt_steps);
+    atomicAdd(&ka.counters[4], (unsigned long long)cnt_w_iter);
+    atomicAdd(&ka.counters[5], (unsigned long long)cnt_w_step);
+    atomicAdd(&ka.counters[6], (unsigned long long)cnt_w_test);
+    atomicAdd(&ka.counters[7], (unsigned long long)cnt_items);
   }
 }
 

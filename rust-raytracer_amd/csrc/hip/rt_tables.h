@@ -44,8 +44,8 @@ inline GridParams grid_params_from_env() {
   return p;
 }
 
-// Uniform grid over the ordinary spheres; see GridDesc / GRID_MARGIN in rt_core.h for what the
-// walk relies on: sphere i is listed in every cell its bounding box, grown by GRID_MARGIN
+// Uniform grid over the ordinary spheres; see GridDesc / 2*GridDesc.pull in rt_core.h for what the
+// walk relies on: sphere i is listed in every cell its bounding box, grown by 2*GridDesc.pull
 // cells, overlaps (cells farther from the centre than the radius are dropped again).
 inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
   const uint32_t n = sc.n_spheres;
@@ -98,11 +98,14 @@ inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
     G.gmin[k] = lo[k];
     G.inv_cell[k] = (double)G.n[k] / ext[k];
   }
-  G.n_cells = G.n[0] * G.n[1] * G.n[2];
+  G.pull = (float)(8.0 * grid_walk_eps(std::max(G.n[0], std::max(G.n[1], G.n[2]))));
+  const uint32_t n_inner = G.n[0] * G.n[1] * G.n[2];
+  const uint32_t px = G.n[0] + 2, py = G.n[1] + 2, pz = G.n[2] + 2;  // padded with the EXIT border
+  G.n_cells = px * py * pz;
   // cell range of each gridded sphere (bounding box grown by the walk's margin)
   struct Range { int a[3], b[3]; };
   std::vector<Range> rng(n);
-  const double m = (double)GRID_MARGIN;
+  const double m = 2.0 * (double)G.pull;  // registration margin (rt_core.h "Margins")
   for (uint32_t i = 0; i < n; ++i) {
     if (is_large[i]) continue;
     const RtSphere& s = sc.spheres[i];
@@ -130,20 +133,24 @@ inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
     const double r = std::fabs(s.radius) * (1.0 + 1e-9);
     return d2 <= r * r;
   };
-  std::vector<uint32_t> count(G.n_cells, 0);
+  std::vector<uint32_t> count(n_inner, 0);
+  auto padded = [&](uint32_t c) {
+    const uint32_t ix = c % G.n[0], iy = (c / G.n[0]) % G.n[1], iz = c / (G.n[0] * G.n[1]);
+    return (ix + 1) + px * ((iy + 1) + py * (iz + 1));
+  };
   for (int pass = 0; pass < 2; ++pass) {
     std::vector<uint32_t> cursor;
     if (pass == 1) {
       uint64_t total = 0;
-      t.cell_word.resize(G.n_cells);
-      cursor.resize(G.n_cells);
-      for (uint32_t c = 0; c < G.n_cells; ++c) {
-        if (count[c] > CELL_MAX_COUNT || total > CELL_START_MASK) { all_large(); return; }
-        t.cell_word[c] = (uint32_t)total | (count[c] << CELL_COUNT_SHIFT);
+      t.cell_word.assign(G.n_cells, CELL_EXIT);
+      cursor.resize(n_inner);
+      for (uint32_t c = 0; c < n_inner; ++c) {
+        if (count[c] > CELL_MAX_COUNT || total >= CELL_START_MASK) { all_large(); return; }
+        t.cell_word[padded(c)] = (uint32_t)total | (count[c] << CELL_COUNT_SHIFT);
         cursor[c] = (uint32_t)total;
         total += count[c];
       }
-      if (total > CELL_START_MASK) { all_large(); return; }
+      if (total >= CELL_START_MASK) { all_large(); return; }
       t.cell_items.resize(total);
       G.n_items = (uint32_t)total;
     }

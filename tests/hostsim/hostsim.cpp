@@ -85,6 +85,7 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
     }
   }
   if (stats) {
+    std::memset(stats, 0, sizeof *stats);
     stats->samples = (uint64_t)rows * sc.width * sc.samples_per_pixel;
     stats->segments = segs; stats->sphere_tests = segs * sc.n_spheres; stats->exact_tests = exact;
     stats->tex_oob = oob; stats->kernel_ms = (double)cull_false_reject; stats->frame_ms = 0; stats->grid_steps = steps;

@@ -20,23 +20,39 @@ import __graft_entry__ as graft  # noqa: E402
 AB = os.path.join(ROOT, "build", "ab")
 SRC = os.path.join(ROOT, "rust-raytracer_amd", "csrc", "hip", "rt_hip_api.hip")
 BASE = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
-# name -> (extra compile flags, runtime options)
+# name -> (extra compile flags, runtime options, environment at scene creation)
+W4 = ["-DRT_WAVES_PER_EU=4"]
 VARIANTS = {
-    "w2_ch4_pool": ([], {}),
-    "w4_ch4_pool": (["-DRT_WAVES_PER_EU=4"], {}),
-    "w4_ch4_nopool": (["-DRT_WAVES_PER_EU=4"], {"pool": 0}),
-    "w3_ch4_pool": (["-DRT_WAVES_PER_EU=3"], {}),
-    "w4_ch2_pool": (["-DRT_WAVES_PER_EU=4", "-DRT_CULL_CHUNK=2"], {}),
-    "w4_nopipe_pool": (["-DRT_WAVES_PER_EU=4"], {"variant": 2}),
-    "w5_ch2_pool": (["-DRT_WAVES_PER_EU=5", "-DRT_CULL_CHUNK=2"], {}),
-    "w2_nopipe_nopool": ([], {"variant": 2, "pool": 0}),
+    "b512_w4": (W4, {}, {}),
+    "b256_w4": (W4 + ["-DRT_BLOCK=256"], {}, {}),
+    "b1024_w4": (W4 + ["-DRT_BLOCK=1024"], {}, {}),
+    "b256_w3": (["-DRT_WAVES_PER_EU=3", "-DRT_BLOCK=256"], {}, {}),
+    "b256_w5": (["-DRT_WAVES_PER_EU=5", "-DRT_BLOCK=256"], {}, {}),
+    "b512_w2": (["-DRT_WAVES_PER_EU=2"], {}, {}),
+    "b512_w4_chunk8": (W4, {"chunk_spp": 8}, {}),
+    "b512_w4_chunk16": (W4, {"chunk_spp": 16}, {}),
+    "b512_w4_chunk64": (W4, {"chunk_spp": 64}, {}),
+    "b512_w4_chunk128": (W4, {"chunk_spp": 128}, {}),
+    "b512_w4_cps2": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "2"}),
+    "b512_w4_cps8": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "8"}),
+    "b512_w4_cps16": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "16"}),
+    "b512_w4_brute": (W4, {"variant": 1}, {}),
+    "round1_scan": (W4, {"variant": 2}, {}),
 }
 
 
 def build():
     os.makedirs(AB, exist_ok=True)
-    for name, (flags, _) in VARIANTS.items():
+    built = {}
+    for name, (flags, _, _) in VARIANTS.items():
         out = os.path.join(AB, f"librt_hip_{name}.so")
+        key = tuple(flags)
+        if key in built:  # same binary, different runtime options
+            if os.path.lexists(out):
+                os.remove(out)
+            os.link(built[key], out)
+            continue
+        built[key] = out
         cmd = BASE + flags + [SRC, "-o", out]
         print("+", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -65,7 +81,7 @@ def run(rounds, scene_path, only):
     rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     libs, ref = {}, {}
-    for name, (_, opts) in VARIANTS.items():
+    for name, (_, opts, env) in VARIANTS.items():
         if only and name not in only:
             continue
         path = os.path.join(AB, f"librt_hip_{name}.so")
@@ -73,11 +89,15 @@ def run(rounds, scene_path, only):
             continue
         L = bind(path, abi)
         hs = C.c_void_p()
+        os.environ.update(env)
         assert L.rt_hip_scene_create(sc.ptr, 0, C.byref(hs)) == 0, L.rt_hip_last_error()
+        for k in env:
+            del os.environ[k]
         for k, v in opts.items():
             assert L.rt_hip_set_option(hs, k.encode(), v) == 0
         libs[name] = (L, hs, [], opts.get("pool", 1))
     st = abi.RtStats()
+    stats = {}
     for r in range(rounds + 1):  # round 0 = warm-up + image check
         for name, (L, hs, times, pool) in libs.items():
             assert L.rt_hip_render(hs, None, rgb.data_ptr(), None, stream) == 0, L.rt_hip_last_error()
@@ -88,12 +108,14 @@ def run(rounds, scene_path, only):
                 assert np.array_equal(img, ref[pool]), f"{name}: image differs from the first variant of its accumulation mode"
             else:
                 times.append(st.kernel_ms)
+            stats[name] = (st.exact_tests, st.grid_steps, st.segments)
     samples = w * h * sc.c.samples_per_pixel
     for name, (L, hs, times, pool) in libs.items():
         med = statistics.median(times)
         print(json.dumps({"variant": name, "kernel_ms_median": round(med, 3), "kernel_ms_min": round(min(times), 3),
                           "msamples_per_s": round(samples / med / 1e3, 1), "rounds": rounds,
-                          "exact_per_segment": round(st.exact_tests / max(1, st.segments), 3)}), flush=True)
+                          "exact_per_segment": round(stats[name][0] / max(1, stats[name][2]), 3),
+                          "steps_per_segment": round(stats[name][1] / max(1, stats[name][2]), 3)}), flush=True)
         L.rt_hip_scene_destroy(hs)
 
 
