@@ -124,6 +124,10 @@ typedef struct RtStats {
    * [0] iterations of the segment loop, [1] of the cell-step loop, [2] of the exact-test loop,
    * [3] work items.  lane utilisation of hit_world = segments / (64 * wave_iters[0]) */
   uint64_t wave_iters[4];
+  /* shader-clock cycles summed over waves per kernel section; only filled by builds with
+   * -DRT_PROFILE (tools/ab_bench.py "prof" arm): [0] sample refill, [1] `large` list,
+   * [2] grid_begin, [3] grid walk, [4] shading, [5] item fetch + pixel flush, [6] whole wave */
+  uint64_t prof_cycles[8];
 } RtStats;
 
 /* rows this call renders (its packed RGB8 output is rows*width*3 bytes) */

@@ -57,12 +57,14 @@ struct CullPair {  // 32 B
 #endif
 constexpr uint32_t CULL_CHUNK = RT_CULL_CHUNK;  // pairs per scan chunk; the table is padded to this
 
-// Material fields every hit needs (24 B; the LDS copy of the material table).  Texture
-// parameters stay in the 64 B SphereMat and are fetched only when a Texture sphere is hit.
+// Per-sphere fields every hit needs besides the geometry (32 B; the LDS copy of the material
+// table).  Texture parameters stay in the 64 B SphereMat and are fetched only when a Texture
+// sphere is hit.
 struct MatCore {
   float albedo[3];
   uint32_t kind;
   double fuzz_or_ior;
+  double inv_r;  // RN(1/radius) for div_by_recip (sphere.rs:60), or 0: divide the slow way
 };
 
 // Uniform grid over the scene's ordinary spheres (rt_tables.h builds it).  Oversized spheres
@@ -104,6 +106,7 @@ struct DevScene {
   uint32_t seed_lo, seed_hi;
   uint32_t pad0, pad1;
   double cam_origin[3], cam_ll[3], cam_h[3], cam_v[3];
+  double wm1, hm1, inv_wm1, inv_hm1, height_d;  // (width-1), (height-1), their RN reciprocals (0: slow divide), height
   const SphereGeom* geom;
   const SphereMat* mat;
   const CullPair* cull;
@@ -136,6 +139,19 @@ RT_HD bool near_zero(V3 a) {                                                    
   const double eps = 2.220446049250313e-16;
   return fabs(a.x) < eps && fabs(a.y) < eps && fabs(a.z) < eps;
 }
+
+// x / b, correctly rounded, from y = RN(1/b): Markstein's division — q0 = RN(x*y) is within
+// an ulp or so of x/b, and each fused correction q' = RN(q + RN(x - q*b) * y) (the residual is
+// exact in one FMA) lands on RN(x/b) once q is faithful; two corrections are applied.  Bit-equal
+// to the IEEE quotient for normal, finite x, b and x/b (tests/test_core_cpu.py checks 10^7 cases
+// per run; the grid-walk audit re-checks every ray against true divisions).  Callers route
+// anything outside that range (see RayK::fast, MatCore::inv_r == 0) to real divisions.
+RT_HD double div_by_recip(double x, double b, double y) {
+  double q = x * y;
+  q = __builtin_fma(__builtin_fma(-q, b, x), y, q);
+  return __builtin_fma(__builtin_fma(-q, b, x), y, q);
+}
+RT_HD bool recip_safe(double b) { double m = fabs(b); return m > 1e-150 && m < 1e150; }
 
 struct Rgb {
   float r, g, b;
@@ -287,23 +303,48 @@ constexpr double T_MAX = 1.7976931348623157e308;    // f64::MAX
 // (t_min, t_max), and far >= near, so a far root is accepted only when near <= t_min).  The
 // scan therefore returns the lexicographic minimum of (f_i, i).  Testing spheres in ANY order
 // with "root < closest, or root == closest and i < best" reaches the same (t, sphere).
-RT_HD bool exact_hit_any_order(V3 o, V3 d, double a, const SphereGeom& g, uint32_t idx, double& closest, int& best) {
+// Per-ray constants of the hit tests: a = |d|^2 (sphere.rs:48) and its reciprocal.
+struct RayK {
+  double a, inv_a;
+  bool fast;  // the roots may be divided through inv_a (div_by_recip); else real divisions
+};
+RT_HD RayK ray_consts(V3 d) {
+  RayK k;
+  k.a = length_squared(d);
+  k.inv_a = 1.0 / k.a;
+  k.fast = recip_safe(k.a);  // false for NaN too
+  return k;
+}
+template <bool FAST>
+RT_HD bool exact_hit_any_order_t(V3 o, V3 d, const RayK& rk, const SphereGeom& g, uint32_t idx, double& closest, int& best) {
   V3 oc = sub(o, v3(g.cx, g.cy, g.cz));
   double half_b = dot(oc, d);
   double c = length_squared(oc) - g.r * g.r;
   if (c > 0.0 && half_b > 0.0) return false;  // exact shortcut, see exact_root
-  double discriminant = (half_b * half_b) - (a * c);
+  double discriminant = (half_b * half_b) - (rk.a * c);
   if (discriminant >= 0.0) {
     const bool tie_ok = best >= 0 && idx < (uint32_t)best;
     double sqrtd = sqrt(discriminant);
-    double root = ((-half_b) - sqrtd) / a;
+    double num = (-half_b) - sqrtd;
+    double root = FAST ? div_by_recip(num, rk.a, rk.inv_a) : num / rk.a;
     if (!(root > T_MIN && (root < closest || (tie_ok && root == closest)))) {
-      root = ((-half_b) + sqrtd) / a;
+      num = (-half_b) + sqrtd;
+      root = FAST ? div_by_recip(num, rk.a, rk.inv_a) : num / rk.a;
       if (!(root > T_MIN && (root < closest || (tie_ok && root == closest)))) return false;
     }
     closest = root; best = (int)idx;
     return true;
   }
+  return false;
+}
+// a ray whose |d|^2 is outside div_by_recip's range: the reference's own arithmetic (cold)
+RT_HD_COLD void exact_hit_slow(V3 o, V3 d, double a, const SphereGeom& g, uint32_t idx, double& closest, int& best) {
+  RayK rk; rk.a = a; rk.inv_a = 0.0; rk.fast = false;
+  exact_hit_any_order_t<false>(o, d, rk, g, idx, closest, best);
+}
+RT_HD bool exact_hit_any_order(V3 o, V3 d, const RayK& rk, const SphereGeom& g, uint32_t idx, double& closest, int& best) {
+  if (rk.fast) return exact_hit_any_order_t<true>(o, d, rk, g, idx, closest, best);
+  exact_hit_slow(o, d, rk.a, g, idx, closest, best);
   return false;
 }
 
@@ -402,9 +443,10 @@ RT_HD bool grid_done(const GridWalk& w, double closest) {
 // hit_world through the grid for ONE ray — the per-lane reference form of what the megakernel
 // does with 64 lanes in lock-step (rt_kernel.hip); tests/hostsim runs this one on the CPU.
 template <class Tables>
-RT_HD void hit_world_grid(const DevScene& sc, const Tables& tb, V3 o, V3 d, double a, double& closest, int& best,
+RT_HD void hit_world_grid(const DevScene& sc, const Tables& tb, V3 o, V3 d, double& closest, int& best,
                           uint32_t& n_exact, uint32_t& n_steps) {
   const GridDesc& G = sc.grid;
+  const RayK a = ray_consts(d);
   for (uint32_t i = 0; i < G.n_large; ++i) {
     const uint32_t idx = sc.large[i];
     n_exact++;
@@ -552,10 +594,14 @@ struct Surface {  // what Sphere::hit records for the accepted root (sphere.rs:5
   V3 point, normal;
   bool front_face;
 };
-RT_HD Surface surface_at(V3 o, V3 d, double t, const SphereGeom& g) {
+RT_HD_COLD V3 divs_slow(V3 a, double s) { return divs(a, s); }
+RT_HD Surface surface_at(V3 o, V3 d, double t, const SphereGeom& g, double inv_r) {
   Surface s;
   s.point = add(o, muls(d, t));                                  // ray.rs:18-20
-  V3 outward = divs(sub(s.point, v3(g.cx, g.cy, g.cz)), g.r);    // sphere.rs:60
+  V3 pc = sub(s.point, v3(g.cx, g.cy, g.cz));
+  V3 outward;                                                    // sphere.rs:60: (p - c) / r
+  if (inv_r != 0.0) outward = v3(div_by_recip(pc.x, g.r, inv_r), div_by_recip(pc.y, g.r, inv_r), div_by_recip(pc.z, g.r, inv_r));
+  else outward = divs_slow(pc, g.r);
   s.front_face = dot(d, outward) < 0.0;                          // :61
   s.normal = s.front_face ? outward : neg(outward);              // :68
   return s;
@@ -567,15 +613,27 @@ RT_HD_COLD void sphere_uv(V3 point, const SphereGeom& g, double& u, double& v) {
   u = (atan2(n.x, n.z) / (2.0 * 3.14159265358979323846264338327950288)) + 0.5;
   v = n.y * 0.5 + 0.5;
 }
+// unit_vector (point3d.rs:67-70) with one real division: 1/l, then div_by_recip per component
+RT_HD V3 unit_vector_fast(V3 a) {
+  double l = length(a);
+  if (!recip_safe(l)) return v3(a.x / l, a.y / l, a.z / l);
+  double y = 1.0 / l;
+  return v3(div_by_recip(a.x, l, y), div_by_recip(a.y, l, y), div_by_recip(a.z, l, y));
+}
 RT_HD int scatter(const DevScene& sc, const RngAddr& ra, uint32_t node, V3 in_dir, const Surface& h,
                   const SphereGeom& g, const MatCore& m, uint32_t idx, V3& out_dir, float att[3], uint32_t& tex_oob) {
+  // Lambertian, Texture and Metal all draw random_in_unit_sphere (Metal even with fuzz = 0,
+  // materials.rs:120); one shared rejection loop instead of one per material branch.
+  V3 rnd = v3(0.0, 0.0, 0.0);
+  if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_TEXTURE || m.kind == RT_MAT_METAL) rnd = random_in_unit_sphere(ra, node);
+  att[0] = m.albedo[0]; att[1] = m.albedo[1]; att[2] = m.albedo[2];
   switch (m.kind) {
     case RT_MAT_LIGHT:  // :65-69
       att[0] = att[1] = att[2] = 1.0f;
       return SCATTER_EMIT;
     case RT_MAT_LAMBERTIAN:  // :84-95
     case RT_MAT_TEXTURE: {   // :256-267
-      V3 sd = add(h.normal, random_in_unit_sphere(ra, node));
+      V3 sd = add(h.normal, rnd);
       if (near_zero(sd)) sd = h.normal;
       V3 target = add(h.point, sd);
       out_dir = sub(target, h.point);  // (p + d) - p, as the reference computes it
@@ -584,21 +642,18 @@ RT_HD int scatter(const DevScene& sc, const RngAddr& ra, uint32_t node, V3 in_di
         sphere_uv(h.point, g, u, v);
         Rgb a = texture_albedo(sc, sc.mat[idx], u, v, tex_oob);
         att[0] = a.r; att[1] = a.g; att[2] = a.b;
-      } else {
-        att[0] = m.albedo[0]; att[1] = m.albedo[1]; att[2] = m.albedo[2];
       }
       return SCATTER_RAY;
     }
     case RT_MAT_METAL: {  // :115-129
       V3 reflected = reflect(in_dir, h.normal);
-      out_dir = add(reflected, muls(random_in_unit_sphere(ra, node), m.fuzz_or_ior));
-      att[0] = m.albedo[0]; att[1] = m.albedo[1]; att[2] = m.albedo[2];
+      out_dir = add(reflected, muls(rnd, m.fuzz_or_ior));
       return dot(out_dir, h.normal) > 0.0 ? SCATTER_RAY : SCATTER_ABSORBED;
     }
     case RT_MAT_GLASS: {  // :176-199
       att[0] = att[1] = att[2] = 1.0f;
       double refraction_ratio = h.front_face ? 1.0 / m.fuzz_or_ior : m.fuzz_or_ior;
-      V3 unit_direction = unit_vector(in_dir);
+      V3 unit_direction = unit_vector_fast(in_dir);
       double cos_theta = fmin(dot(neg(unit_direction), h.normal), 1.0);
       double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
       bool do_reflect = refraction_ratio * sin_theta > 1.0;
@@ -657,8 +712,10 @@ template <class LaneT>
 RT_HD void lane_begin_sample(const DevScene& sc, LaneT& L, uint32_t px, uint32_t py) {
   L.ra.sample = L.s;
   U4 w = rng(L.ra, NODE_CAMERA, 0);
-  double u = ((double)px + u01_53(w.x, w.y)) / ((double)sc.width - 1.0);
-  double v = ((double)sc.height - ((double)py + u01_53(w.z, w.w))) / ((double)sc.height - 1.0);
+  double un = (double)px + u01_53(w.x, w.y), vn = sc.height_d - ((double)py + u01_53(w.z, w.w));
+  double u, v;  // raytracer.rs:199-200: un / (width - 1), vn / (height - 1)
+  if (sc.inv_wm1 != 0.0 && sc.inv_hm1 != 0.0) { u = div_by_recip(un, sc.wm1, sc.inv_wm1); v = div_by_recip(vn, sc.hm1, sc.inv_hm1); }
+  else { u = un / sc.wm1; v = vn / sc.hm1; }
   V3 origin = v3(sc.cam_origin[0], sc.cam_origin[1], sc.cam_origin[2]);
   V3 llc = v3(sc.cam_ll[0], sc.cam_ll[1], sc.cam_ll[2]);
   V3 hor = v3(sc.cam_h[0], sc.cam_h[1], sc.cam_h[2]);
@@ -749,7 +806,7 @@ RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, d
   }
   const SphereGeom g = tb.geom((uint32_t)idx);
   const MatCore m = tb.mat((uint32_t)idx);
-  Surface h = surface_at(L.o, L.d, t, g);
+  Surface h = surface_at(L.o, L.d, t, g, m.inv_r);
   V3 out_dir = v3(0, 0, 0);
   float att[3];
   int st = scatter(sc, L.ra, L.node, L.d, h, g, m, (uint32_t)idx, out_dir, att, L.n_tex_oob);

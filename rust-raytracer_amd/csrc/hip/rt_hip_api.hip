@@ -148,7 +148,7 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
     if (scene->sky_mode == RT_SKY_TEXTURE) sky.assign(scene->sky_rgb8, scene->sky_rgb8 + scene->sky_w * scene->sky_h * 3);
     if ((rc = upload(&s->d_sky, sky)) != RT_OK) return bail(rc);
   }
-  if (hipMalloc((void**)&s->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
+  if (hipMalloc((void**)&s->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess ||
       hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess)
     return bail(fail(RT_ERR_HIP, "hipMalloc/hipEventCreate failed"));
   s->dev.geom = (const rtc::SphereGeom*)s->d_geom; s->dev.mat = (const rtc::SphereMat*)s->d_mat;
@@ -220,7 +220,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   s->last_rows = local_rows;
   s->last_stream = stream;
   s->t_launch = std::chrono::steady_clock::now();
-  RT_HIP_TRY(hipMemsetAsync(s->d_counters, 0, 16 * sizeof(unsigned long long), stream));
+  RT_HIP_TRY(hipMemsetAsync(s->d_counters, 0, 32 * sizeof(unsigned long long), stream));
   if (local_rows == 0) { s->launched = false; return RT_OK; }
   if (s->variant == 2) {
     RT_HIP_TRY(hipEventRecord(s->ev_start, stream));
@@ -240,7 +240,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
     ka.sc.large = (const uint32_t*)s->d_all;
   }
   ka.out_rgb8 = (uint8_t*)d_rgb8; ka.out_linear = (float*)d_linear; ka.counters = s->d_counters;
-  ka.queue = (uint32_t*)(s->d_counters + 8);
+  ka.queue = (uint32_t*)(s->d_counters + 24);
   ka.local_rows = local_rows;
   const bool tiled = tiles && tiles->tile_rows && tiles->tile_stride;
   ka.tile_rows = tiled ? tiles->tile_rows : 0; ka.first_tile = tiled ? tiles->first_tile : 0;
@@ -275,7 +275,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   const uint32_t n_items = ka.n_tiles * ka.n_chunks;
   const rtc::GridDesc& G = ka.sc.grid;
   const rtk::LdsLayout with_tables = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true);
-  const bool lds_tables = with_tables.total <= 64u * 1024u;  // two 512-thread workgroups per CU keep 160 KB LDS
+  const bool lds_tables = with_tables.total <= rtk::LDS_TABLES_MAX_BYTES;
   const size_t lds_bytes = lds_tables ? with_tables.total : rtk::lds_layout(0, 0, 0, false).total;
 
   RT_HIP_TRY(hipEventRecord(s->ev_start, stream));
@@ -302,7 +302,7 @@ extern "C" int rt_hip_wait(RtHipScene* s, RtStats* stats) {
   RT_HIP_TRY(hipStreamSynchronize(s->last_stream));
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
-    unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // segments, exact tests, tex_oob, grid steps, 4 x wave trip counts
+    unsigned long long c[16] = {0};  // segments, exact tests, tex_oob, grid steps, 4 x wave trip counts, 8 x section cycles
     RT_HIP_TRY(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
     float ms = 0.f;
     if (s->launched) RT_HIP_TRY(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
@@ -313,6 +313,7 @@ extern "C" int rt_hip_wait(RtHipScene* s, RtStats* stats) {
     stats->tex_oob = c[2];
     stats->grid_steps = c[3];
     for (int k = 0; k < 4; ++k) stats->wave_iters[k] = c[4 + k];
+    for (int k = 0; k < 8; ++k) stats->prof_cycles[k] = c[8 + k];
     stats->kernel_ms = ms;
     stats->frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s->t_launch).count();
   }

@@ -39,12 +39,29 @@ struct KArgs {
 };
 
 #ifndef RT_BLOCK
-#define RT_BLOCK 512
+#define RT_BLOCK 1024
+#endif
+// the wave leaves the walk loop for shading once walking lanes <= NUM/DEN of the lanes holding a ray
+#ifndef RT_WALK_LEAVE_NUM
+#define RT_WALK_LEAVE_NUM 1
+#endif
+#ifndef RT_WALK_LEAVE_DEN
+#define RT_WALK_LEAVE_DEN 4
 #endif
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_ATTR
 #else
 #define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU)))
+#endif
+
+#ifdef RT_PROFILE
+#define RT_PROF_DECL unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_last = __builtin_readcyclecounter(); const unsigned long long prof_begin = prof_last;
+#define RT_PROF(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof_t[k] += now_ - prof_last; prof_last = now_; } while (0)
+#define RT_PROF_COUNT(c) do { (c)++; } while (0)
+#else
+#define RT_PROF_COUNT(c) do { } while (0)
+#define RT_PROF_DECL
+#define RT_PROF(k) do { } while (0)
 #endif
 
 constexpr int BLOCK = RT_BLOCK;
@@ -55,13 +72,18 @@ constexpr int TILE = 8;  // wave tile = 8x8 pixels
 typedef const double __attribute__((address_space(4))) * F64PtrK;
 typedef const uint32_t __attribute__((address_space(4))) * U32PtrK;
 
-// ---- dynamic LDS layout: [pixel sums: WAVES x 64 x 3 u64][geom][matc][cell words][cell items]
+// ---- dynamic LDS layout: [pixel sums: WAVES x 64 x 3 u64][parked walk state: WAVES x 15 x 64 u32]
+//                          [geom][matc][cell words][cell items]
+constexpr uint32_t PARK_WORDS = 15;
+// one resident set of workgroups per CU must fit 160 KB of LDS
+constexpr uint32_t LDS_TABLES_MAX_BYTES = BLOCK >= 1024 ? 156u * 1024u : (BLOCK >= 512 ? 78u * 1024u : 52u * 1024u);
 struct LdsLayout {
-  uint32_t geom_off, matc_off, cell_off, item_off, total;
+  uint32_t park_off, geom_off, matc_off, cell_off, item_off, total;
 };
 __host__ __device__ inline LdsLayout lds_layout(uint32_t n_spheres, uint32_t n_cells, uint32_t n_items, bool tables) {
   LdsLayout l;
   uint32_t o = WAVES * 64u * 3u * (uint32_t)sizeof(unsigned long long);
+  l.park_off = o; o += WAVES * PARK_WORDS * 64u * 4u;
   l.geom_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(SphereGeom);
   l.matc_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(MatCore);
   l.cell_off = o; if (tables) o += n_cells * 4u;
@@ -89,6 +111,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   unsigned long long* const wave_acc = reinterpret_cast<unsigned long long*>(lds_raw) + wave * 192u;
   const LdsLayout lay = lds_layout(sc.n_spheres, G.n_cells, G.n_items, LDS_TABLES);
+  uint32_t* const park = reinterpret_cast<uint32_t*>(lds_raw + lay.park_off) + wave * (PARK_WORDS * 64u) + lane;
 
   if constexpr (LDS_TABLES) {  // stage the tables once per (persistent) workgroup
     {
@@ -99,7 +122,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     {
       double* dst = reinterpret_cast<double*>(lds_raw + lay.matc_off);
       const double* src = reinterpret_cast<const double*>(sc.matc);
-      for (uint32_t i = threadIdx.x; i < sc.n_spheres * 3u; i += BLOCK) dst[i] = src[i];
+      for (uint32_t i = threadIdx.x; i < sc.n_spheres * (uint32_t)(sizeof(MatCore) / 8u); i += BLOCK) dst[i] = src[i];
     }
     {
       uint32_t* dst = reinterpret_cast<uint32_t*>(lds_raw + lay.cell_off);
@@ -138,9 +161,10 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   L.o = v3(0, 0, 0); L.d = v3(0, 0, 1);
   fwd_init(L.fwd);
   if constexpr (HL) L.ls.top = 0;
-  uint32_t cnt_segments = 0, cnt_exact = 0, cnt_steps = 0;  // wave-uniform (SGPR) counters
-  uint32_t cnt_w_iter = 0, cnt_w_step = 0, cnt_w_test = 0, cnt_items = 0;
+  uint32_t n_segments = 0, n_exact = 0, n_steps = 0;  // per-lane counters (one exec-masked add each)
+  uint32_t cnt_w_iter = 0, cnt_w_step = 0, cnt_w_test = 0, cnt_items = 0;  // wave trip counts (RT_PROFILE builds)
 
+  RT_PROF_DECL
   const uint32_t n_items = ka.n_tiles * ka.n_chunks;
   auto fetch_item = [&]() -> uint32_t {
     uint32_t v = 0;
@@ -161,13 +185,26 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     const uint32_t s_count = sc.spp - s_begin < ka.chunk_spp ? sc.spp - s_begin : ka.chunk_spp;
     const uint32_t total_w = 64u * s_count;  // pool item w = (pixel slot w & 63, sample s_begin + (w >> 6))
     wave_acc[lane * 3u] = 0ull; wave_acc[lane * 3u + 1u] = 0ull; wave_acc[lane * 3u + 2u] = 0ull;
-    cnt_items++;
+    RT_PROF_COUNT(cnt_items);
 
     // max_depth == 0: ray_color returns black before tracing anything (raytracer.rs:80-82)
     bool alive = sc.max_depth != 0u;
     bool need_new = true, has_ray = false;
     uint32_t cur_p = lane, next_w = 0;
 
+    // Per-lane hit_world state.  A lane's grid walk may span several iterations of the loop
+    // below: the wave stops walking as soon as most lanes are ready to shade, shades those, and
+    // the stragglers carry on next to the freshly scattered rays (their state is parked in LDS
+    // while the wave shades, so it costs no registers there).
+    bool walking = false;
+    float tm0 = 0.f, tm1 = 0.f, tm2 = 0.f;  // GridWalk.tmax
+    float iv0 = 0.f, iv1 = 0.f, iv2 = 0.f;  // signed 1/direction; GridWalk.delta = |iv|
+    int lin = 0;
+    double t0 = 0.0, closest = T_MAX;
+    int best = -1;
+    uint32_t it = 0, end = 0, last = 0xFFFFFFFFu;
+
+    RT_PROF(5);
     for (;;) {
       // ---------------------------------------------------------- refill from the sample pool
       {
@@ -193,87 +230,127 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         }
       }
       if (!__any(alive)) break;
-      cnt_w_iter++;
+      RT_PROF_COUNT(cnt_w_iter);
+      RT_PROF(0);
 
       // ---------------------------------------------------------- hit_world (raytracer.rs:44-59)
-      const double a = length_squared(L.d);
-      double closest = T_MAX;
-      int best = -1;
-      cnt_segments += (uint32_t)__builtin_popcountll(__ballot(has_ray));
-
-      // (1) spheres outside the grid: every lane tests them; the record is wave-uniform -> SGPRs
-      for (uint32_t i = 0; i < n_large; ++i) {
-        const uint32_t idx = large_k[i];
-        const F64PtrK gp = geom_k + (size_t)idx * 4u;
-        SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
-        if (has_ray) exact_hit_any_order(L.o, L.d, a, g, idx, closest, best);
-      }
-      cnt_exact += n_large * (uint32_t)__builtin_popcountll(__ballot(has_ray));
-
-      // (2) per-lane DDA through the grid; each lane tests the spheres its own cells list
-      if (has_grid) {
+      const RayK rk = ray_consts(L.d);
+      const bool fresh = has_ray && !walking;  // a new ray (camera or scattered): starts its hit_world here
+      const unsigned long long m_fresh = __ballot(fresh);
+      if (m_fresh) {
+        if (fresh) { closest = T_MAX; best = -1; n_segments++; }
+        // (1) spheres outside the grid: every fresh lane tests them; the record is wave-uniform -> SGPRs
+        for (uint32_t i = 0; i < n_large; ++i) {
+          const uint32_t idx = large_k[i];
+          const F64PtrK gp = geom_k + (size_t)idx * 4u;
+          SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
+          if (fresh && rk.fast) exact_hit_any_order_t<true>(L.o, L.d, rk, g, idx, closest, best);
+        }
+        if (fresh && rk.fast) n_exact += n_large;
+        RT_PROF(1);
+        // (2) enter the grid
         GridWalk w;
-        const int mode = has_ray ? grid_begin(G, L.o, L.d, w) : GRID_MISS;
-        bool walking = mode == GRID_WALK;
-        if (__any(mode == GRID_FALLBACK)) {  // numerically unsafe ray: the reference's full scan for that lane
+        const int mode = !fresh ? GRID_MISS : (!rk.fast ? GRID_FALLBACK : (has_grid ? grid_begin(G, L.o, L.d, w) : GRID_MISS));
+        if (__any(mode == GRID_FALLBACK)) {  // numerically unsafe ray: the reference's full scan, real divisions
           for (uint32_t idx = 0; idx < sc.n_spheres; ++idx) {
             const F64PtrK gp = geom_k + (size_t)idx * 4u;
             SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
-            if (mode == GRID_FALLBACK) exact_hit_any_order(L.o, L.d, a, g, idx, closest, best);
+            if (mode == GRID_FALLBACK) exact_hit_slow(L.o, L.d, rk.a, g, idx, closest, best);
           }
-          cnt_exact += sc.n_spheres * (uint32_t)__builtin_popcountll(__ballot(mode == GRID_FALLBACK));
+          if (mode == GRID_FALLBACK) n_exact += sc.n_spheres;
         }
-        uint32_t it = 0, end = 0, last = 0xFFFFFFFFu;
-        if (walking) {
-          const uint32_t word = cell_word[w.lin];
+        if (mode == GRID_WALK) {
+          walking = true;
+          tm0 = w.tmax[0]; tm1 = w.tmax[1]; tm2 = w.tmax[2];
+          iv0 = w.dl[0] < 0 ? -w.delta[0] : w.delta[0]; iv1 = w.dl[1] < 0 ? -w.delta[1] : w.delta[1];
+          iv2 = w.dl[2] < 0 ? -w.delta[2] : w.delta[2];
+          lin = w.lin; t0 = w.t0; last = 0xFFFFFFFFu;
+          const uint32_t word = cell_word[lin];
           it = word & CELL_START_MASK; end = it + (word >> CELL_COUNT_SHIFT);
         }
-        for (;;) {
-          // (a) lanes whose cell is exhausted move on until they stand in a cell with spheres
-          for (;;) {
+        RT_PROF(2);
+      }
+
+      // (3) walk rounds: every walking lane either moves to its next cell or tests one sphere
+      {
+        const int pxs = (int)G.n[0] + 2, pxys = pxs * ((int)G.n[1] + 2);
+        const int dl0 = iv0 < 0.0f ? -1 : 1, dl1 = iv1 < 0.0f ? -pxs : pxs, dl2 = iv2 < 0.0f ? -pxys : pxys;
+        const uint32_t n_ray = (uint32_t)__builtin_popcountll(__ballot(has_ray));
+        for (bool first = true;; first = false) {
+          const unsigned long long mw = __ballot(walking);
+          // stop when nobody walks, or (after at least one round, so stragglers always advance)
+          // when all but a few of the lanes that hold a ray can be shaded
+          if (!mw || (!first && (uint32_t)__builtin_popcountll(mw) * RT_WALK_LEAVE_DEN <= n_ray * RT_WALK_LEAVE_NUM)) break;
+          // (a) lanes whose cell is exhausted: finished, or on to the next cell (up to two cells per round)
+#pragma unroll 1
+          for (int hop = 0; hop < 2; ++hop) {
             const bool moving = walking && it == end;
             if (!__any(moving)) break;
-            cnt_w_step++;
-            bool stepped = false;
+            RT_PROF_COUNT(cnt_w_step);
             if (moving) {
-              stepped = !(best >= 0 && grid_done(w, closest));
-              if (stepped) {
-                grid_step(w);
-                const uint32_t word = cell_word[w.lin];
+              float tc = (float)(closest - t0);
+              tc = tc + fabsf(tc) * 2.384185791015625e-07f;  // grid_done
+              const float tmin = rt_min3f(tm0, tm1, tm2);
+              if (!(best >= 0 && tc < tmin)) {  // grid_step
+                n_steps++;
+                const bool sx = tm0 == tmin, sy = !sx && tm1 == tmin, sz = !sx && !sy;
+                tm0 += sx ? fabsf(iv0) : 0.0f; tm1 += sy ? fabsf(iv1) : 0.0f; tm2 += sz ? fabsf(iv2) : 0.0f;
+                lin += sx ? dl0 : (sy ? dl1 : dl2);
+                const uint32_t word = cell_word[lin];
                 it = word & CELL_START_MASK; end = it + (word >> CELL_COUNT_SHIFT);
                 if (word == CELL_EXIT) { walking = false; end = it; }
               } else walking = false;
             }
-            cnt_steps += (uint32_t)__builtin_popcountll(__ballot(stepped));
           }
-          const unsigned long long mt = __ballot(walking);
-          if (!mt) break;
-          cnt_w_test++;
-          // (b) one exact Sphere::hit per walking lane
-          bool tested = false;
-          if (walking) {
-            const uint32_t idx = cell_items[it];
-            it++;
-            if (idx != last) {  // a sphere spanning consecutive cells is not re-tested
-              last = idx; tested = true;
-              exact_hit_any_order(L.o, L.d, a, tb.geom(idx), idx, closest, best);
+          const bool testing = walking && it != end;
+          if (__any(testing)) {  // (b) one exact Sphere::hit per lane standing in a cell with spheres left
+            RT_PROF_COUNT(cnt_w_test);
+            if (testing) {
+              const uint32_t idx = cell_items[it];
+              it++;
+              if (idx != last) {  // a sphere spanning consecutive cells is not re-tested
+                last = idx; n_exact++;
+                exact_hit_any_order_t<true>(L.o, L.d, rk, tb.geom(idx), idx, closest, best);
+              }
             }
           }
-          cnt_exact += (uint32_t)__builtin_popcountll(__ballot(tested));
         }
       }
+      RT_PROF(3);
 
       // ---------------------------------------------------------- ray_color body
-      if (has_ray) {
-        need_new = lane_shade(sc, tb, L, best, closest);
+      const bool ready = has_ray && !walking;
+      const int hit_idx = best;
+      const double hit_t = closest;
+      const bool any_parked = __any(walking);
+      if (any_parked) {  // park the stragglers' walk state; nothing of it stays live in registers while shading
+        park[0 * 64] = __float_as_uint(tm0); park[1 * 64] = __float_as_uint(tm1); park[2 * 64] = __float_as_uint(tm2);
+        park[3 * 64] = __float_as_uint(iv0); park[4 * 64] = __float_as_uint(iv1); park[5 * 64] = __float_as_uint(iv2);
+        park[6 * 64] = (uint32_t)lin; park[7 * 64] = it; park[8 * 64] = end; park[9 * 64] = last; park[10 * 64] = (uint32_t)best;
+        const unsigned long long t0b = (unsigned long long)__double_as_longlong(t0), clb = (unsigned long long)__double_as_longlong(closest);
+        park[11 * 64] = (uint32_t)t0b; park[12 * 64] = (uint32_t)(t0b >> 32);
+        park[13 * 64] = (uint32_t)clb; park[14 * 64] = (uint32_t)(clb >> 32);
+      }
+      tm0 = tm1 = tm2 = iv0 = iv1 = iv2 = 0.f; lin = 0; it = end = 0; last = 0xFFFFFFFFu; best = -1; t0 = 0.0; closest = T_MAX;
+      if (ready) {
+        need_new = lane_shade(sc, tb, L, hit_idx, hit_t);
         if (need_new) {  // sample finished: add it to its pixel (raytracer.rs:203-205)
           atomicAdd(&wave_acc[cur_p * 3u], sample_to_fixed(L.val[0]));
           atomicAdd(&wave_acc[cur_p * 3u + 1u], sample_to_fixed(L.val[1]));
           atomicAdd(&wave_acc[cur_p * 3u + 2u], sample_to_fixed(L.val[2]));
         }
       }
+      if (any_parked) {
+        tm0 = __uint_as_float(park[0 * 64]); tm1 = __uint_as_float(park[1 * 64]); tm2 = __uint_as_float(park[2 * 64]);
+        iv0 = __uint_as_float(park[3 * 64]); iv1 = __uint_as_float(park[4 * 64]); iv2 = __uint_as_float(park[5 * 64]);
+        lin = (int)park[6 * 64]; it = park[7 * 64]; end = park[8 * 64]; last = park[9 * 64]; best = (int)park[10 * 64];
+        t0 = __longlong_as_double((long long)(((unsigned long long)park[12 * 64] << 32) | park[11 * 64]));
+        closest = __longlong_as_double((long long)(((unsigned long long)park[14 * 64] << 32) | park[13 * 64]));
+      }
+      RT_PROF(4);
     }
 
+    RT_PROF(0);
     // ------------------------------------------------------------ item done: flush the pixel sums
     if (pixel_valid) {
       const size_t o = ((size_t)lr * sc.width + px) * 3;
@@ -294,19 +371,26 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     }
   }
 
-  // counters: one atomic per wave (tex_oob is per lane and almost always zero)
-  unsigned long long c2 = L.n_tex_oob;
+  // counters: wave reduction, one atomic per wave
+  unsigned long long c0 = n_segments, c1 = n_exact, c2 = L.n_tex_oob, c3 = n_steps;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) c2 += __shfl_down(c2, off);
+  for (int off = 32; off > 0; off >>= 1) {
+    c0 += __shfl_down(c0, off); c1 += __shfl_down(c1, off); c2 += __shfl_down(c2, off); c3 += __shfl_down(c3, off);
+  }
   if (lane == 0) {
-    atomicAdd(&ka.counters[0], (unsigned long long)cnt_segments);
-    atomicAdd(&ka.counters[1], (unsigned long long)cnt_exact);
+    atomicAdd(&ka.counters[0], c0);
+    atomicAdd(&ka.counters[1], c1);
     if (c2) atomicAdd(&ka.counters[2], c2);
-    atomicAdd(&ka.counters[3], (unsigned long long)cnt_steps);
+    atomicAdd(&ka.counters[3], c3);
     atomicAdd(&ka.counters[4], (unsigned long long)cnt_w_iter);
     atomicAdd(&ka.counters[5], (unsigned long long)cnt_w_step);
     atomicAdd(&ka.counters[6], (unsigned long long)cnt_w_test);
     atomicAdd(&ka.counters[7], (unsigned long long)cnt_items);
+#ifdef RT_PROFILE
+    RT_PROF(5);
+    prof_t[6] = prof_last - prof_begin;
+    for (int k = 0; k < 7; ++k) atomicAdd(&ka.counters[8 + k], prof_t[k]);
+#endif
   }
 }
 

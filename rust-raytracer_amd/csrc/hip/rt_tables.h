@@ -217,6 +217,7 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
     MatCore mc;
     mc.albedo[0] = m.albedo[0]; mc.albedo[1] = m.albedo[1]; mc.albedo[2] = m.albedo[2];
     mc.kind = m.kind; mc.fuzz_or_ior = m.fuzz_or_ior;
+    mc.inv_r = recip_safe(s.radius) ? 1.0 / s.radius : 0.0;
     t.matc[i] = mc;
     if (s.kind == RT_MAT_LIGHT) t.lights.push_back(i);
     if (s.kind == RT_MAT_LAMBERTIAN || s.kind == RT_MAT_METAL)
@@ -245,6 +246,8 @@ inline void fill_dev_scene(const RtScene& sc, const HostTables& t, DevScene& d) 
     d.cam_h[i] = sc.cam_horizontal[i]; d.cam_v[i] = sc.cam_vertical[i];
   }
   d.sky_w = sc.sky_w; d.sky_h = sc.sky_h;
+  d.wm1 = (double)sc.width - 1.0; d.hm1 = (double)sc.height - 1.0; d.height_d = (double)sc.height;
+  d.inv_wm1 = sc.width > 1 ? 1.0 / d.wm1 : 0.0; d.inv_hm1 = sc.height > 1 ? 1.0 / d.hm1 : 0.0;
   d.grid = t.grid;
 }
 

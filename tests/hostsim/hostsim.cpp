@@ -43,7 +43,7 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
         L.n_segments++;
         if (use_cull == 3 || use_cull == 4) {  // the product's hit_world: `large` list + grid walk
           uint32_t n_steps = 0;
-          hit_world_grid(ds, tb, L.o, L.d, a, closest, best, L.n_exact, n_steps);
+          hit_world_grid(ds, tb, L.o, L.d, closest, best, L.n_exact, n_steps);
           steps += n_steps;
           if (use_cull == 4) {  // audit: the reference's brute force must agree on (t, sphere), bit for bit
             double c2 = T_MAX; int b2 = -1;
@@ -151,7 +151,7 @@ extern "C" int hostsim_hit_world(const RtScene* scene, const double o[3], const 
   V3 oo = v3(o[0], o[1], o[2]), dd = v3(d[0], d[1], d[2]);
   const double a = length_squared(dd);
   double c1 = T_MAX; int b1 = -1; uint32_t ne = 0, ns = 0;
-  hit_world_grid(ds, tb, oo, dd, a, c1, b1, ne, ns);
+  hit_world_grid(ds, tb, oo, dd, c1, b1, ne, ns);
   double c2 = T_MAX; int b2 = -1;
   for (uint32_t i = 0; i < scene->n_spheres; ++i) {
     double r = exact_root(oo, dd, a, t.geom[i], T_MIN, c2);

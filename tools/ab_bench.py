@@ -37,6 +37,7 @@ VARIANTS = {
     "b512_w4_cps8": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "8"}),
     "b512_w4_cps16": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "16"}),
     "b512_w4_brute": (W4, {"variant": 1}, {}),
+    "prof": (W4 + ["-DRT_PROFILE"], {}, {}),
     "round1_scan": (W4, {"variant": 2}, {}),
 }
 

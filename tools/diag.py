@@ -19,10 +19,13 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--lib", default="", help="alternative librt_hip .so (an A/B build)")
     a = ap.parse_args()
     import torch
     os.chdir(ROOT)
     pkg = graft.load_package()
+    if a.lib:
+        pkg.hip.LIB_PATH = os.path.abspath(a.lib)
     sc = pkg.host.Scene.load(a.scene)
     if a.width:
         sc.c.width = a.width
@@ -55,6 +58,11 @@ def main():
                lane_util_steps=round(st["grid_steps"] / max(1, 64 * wi[1]), 4),
                lane_util_tests=round(st["exact_tests"] / max(1, 64 * wi[2]), 4),
                items=wi[3])
+    pc = st["prof_cycles"]
+    if pc[6]:
+        names = ["refill", "large", "grid_begin", "walk", "shade", "item", "total"]
+        out["prof_share"] = {n: round(pc[i] / pc[6], 4) for i, n in enumerate(names[:6])}
+        out["prof_cycles_per_wave_iter"] = {n: round(pc[i] / max(1, wi[0]), 1) for i, n in enumerate(names)}
     print(json.dumps(out))
 
 
