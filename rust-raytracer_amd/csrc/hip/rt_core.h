@@ -115,7 +115,7 @@ struct DevScene {
   const uint8_t* sky;      // sky texture RGB8
   uint64_t sky_w, sky_h;
   GridDesc grid;
-  const uint32_t* cell_word;   // [n_cells] first item | count << 20
+  const uint32_t* cell_word;   // [n_cells][2]: {first item | count << 20, first two item indices (u16 | u16 << 16, 0xFFFF = none)}
   const uint16_t* cell_items;  // [n_items] sphere indices, object order inside a cell
   const uint32_t* large;       // [n_large] sphere indices, object order
   const MatCore* matc;         // [n_spheres]
@@ -462,7 +462,7 @@ RT_HD void hit_world_grid(const DevScene& sc, const Tables& tb, V3 o, V3 d, doub
   }
   uint32_t last = 0xFFFFFFFFu;
   for (;;) {
-    const uint32_t word = sc.cell_word[w.lin];
+    const uint32_t word = sc.cell_word[2 * w.lin];
     if (word == CELL_EXIT) return;
     const uint32_t first = word & CELL_START_MASK, count = word >> CELL_COUNT_SHIFT;
     for (uint32_t k = 0; k < count; ++k) {

@@ -41,13 +41,7 @@ struct KArgs {
 #ifndef RT_BLOCK
 #define RT_BLOCK 1024
 #endif
-// the wave leaves the walk loop for shading once walking lanes <= NUM/DEN of the lanes holding a ray
-#ifndef RT_WALK_LEAVE_NUM
-#define RT_WALK_LEAVE_NUM 1
-#endif
-#ifndef RT_WALK_LEAVE_DEN
-#define RT_WALK_LEAVE_DEN 4
-#endif
+
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_ATTR
 #else
@@ -72,21 +66,18 @@ constexpr int TILE = 8;  // wave tile = 8x8 pixels
 typedef const double __attribute__((address_space(4))) * F64PtrK;
 typedef const uint32_t __attribute__((address_space(4))) * U32PtrK;
 
-// ---- dynamic LDS layout: [pixel sums: WAVES x 64 x 3 u64][parked walk state: WAVES x 15 x 64 u32]
-//                          [geom][matc][cell words][cell items]
-constexpr uint32_t PARK_WORDS = 15;
+// ---- dynamic LDS layout: [pixel sums: WAVES x 64 x 3 u64][geom][matc][cell entries][cell items]
 // one resident set of workgroups per CU must fit 160 KB of LDS
 constexpr uint32_t LDS_TABLES_MAX_BYTES = BLOCK >= 1024 ? 156u * 1024u : (BLOCK >= 512 ? 78u * 1024u : 52u * 1024u);
 struct LdsLayout {
-  uint32_t park_off, geom_off, matc_off, cell_off, item_off, total;
+  uint32_t geom_off, matc_off, cell_off, item_off, total;
 };
 __host__ __device__ inline LdsLayout lds_layout(uint32_t n_spheres, uint32_t n_cells, uint32_t n_items, bool tables) {
   LdsLayout l;
   uint32_t o = WAVES * 64u * 3u * (uint32_t)sizeof(unsigned long long);
-  l.park_off = o; o += WAVES * PARK_WORDS * 64u * 4u;
   l.geom_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(SphereGeom);
   l.matc_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(MatCore);
-  l.cell_off = o; if (tables) o += n_cells * 4u;
+  l.cell_off = o; if (tables) o += n_cells * 8u;
   l.item_off = o; if (tables) o += (n_items * 2u + 7u) & ~7u;
   l.total = o;
   return l;
@@ -111,7 +102,6 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   unsigned long long* const wave_acc = reinterpret_cast<unsigned long long*>(lds_raw) + wave * 192u;
   const LdsLayout lay = lds_layout(sc.n_spheres, G.n_cells, G.n_items, LDS_TABLES);
-  uint32_t* const park = reinterpret_cast<uint32_t*>(lds_raw + lay.park_off) + wave * (PARK_WORDS * 64u) + lane;
 
   if constexpr (LDS_TABLES) {  // stage the tables once per (persistent) workgroup
     {
@@ -126,7 +116,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     }
     {
       uint32_t* dst = reinterpret_cast<uint32_t*>(lds_raw + lay.cell_off);
-      for (uint32_t i = threadIdx.x; i < G.n_cells; i += BLOCK) dst[i] = sc.cell_word[i];
+      for (uint32_t i = threadIdx.x; i < 2u * G.n_cells; i += BLOCK) dst[i] = sc.cell_word[i];
     }
     {
       uint16_t* dst = reinterpret_cast<uint16_t*>(lds_raw + lay.item_off);
@@ -136,16 +126,16 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   }
   using Tables = typename std::conditional<LDS_TABLES, LdsTables, GlobalTables>::type;
   Tables tb;
-  const uint32_t* cell_word;
+  const uint2* cell_word;
   const uint16_t* cell_items;
   if constexpr (LDS_TABLES) {
     tb.g = reinterpret_cast<const double*>(lds_raw + lay.geom_off);
     tb.m = reinterpret_cast<const MatCore*>(lds_raw + lay.matc_off);
-    cell_word = reinterpret_cast<const uint32_t*>(lds_raw + lay.cell_off);
+    cell_word = reinterpret_cast<const uint2*>(lds_raw + lay.cell_off);
     cell_items = reinterpret_cast<const uint16_t*>(lds_raw + lay.item_off);
   } else {
     tb.g = sc.geom; tb.m = sc.matc;
-    cell_word = sc.cell_word; cell_items = sc.cell_items;
+    cell_word = reinterpret_cast<const uint2*>(sc.cell_word); cell_items = sc.cell_items;
   }
   const F64PtrK geom_k = (F64PtrK)(uintptr_t)sc.geom;
   const U32PtrK large_k = (U32PtrK)(uintptr_t)sc.large;
@@ -192,18 +182,6 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     bool need_new = true, has_ray = false;
     uint32_t cur_p = lane, next_w = 0;
 
-    // Per-lane hit_world state.  A lane's grid walk may span several iterations of the loop
-    // below: the wave stops walking as soon as most lanes are ready to shade, shades those, and
-    // the stragglers carry on next to the freshly scattered rays (their state is parked in LDS
-    // while the wave shades, so it costs no registers there).
-    bool walking = false;
-    float tm0 = 0.f, tm1 = 0.f, tm2 = 0.f;  // GridWalk.tmax
-    float iv0 = 0.f, iv1 = 0.f, iv2 = 0.f;  // signed 1/direction; GridWalk.delta = |iv|
-    int lin = 0;
-    double t0 = 0.0, closest = T_MAX;
-    int best = -1;
-    uint32_t it = 0, end = 0, last = 0xFFFFFFFFu;
-
     RT_PROF(5);
     for (;;) {
       // ---------------------------------------------------------- refill from the sample pool
@@ -235,78 +213,94 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 
       // ---------------------------------------------------------- hit_world (raytracer.rs:44-59)
       const RayK rk = ray_consts(L.d);
-      const bool fresh = has_ray && !walking;  // a new ray (camera or scattered): starts its hit_world here
-      const unsigned long long m_fresh = __ballot(fresh);
-      if (m_fresh) {
-        if (fresh) { closest = T_MAX; best = -1; n_segments++; }
-        // (1) spheres outside the grid: every fresh lane tests them; the record is wave-uniform -> SGPRs
-        for (uint32_t i = 0; i < n_large; ++i) {
-          const uint32_t idx = large_k[i];
+      double closest = T_MAX;
+      int best = -1;
+      if (has_ray) n_segments++;
+      // (1) spheres outside the grid: every lane tests them; the record is wave-uniform -> SGPRs
+      for (uint32_t i = 0; i < n_large; ++i) {
+        const uint32_t idx = large_k[i];
+        const F64PtrK gp = geom_k + (size_t)idx * 4u;
+        SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
+        if (has_ray && rk.fast) exact_hit_any_order_t<true>(L.o, L.d, rk, g, idx, closest, best);
+      }
+      if (has_ray && rk.fast) n_exact += n_large;
+      RT_PROF(1);
+      // (2) enter the grid
+      GridWalk w;
+      const int mode = !has_ray ? GRID_MISS : (!rk.fast ? GRID_FALLBACK : (has_grid ? grid_begin(G, L.o, L.d, w) : GRID_MISS));
+      if (__any(mode == GRID_FALLBACK)) {  // numerically unsafe ray: the reference's full scan, real divisions
+        for (uint32_t idx = 0; idx < sc.n_spheres; ++idx) {
           const F64PtrK gp = geom_k + (size_t)idx * 4u;
           SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
-          if (fresh && rk.fast) exact_hit_any_order_t<true>(L.o, L.d, rk, g, idx, closest, best);
+          if (mode == GRID_FALLBACK) exact_hit_slow(L.o, L.d, rk.a, g, idx, closest, best);
         }
-        if (fresh && rk.fast) n_exact += n_large;
-        RT_PROF(1);
-        // (2) enter the grid
-        GridWalk w;
-        const int mode = !fresh ? GRID_MISS : (!rk.fast ? GRID_FALLBACK : (has_grid ? grid_begin(G, L.o, L.d, w) : GRID_MISS));
-        if (__any(mode == GRID_FALLBACK)) {  // numerically unsafe ray: the reference's full scan, real divisions
-          for (uint32_t idx = 0; idx < sc.n_spheres; ++idx) {
-            const F64PtrK gp = geom_k + (size_t)idx * 4u;
-            SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
-            if (mode == GRID_FALLBACK) exact_hit_slow(L.o, L.d, rk.a, g, idx, closest, best);
-          }
-          if (mode == GRID_FALLBACK) n_exact += sc.n_spheres;
-        }
-        if (mode == GRID_WALK) {
-          walking = true;
-          tm0 = w.tmax[0]; tm1 = w.tmax[1]; tm2 = w.tmax[2];
-          iv0 = w.dl[0] < 0 ? -w.delta[0] : w.delta[0]; iv1 = w.dl[1] < 0 ? -w.delta[1] : w.delta[1];
-          iv2 = w.dl[2] < 0 ? -w.delta[2] : w.delta[2];
-          lin = w.lin; t0 = w.t0; last = 0xFFFFFFFFu;
-          const uint32_t word = cell_word[lin];
-          it = word & CELL_START_MASK; end = it + (word >> CELL_COUNT_SHIFT);
-        }
-        RT_PROF(2);
+        if (mode == GRID_FALLBACK) n_exact += sc.n_spheres;
       }
-
-      // (3) walk rounds: every walking lane either moves to its next cell or tests one sphere
-      {
-        const int pxs = (int)G.n[0] + 2, pxys = pxs * ((int)G.n[1] + 2);
-        const int dl0 = iv0 < 0.0f ? -1 : 1, dl1 = iv1 < 0.0f ? -pxs : pxs, dl2 = iv2 < 0.0f ? -pxys : pxys;
-        const uint32_t n_ray = (uint32_t)__builtin_popcountll(__ballot(has_ray));
-        for (bool first = true;; first = false) {
-          const unsigned long long mw = __ballot(walking);
-          // stop when nobody walks, or (after at least one round, so stragglers always advance)
-          // when all but a few of the lanes that hold a ray can be shaded
-          if (!mw || (!first && (uint32_t)__builtin_popcountll(mw) * RT_WALK_LEAVE_DEN <= n_ray * RT_WALK_LEAVE_NUM)) break;
-          // (a) lanes whose cell is exhausted: finished, or on to the next cell (up to two cells per round)
-#pragma unroll 1
-          for (int hop = 0; hop < 2; ++hop) {
-            const bool moving = walking && it == end;
-            if (!__any(moving)) break;
+      if (has_grid) {
+        // (3) walk rounds: every walking lane moves on by up to two cells and/or tests one sphere.
+        // Per-lane walk state: tm = GridWalk.tmax, dt = GridWalk.delta, dl = GridWalk.dl, lin;
+        // the current cell's untested spheres are items [it, end), the next two of them also in `pend`.
+        bool walking = mode == GRID_WALK;
+        float tm0 = w.tmax[0], tm1 = w.tmax[1], tm2 = w.tmax[2];
+        const float dt0 = w.delta[0], dt1 = w.delta[1], dt2 = w.delta[2];
+        const int dl0 = w.dl[0], dl1 = w.dl[1], dl2 = w.dl[2];
+        int lin = walking ? w.lin : 0;
+        const double t0 = w.t0;
+        uint32_t it = 0, end = 0, pend = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
+        const int lin_max = (int)G.n_cells - 1;
+        if (walking) {
+          const uint2 e = cell_word[lin];
+          it = e.x & CELL_START_MASK; end = it + (e.x >> CELL_COUNT_SHIFT); pend = e.y;
+        }
+        for (;;) {
+          if (!__any(walking)) break;
+          // (a) lanes whose cell is exhausted: finished, or on to the next non-empty cell.  The next
+          // TWO cells along the ray are computed and fetched together (one LDS round trip), the
+          // second one is used only if the first is empty.
+          const bool moving = walking && it == end;
+          if (__any(moving)) {
             RT_PROF_COUNT(cnt_w_step);
             if (moving) {
               float tc = (float)(closest - t0);
               tc = tc + fabsf(tc) * 2.384185791015625e-07f;  // grid_done
-              const float tmin = rt_min3f(tm0, tm1, tm2);
-              if (!(best >= 0 && tc < tmin)) {  // grid_step
+              const bool hit = best >= 0;
+              const float tminA = rt_min3f(tm0, tm1, tm2);
+              if (hit && tc < tminA) walking = false;
+              else {
+                // grid_step x 2
+                const bool ax = tm0 == tminA, ay = !ax && tm1 == tminA, az = !ax && !ay;
+                const float a0 = tm0 + (ax ? dt0 : 0.0f), a1 = tm1 + (ay ? dt1 : 0.0f), a2 = tm2 + (az ? dt2 : 0.0f);
+                const int linA = lin + (ax ? dl0 : (ay ? dl1 : dl2));
+                const float tminB = rt_min3f(a0, a1, a2);
+                const bool bx_ = a0 == tminB, by_ = !bx_ && a1 == tminB, bz_ = !bx_ && !by_;
+                const float b0 = a0 + (bx_ ? dt0 : 0.0f), b1 = a1 + (by_ ? dt1 : 0.0f), b2 = a2 + (bz_ ? dt2 : 0.0f);
+                int linB = linA + (bx_ ? dl0 : (by_ ? dl1 : dl2));
+                linB = linB < 0 ? 0 : (linB > lin_max ? lin_max : linB);  // speculative address: keep it inside the table
+                const uint2 eA = cell_word[linA];
+                const uint2 eB = cell_word[linB];
                 n_steps++;
-                const bool sx = tm0 == tmin, sy = !sx && tm1 == tmin, sz = !sx && !sy;
-                tm0 += sx ? fabsf(iv0) : 0.0f; tm1 += sy ? fabsf(iv1) : 0.0f; tm2 += sz ? fabsf(iv2) : 0.0f;
-                lin += sx ? dl0 : (sy ? dl1 : dl2);
-                const uint32_t word = cell_word[lin];
-                it = word & CELL_START_MASK; end = it + (word >> CELL_COUNT_SHIFT);
-                if (word == CELL_EXIT) { walking = false; end = it; }
-              } else walking = false;
+                const bool exitA = eA.x == CELL_EXIT, emptyA = (eA.x >> CELL_COUNT_SHIFT) == 0u;
+                const bool doneA = hit && tc < tminB;  // the closest hit lies inside cell A
+                if (exitA || !emptyA || doneA) {  // stay in A (or stop there)
+                  tm0 = a0; tm1 = a1; tm2 = a2; lin = linA;
+                  it = eA.x & CELL_START_MASK; end = it + (eA.x >> CELL_COUNT_SHIFT); pend = eA.y;
+                  if (exitA || emptyA) { walking = false; end = it; }
+                } else {                           // A is empty: on to B
+                  n_steps++;
+                  tm0 = b0; tm1 = b1; tm2 = b2; lin = linB;
+                  it = eB.x & CELL_START_MASK; end = it + (eB.x >> CELL_COUNT_SHIFT); pend = eB.y;
+                  if (eB.x == CELL_EXIT) { walking = false; end = it; }
+                }
+              }
             }
           }
           const bool testing = walking && it != end;
           if (__any(testing)) {  // (b) one exact Sphere::hit per lane standing in a cell with spheres left
             RT_PROF_COUNT(cnt_w_test);
             if (testing) {
-              const uint32_t idx = cell_items[it];
+              uint32_t idx = pend & 0xFFFFu;
+              if (idx == 0xFFFFu) idx = cell_items[it];  // third and later items of a cell: from the list
+              pend = (pend >> 16) | 0xFFFF0000u;
               it++;
               if (idx != last) {  // a sphere spanning consecutive cells is not re-tested
                 last = idx; n_exact++;
@@ -319,33 +313,13 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       RT_PROF(3);
 
       // ---------------------------------------------------------- ray_color body
-      const bool ready = has_ray && !walking;
-      const int hit_idx = best;
-      const double hit_t = closest;
-      const bool any_parked = __any(walking);
-      if (any_parked) {  // park the stragglers' walk state; nothing of it stays live in registers while shading
-        park[0 * 64] = __float_as_uint(tm0); park[1 * 64] = __float_as_uint(tm1); park[2 * 64] = __float_as_uint(tm2);
-        park[3 * 64] = __float_as_uint(iv0); park[4 * 64] = __float_as_uint(iv1); park[5 * 64] = __float_as_uint(iv2);
-        park[6 * 64] = (uint32_t)lin; park[7 * 64] = it; park[8 * 64] = end; park[9 * 64] = last; park[10 * 64] = (uint32_t)best;
-        const unsigned long long t0b = (unsigned long long)__double_as_longlong(t0), clb = (unsigned long long)__double_as_longlong(closest);
-        park[11 * 64] = (uint32_t)t0b; park[12 * 64] = (uint32_t)(t0b >> 32);
-        park[13 * 64] = (uint32_t)clb; park[14 * 64] = (uint32_t)(clb >> 32);
-      }
-      tm0 = tm1 = tm2 = iv0 = iv1 = iv2 = 0.f; lin = 0; it = end = 0; last = 0xFFFFFFFFu; best = -1; t0 = 0.0; closest = T_MAX;
-      if (ready) {
-        need_new = lane_shade(sc, tb, L, hit_idx, hit_t);
+      if (has_ray) {
+        need_new = lane_shade(sc, tb, L, best, closest);
         if (need_new) {  // sample finished: add it to its pixel (raytracer.rs:203-205)
           atomicAdd(&wave_acc[cur_p * 3u], sample_to_fixed(L.val[0]));
           atomicAdd(&wave_acc[cur_p * 3u + 1u], sample_to_fixed(L.val[1]));
           atomicAdd(&wave_acc[cur_p * 3u + 2u], sample_to_fixed(L.val[2]));
         }
-      }
-      if (any_parked) {
-        tm0 = __uint_as_float(park[0 * 64]); tm1 = __uint_as_float(park[1 * 64]); tm2 = __uint_as_float(park[2 * 64]);
-        iv0 = __uint_as_float(park[3 * 64]); iv1 = __uint_as_float(park[4 * 64]); iv2 = __uint_as_float(park[5 * 64]);
-        lin = (int)park[6 * 64]; it = park[7 * 64]; end = park[8 * 64]; last = park[9 * 64]; best = (int)park[10 * 64];
-        t0 = __longlong_as_double((long long)(((unsigned long long)park[12 * 64] << 32) | park[11 * 64]));
-        closest = __longlong_as_double((long long)(((unsigned long long)park[14 * 64] << 32) | park[13 * 64]));
       }
       RT_PROF(4);
     }

@@ -58,7 +58,7 @@ inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
     for (uint32_t i = 0; i < n; ++i) t.large[i] = i;
     G.n_large = n;
   };
-  if (n < gp.min_spheres || n > 65535u) { all_large(); return; }
+  if (n < gp.min_spheres || n > 65535u) { all_large(); return; }  // item indices are u16, 0xFFFF = none
   std::vector<uint8_t> is_large(n, 0);
   std::vector<double> radii;
   for (uint32_t i = 0; i < n; ++i) {
@@ -142,11 +142,11 @@ inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
     std::vector<uint32_t> cursor;
     if (pass == 1) {
       uint64_t total = 0;
-      t.cell_word.assign(G.n_cells, CELL_EXIT);
+      t.cell_word.assign(2 * (size_t)G.n_cells, CELL_EXIT);  // {word, first two items} per cell
       cursor.resize(n_inner);
       for (uint32_t c = 0; c < n_inner; ++c) {
         if (count[c] > CELL_MAX_COUNT || total >= CELL_START_MASK) { all_large(); return; }
-        t.cell_word[padded(c)] = (uint32_t)total | (count[c] << CELL_COUNT_SHIFT);
+        t.cell_word[2 * padded(c)] = (uint32_t)total | (count[c] << CELL_COUNT_SHIFT);
         cursor[c] = (uint32_t)total;
         total += count[c];
       }
@@ -165,6 +165,12 @@ inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
             if (pass == 0) count[c]++; else t.cell_items[cursor[c]++] = (uint16_t)i;
           }
     }
+  }
+  for (uint32_t c = 0; c < n_inner; ++c) {  // inline copy of each cell's first two items
+    const uint32_t word = t.cell_word[2 * padded(c)];
+    const uint32_t first = word & CELL_START_MASK, cnt = word >> CELL_COUNT_SHIFT;
+    const uint32_t i0 = cnt > 0 ? t.cell_items[first] : 0xFFFFu, i1 = cnt > 1 ? t.cell_items[first + 1] : 0xFFFFu;
+    t.cell_word[2 * padded(c) + 1] = i0 | (i1 << 16);
   }
   for (uint32_t i = 0; i < n; ++i) if (is_large[i]) t.large.push_back(i);
   G.n_large = (uint32_t)t.large.size();

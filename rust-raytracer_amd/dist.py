@@ -28,23 +28,35 @@ def max_local_rows(height, world, tile_rows=TILE_ROWS):
     return max(abi.tiles_local_rows(height, shard(r, world, tile_rows)) for r in range(world))
 
 
+_PERM_CACHE = {}
+
+
+def _assembly_perm(height, world, tile_rows, pad_rows, device):
+    """perm[y] = rank * pad_rows + local_row of global scanline y (built once per layout)."""
+    key = (height, world, tile_rows, pad_rows, str(device))
+    perm = _PERM_CACHE.get(key)
+    if perm is None:
+        idx = [0] * height
+        for r in range(world):
+            for lr, y in enumerate(abi.tiles_global_rows(height, shard(r, world, tile_rows))):
+                idx[y] = r * pad_rows + lr
+        perm = torch.as_tensor(idx, device=device, dtype=torch.long)
+        _PERM_CACHE[key] = perm
+    return perm
+
+
 def gather_frame(local_rgb8, height, width, rank, world, tile_rows=TILE_ROWS, dst=0):
     """local_rgb8: uint8 tensor [max_local_rows, width, 3] on this rank's device (rows beyond
     this rank's share are padding).  Returns the assembled [height, width, 3] frame on `dst`,
-    None elsewhere.  One collective."""
+    None elsewhere.  ONE collective (gather of the packed tiles) + one row permutation on dst."""
     if world <= 1:
         return local_rgb8[:height]
     pad_rows = max_local_rows(height, world, tile_rows)
     assert local_rgb8.shape[0] == pad_rows, (local_rgb8.shape, pad_rows)
     if rank == dst:
-        parts = [torch.empty_like(local_rgb8) for _ in range(world)]
-        dist.gather(local_rgb8, parts, dst=dst)
-        frame = torch.empty((height, width, 3), dtype=torch.uint8, device=local_rgb8.device)
-        for r in range(world):  # de-interleave: packed local rows -> global scanlines
-            rows = abi.tiles_global_rows(height, shard(r, world, tile_rows))
-            if rows:
-                idx = torch.as_tensor(rows, device=local_rgb8.device, dtype=torch.long)
-                frame.index_copy_(0, idx, parts[r][: len(rows)])
-        return frame
+        stacked = torch.empty((world, pad_rows, width, 3), dtype=torch.uint8, device=local_rgb8.device)
+        dist.gather(local_rgb8, [stacked[r] for r in range(world)], dst=dst)
+        perm = _assembly_perm(height, world, tile_rows, pad_rows, local_rgb8.device)
+        return stacked.view(world * pad_rows, width, 3).index_select(0, perm)  # de-interleave: packed rows -> scanlines
     dist.gather(local_rgb8, None, dst=dst)
     return None
