@@ -66,7 +66,7 @@ constexpr int TILE = 8;  // wave tile = 8x8 pixels
 typedef const double __attribute__((address_space(4))) * F64PtrK;
 typedef const uint32_t __attribute__((address_space(4))) * U32PtrK;
 
-// ---- dynamic LDS layout: [pixel sums: WAVES x 64 x 3 u64][geom][matc][cell entries][cell items]
+// ---- dynamic LDS layout: [pixel sums: WAVES x 2 item slots x 64 x 3 u64][geom][matc][cell entries][cell items]
 // one resident set of workgroups per CU must fit 160 KB of LDS
 constexpr uint32_t LDS_TABLES_MAX_BYTES = BLOCK >= 1024 ? 156u * 1024u : (BLOCK >= 512 ? 78u * 1024u : 52u * 1024u);
 struct LdsLayout {
@@ -74,13 +74,24 @@ struct LdsLayout {
 };
 __host__ __device__ inline LdsLayout lds_layout(uint32_t n_spheres, uint32_t n_cells, uint32_t n_items, bool tables) {
   LdsLayout l;
-  uint32_t o = WAVES * 64u * 3u * (uint32_t)sizeof(unsigned long long);
+  uint32_t o = WAVES * 2u * 64u * 3u * (uint32_t)sizeof(unsigned long long);
   l.geom_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(SphereGeom);
   l.matc_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(MatCore);
   l.cell_off = o; if (tables) o += n_cells * 8u;
   l.item_off = o; if (tables) o += (n_items * 2u + 7u) & ~7u;
   l.total = o;
   return l;
+}
+
+// The kernel arguments live in the kernarg segment (constant memory).  Reading them through a
+// pointer the compiler cannot see through makes every section of the path loop RE-LOAD the few
+// fields it needs (s_load, scalar cache) instead of keeping all ~80 argument SGPRs live across
+// the hot walk loop, where they were being spilled to VGPR lanes.
+typedef const KArgs __attribute__((address_space(4)))* KArgsK;
+__device__ __forceinline__ const KArgs& fresh_args() {
+  KArgsK p = (KArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const KArgs*)p;
 }
 
 struct LdsTables {  // per-lane gathers from the workgroup's LDS copies
@@ -100,7 +111,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   const GridDesc& G = sc.grid;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  unsigned long long* const wave_acc = reinterpret_cast<unsigned long long*>(lds_raw) + wave * 192u;
+  unsigned long long* const wave_acc = reinterpret_cast<unsigned long long*>(lds_raw) + wave * 384u;  // 2 item slots x 64 px x 3
   const LdsLayout lay = lds_layout(sc.n_spheres, G.n_cells, G.n_items, LDS_TABLES);
 
   if constexpr (LDS_TABLES) {  // stage the tables once per (persistent) workgroup
@@ -137,10 +148,6 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     tb.g = sc.geom; tb.m = sc.matc;
     cell_word = reinterpret_cast<const uint2*>(sc.cell_word); cell_items = sc.cell_items;
   }
-  const F64PtrK geom_k = (F64PtrK)(uintptr_t)sc.geom;
-  const U32PtrK large_k = (U32PtrK)(uintptr_t)sc.large;
-  const uint32_t n_large = G.n_large;
-  const bool has_grid = G.n[0] != 0u;
 
   typedef Lane<HL, SIMPLE> LaneT;
   LaneT L;
@@ -155,63 +162,124 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   uint32_t cnt_w_iter = 0, cnt_w_step = 0, cnt_w_test = 0, cnt_items = 0;  // wave trip counts (RT_PROFILE builds)
 
   RT_PROF_DECL
-  const uint32_t n_items = ka.n_tiles * ka.n_chunks;
+  const uint32_t n_items = ka.n_tiles * ka.n_chunks;  // (one SGPR across the loop)
   auto fetch_item = [&]() -> uint32_t {
     uint32_t v = 0;
-    if (lane == 0) v = atomicAdd(ka.queue, 1u);
+    if (lane == 0) v = atomicAdd(fresh_args().queue, 1u);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
   };
 
-  for (uint32_t item = fetch_item(); item < n_items; item = fetch_item()) {
+  // ---- streaming work items.  A wave holds up to two items at a time: the CURRENT one hands out
+  // samples, the PREVIOUS one only waits for its last paths to finish; when the current item has
+  // no samples left, lanes go straight on with the next item from the queue, so no lane idles
+  // while a neighbour finishes a long path (only at the very end of the frame).  Each item slot
+  // has its own set of pixel sums in LDS.
+  uint32_t s_bx[2] = {0, 0}, s_by[2] = {0, 0}, s_sbeg[2] = {0, 0}, s_total[2] = {0, 0}, s_next[2] = {0, 0}, s_out[2] = {0, 0};
+  bool s_active[2] = {false, false};
+  uint32_t cur = 0;
+  bool q_empty = false;
+  uint32_t py_slot[2] = {0, 0};   // per lane: global scanline of this lane's pixel slot in item slot k
+  bool ok_slot[2] = {false, false};  // per lane: that pixel slot is inside the image
+  uint32_t my_slot = 0, cur_p = lane;
+  bool has_ray = false;
+
+  auto open_item = [&](uint32_t k, uint32_t item) {
+    const KArgs& ka = fresh_args();
+    const DevScene& sc = ka.sc;
     // chunk-major order: the last items of the frame are spread over the whole image
     const uint32_t chunk = item / ka.n_tiles, tile = item - chunk * ka.n_tiles;
     const uint32_t by = tile / ka.tiles_x, bx = tile - by * ka.tiles_x;
     const uint32_t px = bx * TILE + (lane & 7u);
     const uint32_t lr = by * TILE + (lane >> 3);  // local (packed) row
-    const bool pixel_valid = px < sc.width && lr < ka.local_rows;
     uint32_t py = lr;  // global scanline (raytracer.rs:255: band index, 0 = top)
     if (ka.tile_rows != 0u) py = (ka.first_tile + (lr / ka.tile_rows) * ka.tile_stride) * ka.tile_rows + lr % ka.tile_rows;
     const uint32_t s_begin = chunk * ka.chunk_spp;
     const uint32_t s_count = sc.spp - s_begin < ka.chunk_spp ? sc.spp - s_begin : ka.chunk_spp;
-    const uint32_t total_w = 64u * s_count;  // pool item w = (pixel slot w & 63, sample s_begin + (w >> 6))
-    wave_acc[lane * 3u] = 0ull; wave_acc[lane * 3u + 1u] = 0ull; wave_acc[lane * 3u + 2u] = 0ull;
+    s_bx[k] = bx; s_by[k] = by; s_sbeg[k] = s_begin; s_next[k] = 0; s_out[k] = 0; s_active[k] = true;
+    // pool item w = (pixel slot w & 63, sample s_begin + (w >> 6)); max_depth == 0: ray_color
+    // returns black before tracing anything (raytracer.rs:80-82), so nothing is handed out
+    s_total[k] = sc.max_depth != 0u ? 64u * s_count : 0u;
+    py_slot[k] = py; ok_slot[k] = px < sc.width && lr < ka.local_rows;
+    unsigned long long* acc = wave_acc + k * 192u;
+    acc[lane * 3u] = 0ull; acc[lane * 3u + 1u] = 0ull; acc[lane * 3u + 2u] = 0ull;
     RT_PROF_COUNT(cnt_items);
-
-    // max_depth == 0: ray_color returns black before tracing anything (raytracer.rs:80-82)
-    bool alive = sc.max_depth != 0u;
-    bool need_new = true, has_ray = false;
-    uint32_t cur_p = lane, next_w = 0;
-
-    RT_PROF(5);
-    for (;;) {
-      // ---------------------------------------------------------- refill from the sample pool
-      {
-        const bool want = alive && need_new;
-        const unsigned long long m = __ballot(want);
-        if (m) {
-          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          const uint32_t w = next_w + rank;
-          next_w += (uint32_t)__builtin_popcountll(m);
-          const uint32_t p = w & 63u;
-          const uint32_t p_py = (uint32_t)__shfl((int)py, (int)p);
-          const int p_ok = __shfl((int)pixel_valid, (int)p);
-          if (want) {
-            if (w >= total_w) { alive = false; has_ray = false; }
-            else if (!p_ok) { has_ray = false; }  // slot outside the image: ask again next iteration
-            else {
-              const uint32_t p_px = bx * TILE + (p & 7u);
-              cur_p = p; L.s = s_begin + (w >> 6); L.ra.pixel = p_py * sc.width + p_px;
-              lane_begin_sample(sc, L, p_px, p_py);
-              need_new = false; has_ray = true;
-            }
-          }
+  };
+  auto flush_item = [&](uint32_t k) {  // all samples of slot k are in its pixel sums: write them out
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const KArgs& ka = fresh_args();
+    const DevScene& sc = ka.sc;
+    const uint32_t px = s_bx[k] * TILE + (lane & 7u), lr = s_by[k] * TILE + (lane >> 3);
+    const unsigned long long* acc = wave_acc + k * 192u;
+    if (px < sc.width && lr < ka.local_rows) {
+      const size_t o = ((size_t)lr * sc.width + px) * 3;
+      if (ka.n_chunks == 1u) {  // raytracer.rs:207-216: mean, sqrt gamma, f32 -> u8, store
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float lin = fixed_to_mean(acc[lane * 3u + c], sc.spp);
+          if (ka.out_linear) ka.out_linear[o + c] = lin;
+          ka.out_rgb8[o + c] = f32_to_u8(__builtin_sqrtf(lin));
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const unsigned long long v = acc[lane * 3u + c];
+          if (v) atomicAdd(&ka.accum[o + c], v);
         }
       }
-      if (!__any(alive)) break;
-      RT_PROF_COUNT(cnt_w_iter);
-      RT_PROF(0);
+    }
+    s_active[k] = false;
+  };
 
+  RT_PROF(5);
+  for (;;) {
+    // ------------------------------------------------------------ refill lanes that hold no path
+    {
+      const DevScene& sc = fresh_args().sc;
+      bool want = !has_ray;
+      for (;;) {
+        const unsigned long long m = __ballot(want);
+        if (!m) break;
+        if (s_active[cur] && s_next[cur] < s_total[cur]) {  // hand out samples of the current item
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          const uint32_t w = s_next[cur] + rank;
+          const uint32_t left = s_total[cur] - s_next[cur], asked = (uint32_t)__builtin_popcountll(m);
+          s_next[cur] += asked < left ? asked : left;
+          const uint32_t p = w & 63u;
+          const uint32_t p_py = (uint32_t)__shfl((int)py_slot[cur], (int)p);
+          const int p_ok = __shfl((int)ok_slot[cur], (int)p);
+          bool took = false;
+          if (want && w < s_total[cur] && p_ok) {  // (a slot outside the image consumes its index and asks again)
+            const uint32_t p_px = s_bx[cur] * TILE + (p & 7u);
+            cur_p = p; my_slot = cur; L.s = s_sbeg[cur] + (w >> 6); L.ra.pixel = p_py * sc.width + p_px;
+            lane_begin_sample(sc, L, p_px, p_py);
+            has_ray = true; want = false; took = true;
+          }
+          s_out[cur] += (uint32_t)__builtin_popcountll(__ballot(took));
+          continue;
+        }
+        // the current slot has nothing (more) to hand out
+        if (s_active[cur] && s_out[cur] == 0u) flush_item(cur);  // and nothing in flight: done with it
+        if (s_active[cur]) {             // it still drains: open the next item in the other slot
+          if (s_active[cur ^ 1u]) break;  // both slots busy: these lanes wait
+          cur ^= 1u;
+        }
+        if (q_empty) break;
+        const uint32_t item = fetch_item();
+        if (item >= n_items) { q_empty = true; break; }
+        open_item(cur, item);
+      }
+    }
+    if (!__any(has_ray)) break;  // nothing in flight, nothing left to hand out
+    RT_PROF_COUNT(cnt_w_iter);
+    RT_PROF(0);
+    {
       // ---------------------------------------------------------- hit_world (raytracer.rs:44-59)
+      const DevScene& sc = fresh_args().sc;
+      const GridDesc& G = sc.grid;
+      const F64PtrK geom_k = (F64PtrK)(uintptr_t)sc.geom;
+      const U32PtrK large_k = (U32PtrK)(uintptr_t)sc.large;
+      const uint32_t n_large = G.n_large;
+      const bool has_grid = G.n[0] != 0u;
       const RayK rk = ray_consts(L.d);
       double closest = T_MAX;
       int best = -1;
@@ -313,35 +381,26 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       RT_PROF(3);
 
       // ---------------------------------------------------------- ray_color body
+      bool finished = false;
       if (has_ray) {
-        need_new = lane_shade(sc, tb, L, best, closest);
-        if (need_new) {  // sample finished: add it to its pixel (raytracer.rs:203-205)
-          atomicAdd(&wave_acc[cur_p * 3u], sample_to_fixed(L.val[0]));
-          atomicAdd(&wave_acc[cur_p * 3u + 1u], sample_to_fixed(L.val[1]));
-          atomicAdd(&wave_acc[cur_p * 3u + 2u], sample_to_fixed(L.val[2]));
+        finished = lane_shade(fresh_args().sc, tb, L, best, closest);
+        if (finished) {  // sample finished: add it to its pixel (raytracer.rs:203-205)
+          unsigned long long* acc = wave_acc + my_slot * 192u + cur_p * 3u;
+          atomicAdd(&acc[0], sample_to_fixed(L.val[0]));
+          atomicAdd(&acc[1], sample_to_fixed(L.val[1]));
+          atomicAdd(&acc[2], sample_to_fixed(L.val[2]));
+          has_ray = false;
+        }
+      }
+      const unsigned long long mf = __ballot(finished);
+      if (mf) {
+#pragma unroll
+        for (uint32_t k = 0; k < 2u; ++k) {
+          s_out[k] -= (uint32_t)__builtin_popcountll(__ballot(finished && my_slot == k));
+          if (s_active[k] && s_out[k] == 0u && s_next[k] >= s_total[k]) flush_item(k);
         }
       }
       RT_PROF(4);
-    }
-
-    RT_PROF(0);
-    // ------------------------------------------------------------ item done: flush the pixel sums
-    if (pixel_valid) {
-      const size_t o = ((size_t)lr * sc.width + px) * 3;
-      if (ka.n_chunks == 1u) {  // raytracer.rs:207-216: mean, sqrt gamma, f32 -> u8, store
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const float lin = fixed_to_mean(wave_acc[lane * 3u + k], sc.spp);
-          if (ka.out_linear) ka.out_linear[o + k] = lin;
-          ka.out_rgb8[o + k] = f32_to_u8(__builtin_sqrtf(lin));
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const unsigned long long v = wave_acc[lane * 3u + k];
-          if (v) atomicAdd(&ka.accum[o + k], v);
-        }
-      }
     }
   }
 
@@ -352,6 +411,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     c0 += __shfl_down(c0, off); c1 += __shfl_down(c1, off); c2 += __shfl_down(c2, off); c3 += __shfl_down(c3, off);
   }
   if (lane == 0) {
+    const KArgs& ka = fresh_args();
     atomicAdd(&ka.counters[0], c0);
     atomicAdd(&ka.counters[1], c1);
     if (c2) atomicAdd(&ka.counters[2], c2);
