@@ -13,13 +13,16 @@ over RCCL; total work is fixed, so scaling is "strong" (the north-star target is
 speed-up of this frame at 8 GPUs).  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      the megakernel against the roof that actually binds it (FP32 vector ALU):
-                ALGORITHMIC ray-sphere tests (segments x n_spheres, the reference's brute
+  roofline      the megakernel against the roof that actually binds it (vector ALU; rocprof
+                shows the VALU pipes >90 % busy and ~6 MB of HBM traffic per frame):
+                ALGORITHMIC ray-sphere tests (segments x n_spheres = the reference's brute
                 force, counted by the kernel) x 17 flop / average kernel time measured with
-                HIP events on the launch stream, vs the 157.3 TFLOP/s FP32 vector peak
+                HIP events on the launch stream, vs the 157.3 TFLOP/s FP32 vector peak.
+                The kernel itself executes far fewer tests (grid walk): `executed` restates
+                the same time in tests actually run.
   roofline_hbm  the HBM view the north star asks for: algorithmic sphere-geometry bytes
-                (32 B per test) per second vs 8 TB/s, plus measured HBM traffic if
-                profiles/hbm_traffic.json (rocprofv3 --pmc passes) is present
+                (32 B per test) per second vs 8 TB/s, plus measured HBM traffic from
+                profiles/hbm_traffic.json (rocprofv3 --pmc passes)
   cpu_baseline  the CPU oracle (a literal restatement of the reference's rayon path) timed
                 on this box's host cores on a bounded sample of the same frame
 """
@@ -121,16 +124,17 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / max(1, args.steps)
     st = gs.wait()                                  # counters of the last launch (this rank's shard)
 
-    t = torch.tensor([elapsed, kernel_ms, float(st["segments"]), float(st["exact_tests"])], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, kernel_ms, float(st["segments"]), float(st["exact_tests"]), float(st["grid_steps"])],
+                     dtype=torch.float64, device=dev)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
-        segments, exact = float(tsum[2]), float(tsum[3])
+        segments, exact, steps = float(tsum[2]), float(tsum[3]), float(tsum[4])
     else:
-        segments, exact = float(st["segments"]), float(st["exact_tests"])
+        segments, exact, steps = float(st["segments"]), float(st["exact_tests"]), float(st["grid_steps"])
 
     if rank == 0:
         samples = W * H * SPP
@@ -157,14 +161,18 @@ def main():
                        "inputs": "scene tables resident in HBM before the timed region"},
             "kernel_ms": round(kernel_ms, 4), "segments_per_sample": round(segments / samples, 4),
             "exact_tests_per_segment": round(exact / max(1.0, segments), 3),
-            "roofline": {"bound": "valu-fp32 (neither hbm nor mfma binds this path; DESIGN.md)", "achieved": round(tflops, 3),
+            "grid_steps_per_segment": round(steps / max(1.0, segments), 3),
+            "roofline": {"bound": "valu", "note": "vector-ALU bound: neither hbm nor mfma binds this path (DESIGN.md §6)",
+                         "achieved": round(tflops, 3),
                          "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / PEAK_FP32_VALU_TFLOPS, 4),
                          "traffic": traffic, "kernel": "rt_megakernel", "flop_per_test": FLOP_PER_TEST,
-                         "tests_per_launch": int(tests_per_launch)},
+                         "tests_per_launch": int(tests_per_launch),
+                         "executed": {"exact_tests_per_launch": int(exact / world),
+                                      "tflops_f64": round(exact / world * FLOP_PER_TEST / (kernel_ms * 1e-3) / 1e12, 3)}},
             "roofline_hbm": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                             "note": "achieved = algorithmic sphere-geometry bytes (32 B/test) per second; they are served "
-                                     "from the scalar cache, real HBM traffic is `traffic` bytes per launch"},
+                             "note": "achieved = algorithmic sphere-geometry bytes (32 B/test) per second; the tables are "
+                                     "LDS-resident, real HBM traffic is `traffic` bytes per launch"},
         }
         if world == 1 and not args.no_cpu_baseline:
             oracle = graft.load_oracle()

@@ -40,11 +40,9 @@ struct RtHipScene {
   void* d_all = nullptr;   // 0..n-1: the `large` list of the brute-force arm (variant 1)
   rtc::GridDesc grid{};    // the product grid (variant 0)
   unsigned long long* d_counters = nullptr;  // 4 counters + the work-queue cursor
-  unsigned long long* d_accum = nullptr;     // fixed-point pixel sums (pixels split over work items)
-  size_t accum_bytes = 0;
   int num_cus = 0;
   int chunk_spp = 0;       // 0 = automatic
-  bool resolve_launched = false;
+
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   hipStream_t last_stream = nullptr;
   bool launched = false;
@@ -81,7 +79,7 @@ extern "C" void rt_hip_scene_destroy(RtHipScene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (void* p : {s->d_geom, s->d_mat, s->d_cull, s->d_lights, s->d_tex, s->d_sky, (void*)s->d_counters, s->d_matc,
-                  s->d_cell_word, s->d_cell_items, s->d_large, s->d_all, (void*)s->d_accum})
+                  s->d_cell_word, s->d_cell_items, s->d_large, s->d_all})
     if (p) (void)hipFree(p);
   if (s->ev_start) (void)hipEventDestroy(s->ev_start);
   if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
@@ -247,9 +245,9 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   ka.tile_stride = tiled ? tiles->tile_stride : 0;
   ka.tiles_x = (s->host.width + rtk::TILE - 1) / rtk::TILE;
   ka.n_tiles = ka.tiles_x * ((local_rows + rtk::TILE - 1) / rtk::TILE);
-  // Work items: split a pixel's samples into chunks until the frame has ~64 items per resident
-  // wave (the last items to finish then cost ~1-2 % of the frame; measured best on the headline
-  // frame, profiles/), but not below 8 samples per item (pool drain + flush overhead).
+  // A tile's samples are handed out to the waves of a workgroup in chunks: ~64 chunk items per
+  // resident wave over the frame (the last items to finish then cost ~1-2 % of it), at least 4
+  // samples per chunk.
   const uint32_t spp = s->host.samples_per_pixel;
   uint32_t chunk_spp = (uint32_t)s->chunk_spp;
   if (chunk_spp == 0) {
@@ -257,22 +255,11 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
     uint64_t chunks = (target_items + ka.n_tiles - 1) / ka.n_tiles;
     if (chunks < 1) chunks = 1;
     chunk_spp = (uint32_t)((spp + chunks - 1) / chunks);
-    if (chunk_spp < 8) chunk_spp = 8;
+    if (chunk_spp < 4) chunk_spp = 4;
   }
   if (chunk_spp > spp || spp == 0) chunk_spp = spp ? spp : 1;
   ka.chunk_spp = chunk_spp;
   ka.n_chunks = spp ? (spp + chunk_spp - 1) / chunk_spp : 1;
-  const size_t n_pixels = (size_t)local_rows * s->host.width;
-  ka.accum = nullptr;
-  if (ka.n_chunks > 1) {
-    const size_t need = n_pixels * 3 * sizeof(unsigned long long);
-    if (need > s->accum_bytes) {
-      if (s->d_accum) { RT_HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(s->d_accum); s->d_accum = nullptr; s->accum_bytes = 0; }
-      RT_HIP_TRY(hipMalloc((void**)&s->d_accum, need));
-      s->accum_bytes = need;
-    }
-    ka.accum = s->d_accum;
-  }
   const uint32_t n_items = ka.n_tiles * ka.n_chunks;
   const rtc::GridDesc& G = ka.sc.grid;
   const rtk::LdsLayout with_tables = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true);
@@ -280,18 +267,12 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   const size_t lds_bytes = lds_tables ? with_tables.total : rtk::lds_layout(0, 0, 0, false).total;
 
   RT_HIP_TRY(hipEventRecord(s->ev_start, stream));
-  if (ka.accum) RT_HIP_TRY(hipMemsetAsync(ka.accum, 0, n_pixels * 3 * sizeof(unsigned long long), stream));
   int rc;
   if (s->has_lights) rc = lds_tables ? launch_grid_t<true, false, true>(s, ka, lds_bytes, n_items, stream) : launch_grid_t<true, false, false>(s, ka, lds_bytes, n_items, stream);
   else if (s->simple_colour) rc = lds_tables ? launch_grid_t<false, true, true>(s, ka, lds_bytes, n_items, stream) : launch_grid_t<false, true, false>(s, ka, lds_bytes, n_items, stream);
   else rc = lds_tables ? launch_grid_t<false, false, true>(s, ka, lds_bytes, n_items, stream) : launch_grid_t<false, false, false>(s, ka, lds_bytes, n_items, stream);
   if (rc != RT_OK) return rc;
   RT_HIP_TRY(hipGetLastError());
-  if (ka.accum) {
-    hipLaunchKernelGGL(rtk::rt_resolve, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream, ka.accum, ka.out_rgb8, ka.out_linear,
-                       (uint32_t)n_pixels, spp);
-    RT_HIP_TRY(hipGetLastError());
-  }
   RT_HIP_TRY(hipEventRecord(s->ev_stop, stream));
   s->launched = true;
   return RT_OK;

@@ -2,9 +2,10 @@
 // (raytracer/src/raytracer.rs:191-218, 71-165, 44-59) as ONE persistent launch.
 //
 // Shape (CDNA4-first):
-//   * persistent workgroups (one resident set per CU) pull work items from a global queue.
-//     Item = (8x8-pixel wave tile, chunk of samples); items are small (a few thousand
-//     samples), so the frame has no tail even though paths differ 50x in length;
+//   * persistent workgroups (one per CU, 16 waves) pull 8x8-pixel TILES from a global queue; a
+//     tile's samples are handed out to the workgroup's waves in small chunks through shared LDS
+//     slots, so the frame has no tail even though paths differ 50x in length, and a pixel's
+//     samples meet in LDS: the only HBM traffic of a frame is the framebuffer write;
 //   * the scene tables a ray touches per segment — f64 sphere geometry, material cores, the
 //     uniform grid's cell words and item lists — are staged ONCE per workgroup into LDS and
 //     gathered from there by lane (ds_read_b64), never from HBM;
@@ -16,9 +17,8 @@
 //     spheres that get the reference's exact f64 Sphere::hit.  The closest hit is the
 //     lexicographic minimum of (t, object index), i.e. bit-identical to the reference's
 //     object-order scan (rt_core.h exact_hit_any_order);
-//   * pixel sums are exact 2^-40 fixed point: in LDS per item, then (when a pixel's samples are
-//     split over several items) u64 atomics into an HBM accumulator that a trivial epilogue
-//     kernel turns into RGB8.  Order-free, hence bit-reproducible for any schedule / GPU count;
+//   * pixel sums are exact 2^-40 fixed point (u64 LDS atomics): order-free, hence
+//     bit-reproducible for any schedule / chunking / GPU count;
 //   * Philox4x32-10 per lane, addressed by (pixel, sample, node, slot).
 #include <hip/hip_runtime.h>
 
@@ -32,10 +32,9 @@ struct KArgs {
   uint8_t* out_rgb8;
   float* out_linear;
   unsigned long long* counters;  // [0] segments, [1] exact tests, [2] tex_oob, [3] grid steps, [4..7] wave trip counts
-  unsigned long long* accum;     // [local pixel][3] fixed-point sums; used when n_chunks > 1
-  uint32_t* queue;               // work-item cursor (zeroed before the launch)
+  uint32_t* queue;               // tile cursor (zeroed before the launch)
   uint32_t local_rows, tile_rows, first_tile, tile_stride;
-  uint32_t tiles_x, n_tiles, n_chunks, chunk_spp;
+  uint32_t tiles_x, n_tiles, n_chunks, chunk_spp;  // a tile's samples are handed out in n_chunks chunks
 };
 
 #ifndef RT_BLOCK
@@ -66,15 +65,29 @@ constexpr int TILE = 8;  // wave tile = 8x8 pixels
 typedef const double __attribute__((address_space(4))) * F64PtrK;
 typedef const uint32_t __attribute__((address_space(4))) * U32PtrK;
 
-// ---- dynamic LDS layout: [pixel sums: WAVES x 2 item slots x 64 x 3 u64][geom][matc][cell entries][cell items]
+// ---- dynamic LDS layout: [tile slot headers: T_SLOTS x 16 B + flags][pixel sums: T_SLOTS x 64 x 3 u64]
+//                          [geom][matc][cell entries][cell items]
 // one resident set of workgroups per CU must fit 160 KB of LDS
 constexpr uint32_t LDS_TABLES_MAX_BYTES = BLOCK >= 1024 ? 156u * 1024u : (BLOCK >= 512 ? 78u * 1024u : 52u * 1024u);
+// Tile slots are shared by the workgroup: every wave holds at most two work items, so 2*WAVES
+// slots can never run out while a wave has room for another item.
+constexpr uint32_t T_SLOTS = 2u * WAVES;
+static_assert(T_SLOTS <= 64u, "one lane per tile slot in the slot scans");
+struct SlotHdr {
+  uint32_t tile;   // tile index of the frame
+  uint32_t next;   // next chunk to hand out (may overshoot n_chunks)
+  uint32_t done;   // chunks whose samples are all in the pixel sums
+  uint32_t state;  // SLOT_*
+};
+enum { SLOT_FREE = 0, SLOT_OPEN = 1, SLOT_OPENING = 2 };
+constexpr uint32_t LDS_HDR_BYTES = T_SLOTS * 16u + 16u;  // + {queue_empty flag, pad}
 struct LdsLayout {
-  uint32_t geom_off, matc_off, cell_off, item_off, total;
+  uint32_t acc_off, geom_off, matc_off, cell_off, item_off, total;
 };
 __host__ __device__ inline LdsLayout lds_layout(uint32_t n_spheres, uint32_t n_cells, uint32_t n_items, bool tables) {
   LdsLayout l;
-  uint32_t o = WAVES * 2u * 64u * 3u * (uint32_t)sizeof(unsigned long long);
+  uint32_t o = LDS_HDR_BYTES;
+  l.acc_off = o; o += T_SLOTS * 64u * 3u * (uint32_t)sizeof(unsigned long long);
   l.geom_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(SphereGeom);
   l.matc_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(MatCore);
   l.cell_off = o; if (tables) o += n_cells * 8u;
@@ -111,8 +124,13 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   const GridDesc& G = sc.grid;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  unsigned long long* const wave_acc = reinterpret_cast<unsigned long long*>(lds_raw) + wave * 384u;  // 2 item slots x 64 px x 3
   const LdsLayout lay = lds_layout(sc.n_spheres, G.n_cells, G.n_items, LDS_TABLES);
+  SlotHdr* const hdr = reinterpret_cast<SlotHdr*>(lds_raw);
+  uint32_t* const wg_q_empty = reinterpret_cast<uint32_t*>(lds_raw + T_SLOTS * 16u);
+  unsigned long long* const tile_acc = reinterpret_cast<unsigned long long*>(lds_raw + lay.acc_off);  // [T_SLOTS][64 px][3]
+  if (threadIdx.x < T_SLOTS) { SlotHdr h; h.tile = 0; h.next = 0; h.done = 0; h.state = SLOT_FREE; hdr[threadIdx.x] = h; }
+  if (threadIdx.x == 0) *wg_q_empty = 0u;
+  if constexpr (!LDS_TABLES) __syncthreads();
 
   if constexpr (LDS_TABLES) {  // stage the tables once per (persistent) workgroup
     {
@@ -162,75 +180,125 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   uint32_t cnt_w_iter = 0, cnt_w_step = 0, cnt_w_test = 0, cnt_items = 0;  // wave trip counts (RT_PROFILE builds)
 
   RT_PROF_DECL
-  const uint32_t n_items = ka.n_tiles * ka.n_chunks;  // (one SGPR across the loop)
-  auto fetch_item = [&]() -> uint32_t {
-    uint32_t v = 0;
-    if (lane == 0) v = atomicAdd(fresh_args().queue, 1u);
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-  };
-
-  // ---- streaming work items.  A wave holds up to two items at a time: the CURRENT one hands out
-  // samples, the PREVIOUS one only waits for its last paths to finish; when the current item has
-  // no samples left, lanes go straight on with the next item from the queue, so no lane idles
-  // while a neighbour finishes a long path (only at the very end of the frame).  Each item slot
-  // has its own set of pixel sums in LDS.
-  uint32_t s_bx[2] = {0, 0}, s_by[2] = {0, 0}, s_sbeg[2] = {0, 0}, s_total[2] = {0, 0}, s_next[2] = {0, 0}, s_out[2] = {0, 0};
+  // ---- work distribution, two levels.
+  // Global: a queue of TILES (8x8 pixels, all their samples).  Workgroup: an open tile lives in
+  // one of T_SLOTS shared LDS slots (header + exact fixed-point pixel sums); its samples are
+  // handed out to the workgroup's waves in n_chunks chunks, and the wave that completes the last
+  // chunk converts the sums and writes the tile's pixels — the only HBM traffic of the frame.
+  // Wave: holds up to two chunk items at a time: the CURRENT one hands out samples, the PREVIOUS
+  // one only waits for its last paths to finish; when the current item has no samples left the
+  // lanes go straight on with the next item, so no lane idles while a neighbour finishes a long
+  // path, and all 16 waves of a workgroup converge on the last tiles of the frame.
+  uint32_t s_k[2] = {0, 0}, s_bx[2] = {0, 0}, s_by[2] = {0, 0}, s_sbeg[2] = {0, 0}, s_total[2] = {0, 0}, s_next[2] = {0, 0}, s_out[2] = {0, 0};
   bool s_active[2] = {false, false};
   uint32_t cur = 0;
-  bool q_empty = false;
-  uint32_t py_slot[2] = {0, 0};   // per lane: global scanline of this lane's pixel slot in item slot k
+  bool q_done = false;            // no more items will ever be available to this wave
+  uint32_t py_slot[2] = {0, 0};   // per lane: global scanline of this lane's pixel slot in item slot j
   bool ok_slot[2] = {false, false};  // per lane: that pixel slot is inside the image
   uint32_t my_slot = 0, cur_p = lane;
   bool has_ray = false;
+  auto bcast = [&](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
 
-  auto open_item = [&](uint32_t k, uint32_t item) {
+  // Take a chunk of an open tile, or open the next tile of the frame.  1: got (k, chunk, tile);
+  // 0: nothing right now (every slot is busy draining); -1: the frame has nothing left to hand out.
+  auto acquire = [&](uint32_t& k_out, uint32_t& chunk_out, uint32_t& tile_out) -> int {
+    const KArgs& ka = fresh_args();
+    const uint32_t n_chunks = ka.n_chunks;
+    for (int tries = 0; tries < 8; ++tries) {
+      const bool mine = lane < T_SLOTS;
+      const uint32_t st = mine ? __hip_atomic_load(&hdr[mine ? lane : 0].state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (uint32_t)SLOT_OPENING;
+      const uint32_t nx = mine ? __hip_atomic_load(&hdr[mine ? lane : 0].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0xFFFFFFFFu;
+      unsigned long long mo = __ballot(mine && st == SLOT_OPEN && nx < n_chunks);
+      while (mo) {  // open tiles with chunks left: take one
+        const uint32_t k = (uint32_t)__builtin_ctzll(mo);
+        mo &= mo - 1ull;
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(&hdr[k].next, 1u);
+        c = bcast(c);
+        if (c < n_chunks) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          k_out = k; chunk_out = c; tile_out = bcast(__hip_atomic_load(&hdr[k].tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+          return 1;
+        }
+      }
+      if (bcast(__hip_atomic_load(wg_q_empty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u)
+        return __ballot(mine && st == SLOT_OPENING) ? 0 : -1;  // (a tile being opened right now will still offer chunks)
+      const unsigned long long mf = __ballot(mine && st == SLOT_FREE);
+      if (!mf) return 0;
+      const uint32_t k = (uint32_t)__builtin_ctzll(mf);
+      uint32_t ok = 0;
+      if (lane == 0) ok = atomicCAS(&hdr[k].state, (uint32_t)SLOT_FREE, (uint32_t)SLOT_OPENING) == (uint32_t)SLOT_FREE ? 1u : 0u;
+      if (!bcast(ok)) continue;  // another wave claimed it: rescan
+      uint32_t tile = 0;
+      if (lane == 0) tile = atomicAdd(ka.queue, 1u);
+      tile = bcast(tile);
+      if (tile >= ka.n_tiles) {  // the frame's queue is empty
+        if (lane == 0) {
+          __hip_atomic_store(wg_q_empty, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(&hdr[k].state, (uint32_t)SLOT_FREE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        continue;
+      }
+      unsigned long long* acc = tile_acc + k * 192u;
+      acc[lane * 3u] = 0ull; acc[lane * 3u + 1u] = 0ull; acc[lane * 3u + 2u] = 0ull;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) {  // publish: tile and done before next, next before state
+        __hip_atomic_store(&hdr[k].tile, tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&hdr[k].done, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&hdr[k].next, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // this wave takes chunk 0
+        __hip_atomic_store(&hdr[k].state, (uint32_t)SLOT_OPEN, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      k_out = k; chunk_out = 0; tile_out = tile;
+      return 1;
+    }
+    return 0;
+  };
+  auto open_item = [&](uint32_t j, uint32_t k, uint32_t chunk, uint32_t tile) {
     const KArgs& ka = fresh_args();
     const DevScene& sc = ka.sc;
-    // chunk-major order: the last items of the frame are spread over the whole image
-    const uint32_t chunk = item / ka.n_tiles, tile = item - chunk * ka.n_tiles;
     const uint32_t by = tile / ka.tiles_x, bx = tile - by * ka.tiles_x;
     const uint32_t px = bx * TILE + (lane & 7u);
     const uint32_t lr = by * TILE + (lane >> 3);  // local (packed) row
     uint32_t py = lr;  // global scanline (raytracer.rs:255: band index, 0 = top)
     if (ka.tile_rows != 0u) py = (ka.first_tile + (lr / ka.tile_rows) * ka.tile_stride) * ka.tile_rows + lr % ka.tile_rows;
     const uint32_t s_begin = chunk * ka.chunk_spp;
-    const uint32_t s_count = sc.spp - s_begin < ka.chunk_spp ? sc.spp - s_begin : ka.chunk_spp;
-    s_bx[k] = bx; s_by[k] = by; s_sbeg[k] = s_begin; s_next[k] = 0; s_out[k] = 0; s_active[k] = true;
+    const uint32_t s_left = sc.spp - s_begin;
+    const uint32_t s_count = s_left < ka.chunk_spp ? s_left : ka.chunk_spp;
+    s_k[j] = k; s_bx[j] = bx; s_by[j] = by; s_sbeg[j] = s_begin; s_next[j] = 0; s_out[j] = 0; s_active[j] = true;
     // pool item w = (pixel slot w & 63, sample s_begin + (w >> 6)); max_depth == 0: ray_color
     // returns black before tracing anything (raytracer.rs:80-82), so nothing is handed out
-    s_total[k] = sc.max_depth != 0u ? 64u * s_count : 0u;
-    py_slot[k] = py; ok_slot[k] = px < sc.width && lr < ka.local_rows;
-    unsigned long long* acc = wave_acc + k * 192u;
-    acc[lane * 3u] = 0ull; acc[lane * 3u + 1u] = 0ull; acc[lane * 3u + 2u] = 0ull;
+    s_total[j] = sc.max_depth != 0u ? 64u * s_count : 0u;
+    py_slot[j] = py; ok_slot[j] = px < sc.width && lr < ka.local_rows;
     RT_PROF_COUNT(cnt_items);
   };
-  auto flush_item = [&](uint32_t k) {  // all samples of slot k are in its pixel sums: write them out
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // all samples of item slot j are in their tile's pixel sums; the last chunk of a tile writes its pixels
+  auto finish_item = [&](uint32_t j) {
     const KArgs& ka = fresh_args();
     const DevScene& sc = ka.sc;
-    const uint32_t px = s_bx[k] * TILE + (lane & 7u), lr = s_by[k] * TILE + (lane >> 3);
-    const unsigned long long* acc = wave_acc + k * 192u;
-    if (px < sc.width && lr < ka.local_rows) {
+    const uint32_t k = s_k[j];
+    s_active[j] = false;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    uint32_t d = 0;
+    if (lane == 0) d = atomicAdd(&hdr[k].done, 1u) + 1u;
+    if (bcast(d) != ka.n_chunks) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t px = s_bx[j] * TILE + (lane & 7u), lr = s_by[j] * TILE + (lane >> 3);
+    const unsigned long long* acc = tile_acc + k * 192u;
+    if (px < sc.width && lr < ka.local_rows) {  // raytracer.rs:207-216: mean, sqrt gamma, f32 -> u8, store
       const size_t o = ((size_t)lr * sc.width + px) * 3;
-      if (ka.n_chunks == 1u) {  // raytracer.rs:207-216: mean, sqrt gamma, f32 -> u8, store
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float lin = fixed_to_mean(acc[lane * 3u + c], sc.spp);
-          if (ka.out_linear) ka.out_linear[o + c] = lin;
-          ka.out_rgb8[o + c] = f32_to_u8(__builtin_sqrtf(lin));
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const unsigned long long v = acc[lane * 3u + c];
-          if (v) atomicAdd(&ka.accum[o + c], v);
-        }
+      for (int c = 0; c < 3; ++c) {
+        const float lin = fixed_to_mean(__hip_atomic_load(&acc[lane * 3u + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), sc.spp);
+        if (ka.out_linear) ka.out_linear[o + c] = lin;
+        ka.out_rgb8[o + c] = f32_to_u8(__builtin_sqrtf(lin));
       }
     }
-    s_active[k] = false;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(&hdr[k].state, (uint32_t)SLOT_FREE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
 
   RT_PROF(5);
+  uint32_t idle_spins = 0;
   for (;;) {
     // ------------------------------------------------------------ refill lanes that hold no path
     {
@@ -257,19 +325,28 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
           s_out[cur] += (uint32_t)__builtin_popcountll(__ballot(took));
           continue;
         }
-        // the current slot has nothing (more) to hand out
-        if (s_active[cur] && s_out[cur] == 0u) flush_item(cur);  // and nothing in flight: done with it
-        if (s_active[cur]) {             // it still drains: open the next item in the other slot
-          if (s_active[cur ^ 1u]) break;  // both slots busy: these lanes wait
+        // the current item has nothing (more) to hand out
+        if (s_active[cur] && s_out[cur] == 0u) finish_item(cur);  // and nothing in flight: done with it
+        if (s_active[cur]) {             // it still drains: the next item goes into the other slot
+          if (s_active[cur ^ 1u]) break;  // both item slots busy: these lanes wait
           cur ^= 1u;
         }
-        if (q_empty) break;
-        const uint32_t item = fetch_item();
-        if (item >= n_items) { q_empty = true; break; }
-        open_item(cur, item);
+        if (q_done) break;
+        uint32_t k = 0, chunk = 0, tile = 0;
+        const int got = acquire(k, chunk, tile);
+        if (got < 0) { q_done = true; break; }
+        if (got == 0) break;
+        open_item(cur, k, chunk, tile);
       }
     }
-    if (!__any(has_ray)) break;  // nothing in flight, nothing left to hand out
+    if (!__any(has_ray)) {
+      // nothing in flight.  Done when the frame has nothing left; otherwise (all tile slots are
+      // draining in other waves) wait a little and ask again — bounded, a wave may always retire.
+      if (q_done || ++idle_spins > (1u << 16)) break;
+      __builtin_amdgcn_s_sleep(32);
+      continue;
+    }
+
     RT_PROF_COUNT(cnt_w_iter);
     RT_PROF(0);
     {
@@ -385,7 +462,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       if (has_ray) {
         finished = lane_shade(fresh_args().sc, tb, L, best, closest);
         if (finished) {  // sample finished: add it to its pixel (raytracer.rs:203-205)
-          unsigned long long* acc = wave_acc + my_slot * 192u + cur_p * 3u;
+          unsigned long long* acc = tile_acc + (my_slot ? s_k[1] : s_k[0]) * 192u + cur_p * 3u;
           atomicAdd(&acc[0], sample_to_fixed(L.val[0]));
           atomicAdd(&acc[1], sample_to_fixed(L.val[1]));
           atomicAdd(&acc[2], sample_to_fixed(L.val[2]));
@@ -395,9 +472,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       const unsigned long long mf = __ballot(finished);
       if (mf) {
 #pragma unroll
-        for (uint32_t k = 0; k < 2u; ++k) {
-          s_out[k] -= (uint32_t)__builtin_popcountll(__ballot(finished && my_slot == k));
-          if (s_active[k] && s_out[k] == 0u && s_next[k] >= s_total[k]) flush_item(k);
+        for (uint32_t j = 0; j < 2u; ++j) {
+          s_out[j] -= (uint32_t)__builtin_popcountll(__ballot(finished && my_slot == j));
+          if (s_active[j] && s_out[j] == 0u && s_next[j] >= s_total[j]) finish_item(j);
         }
       }
       RT_PROF(4);
@@ -425,19 +502,6 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     prof_t[6] = prof_last - prof_begin;
     for (int k = 0; k < 7; ++k) atomicAdd(&ka.counters[8 + k], prof_t[k]);
 #endif
-  }
-}
-
-// Epilogue when a pixel's samples were split over several work items: fixed-point sums ->
-// mean, sqrt gamma, RGB8 (raytracer.rs:207-216).  One thread per pixel channel triple.
-__global__ void rt_resolve(const unsigned long long* accum, uint8_t* out_rgb8, float* out_linear, uint32_t n_pixels, uint32_t spp) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_pixels) return;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float lin = fixed_to_mean(accum[(size_t)i * 3 + k], spp);
-    if (out_linear) out_linear[(size_t)i * 3 + k] = lin;
-    out_rgb8[(size_t)i * 3 + k] = f32_to_u8(__builtin_sqrtf(lin));
   }
 }
 

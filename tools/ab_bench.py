@@ -23,21 +23,16 @@ BASE = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=of
 # name -> (extra compile flags, runtime options, environment at scene creation)
 W4 = ["-DRT_WAVES_PER_EU=4"]
 VARIANTS = {
-    "b512_w4": (W4, {}, {}),
+    "b1024_w4": (W4, {}, {}),
+    "b512_w4": (W4 + ["-DRT_BLOCK=512"], {}, {}),
     "b256_w4": (W4 + ["-DRT_BLOCK=256"], {}, {}),
-    "b1024_w4": (W4 + ["-DRT_BLOCK=1024"], {}, {}),
-    "b256_w3": (["-DRT_WAVES_PER_EU=3", "-DRT_BLOCK=256"], {}, {}),
-    "b256_w5": (["-DRT_WAVES_PER_EU=5", "-DRT_BLOCK=256"], {}, {}),
-    "b512_w2": (["-DRT_WAVES_PER_EU=2"], {}, {}),
-    "b512_w4_chunk8": (W4, {"chunk_spp": 8}, {}),
-    "b512_w4_chunk16": (W4, {"chunk_spp": 16}, {}),
-    "b512_w4_chunk64": (W4, {"chunk_spp": 64}, {}),
-    "b512_w4_chunk128": (W4, {"chunk_spp": 128}, {}),
-    "b512_w4_cps2": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "2"}),
-    "b512_w4_cps8": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "8"}),
-    "b512_w4_cps16": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "16"}),
-    "b512_w4_brute": (W4, {"variant": 1}, {}),
-    "prof": (W4 + ["-DRT_PROFILE"], {}, {}),
+    "b1024_w3": (["-DRT_WAVES_PER_EU=3"], {}, {}),
+    "b1024_w4_chunk4": (W4, {"chunk_spp": 4}, {}),
+    "b1024_w4_chunk16": (W4, {"chunk_spp": 16}, {}),
+    "b1024_w4_chunk128": (W4, {"chunk_spp": 128}, {}),
+    "b1024_w4_cps2": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "2"}),
+    "b1024_w4_cps8": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "8"}),
+    "b1024_w4_brute": (W4, {"variant": 1}, {}),
     "round1_scan": (W4, {"variant": 2}, {}),
 }
 

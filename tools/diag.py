@@ -20,13 +20,20 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--lib", default="", help="alternative librt_hip .so (an A/B build)")
+    ap.add_argument("--procedural", type=int, default=0, help="use the procedural world with this `half` (50 -> ~10 000 spheres)")
     a = ap.parse_args()
     import torch
     os.chdir(ROOT)
     pkg = graft.load_package()
     if a.lib:
         pkg.hip.LIB_PATH = os.path.abspath(a.lib)
-    sc = pkg.host.Scene.load(a.scene)
+    if a.procedural:
+        sys.path.insert(0, os.path.join(ROOT, "scenes"))
+        import procedural
+        sc = pkg.host.Scene.loads(procedural.make_json(width=a.width or 3840, height=a.height or 2160, spp=a.spp or 8, half=a.procedural, seed=0))
+        a.scene = f"procedural_half{a.procedural}"
+    else:
+        sc = pkg.host.Scene.load(a.scene)
     if a.width:
         sc.c.width = a.width
     if a.height:

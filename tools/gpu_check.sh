@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box session: smoke, GPU parity tests, bench line, rocprofv3 kernel stats (+ optional A/B).
+# One GPU-box session: smoke, GPU parity tests, bench line, rocprofv3 kernel stats, PMC passes (+ optional A/B).
 # Usage (from the build container):  gpurun --timeout 900 -- 'bash tools/gpu_check.sh [ab] [pmc]'
 # Every step runs under `timeout` and nothing reads stdin: a stuck step must not eat GPU budget.
 set -u
@@ -14,20 +14,25 @@ timeout 600 python -m pytest tests -m gpu -x -q -s > $OUT/pytest_gpu.log 2>&1; s
 tail -4 $OUT/pytest_gpu.log
 if [[ " $* " == *" ab "* ]]; then
   timeout 300 python tools/ab_bench.py run --rounds 5 > $OUT/ab.log 2>&1; stamp ab $?
-  cat $OUT/ab.log | tail -20
+  grep -v amdgpu.ids $OUT/ab.log | tail -20
 fi
-timeout 300 python bench.py --steps 5 --warmup 1 > $OUT/bench.log 2>&1; stamp bench $?
-tail -1 $OUT/bench.log
 export TMPDIR=/tmp
 REPO=$PWD
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT/prof" -o bench -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline ) > $OUT/rocprof.log 2>&1
-stamp rocprof $?
-STATS=$(find $OUT/prof -name "*kernel_stats.csv" 2>/dev/null | head -1)
-if [ -n "$STATS" ]; then head -6 "$STATS"; fi
 if [[ " $* " == *" pmc "* ]]; then
   # HBM traffic: separate PMC passes, counters only (no trace domains), per the microarch guide
-  ( cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$REPO/$OUT/pmc_fetch" -o bench -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ) > $OUT/pmc_fetch.log 2>&1; stamp pmc_fetch $?
-  ( cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$REPO/$OUT/pmc_write" -o bench -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ) > $OUT/pmc_write.log 2>&1; stamp pmc_write $?
+  for C in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && timeout 300 rocprofv3 --pmc $C --output-format csv -d "$REPO/$OUT/pmc_$C" -o bench -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ) > $OUT/pmc_$C.log 2>&1; stamp pmc_$C $?
+  done
   ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$REPO/$OUT/pmc_sq" -o bench -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ) > $OUT/pmc_sq.log 2>&1; stamp pmc_sq $?
+  ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$REPO/$OUT/pmc_sq2" -o bench -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ) > $OUT/pmc_sq2.log 2>&1; stamp pmc_sq2 $?
+  python tools/pmc_summary.py $OUT > $OUT/pmc_summary.json 2>$OUT/pmc_summary.err; stamp pmc_summary $?
+  cat $OUT/pmc_summary.json
 fi
+# the bench line last: if profiles/hbm_traffic.json was just refreshed by the caller it is picked up next time
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT/prof" -o bench -- python "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline ) > $OUT/rocprof.log 2>&1
+stamp rocprof $?
+STATS=$(find $OUT/prof -name "*kernel_stats.csv" 2>/dev/null | head -1)
+if [ -n "$STATS" ]; then cp "$STATS" $OUT/kernel_stats.csv; head -6 "$STATS"; fi
+timeout 400 python bench.py --steps 10 --warmup 2 > $OUT/bench.log 2>&1; stamp bench $?
+tail -1 $OUT/bench.log
 echo done | tee -a $OUT/summary.txt
