@@ -337,15 +337,25 @@ RT_HD bool exact_hit_any_order_t(V3 o, V3 d, const RayK& rk, const SphereGeom& g
   }
   return false;
 }
-// a ray whose |d|^2 is outside div_by_recip's range: the reference's own arithmetic (cold)
-RT_HD_COLD void exact_hit_slow(V3 o, V3 d, double a, const SphereGeom& g, uint32_t idx, double& closest, int& best) {
+// a ray whose |d|^2 is outside div_by_recip's range: the reference's own arithmetic (cold).
+// Everything travels BY VALUE: a reference parameter of a real call would pin the caller's
+// closest/best (the hottest variables of the kernel) to stack memory.
+struct HitCB {
+  double closest;
+  int best;
+};
+RT_HD_COLD HitCB exact_hit_slow(V3 o, V3 d, double a, SphereGeom g, uint32_t idx, double closest, int best) {
   RayK rk; rk.a = a; rk.inv_a = 0.0; rk.fast = false;
   exact_hit_any_order_t<false>(o, d, rk, g, idx, closest, best);
+  HitCB r; r.closest = closest; r.best = best;
+  return r;
 }
 RT_HD bool exact_hit_any_order(V3 o, V3 d, const RayK& rk, const SphereGeom& g, uint32_t idx, double& closest, int& best) {
   if (rk.fast) return exact_hit_any_order_t<true>(o, d, rk, g, idx, closest, best);
-  exact_hit_slow(o, d, rk.a, g, idx, closest, best);
-  return false;
+  const HitCB r = exact_hit_slow(o, d, rk.a, g, idx, closest, best);
+  const bool hit = r.best != best || r.closest != closest;
+  closest = r.closest; best = r.best;
+  return hit;
 }
 
 // ------------------------------------------------------------------ grid walk (hit_world, raytracer.rs:44-59)
@@ -608,10 +618,15 @@ RT_HD Surface surface_at(V3 o, V3 d, double t, const SphereGeom& g, double inv_r
 }
 // sphere.rs:35-43, evaluated only when the closest hit is a Texture (a pure function of the
 // accepted hit, so skipping it for the other candidates changes nothing)
-RT_HD_COLD void sphere_uv(V3 point, const SphereGeom& g, double& u, double& v) {
+struct UV {
+  double u, v;
+};
+RT_HD_COLD UV sphere_uv(V3 point, SphereGeom g) {  // by value: see exact_hit_slow
   V3 n = unit_vector(sub(point, v3(g.cx, g.cy, g.cz)));
-  u = (atan2(n.x, n.z) / (2.0 * 3.14159265358979323846264338327950288)) + 0.5;
-  v = n.y * 0.5 + 0.5;
+  UV r;
+  r.u = (atan2(n.x, n.z) / (2.0 * 3.14159265358979323846264338327950288)) + 0.5;
+  r.v = n.y * 0.5 + 0.5;
+  return r;
 }
 // unit_vector (point3d.rs:67-70) with one real division: 1/l, then div_by_recip per component
 RT_HD V3 unit_vector_fast(V3 a) {
@@ -638,9 +653,8 @@ RT_HD int scatter(const DevScene& sc, const RngAddr& ra, uint32_t node, V3 in_di
       V3 target = add(h.point, sd);
       out_dir = sub(target, h.point);  // (p + d) - p, as the reference computes it
       if (m.kind == RT_MAT_TEXTURE) {
-        double u, v;
-        sphere_uv(h.point, g, u, v);
-        Rgb a = texture_albedo(sc, sc.mat[idx], u, v, tex_oob);
+        const UV uv = sphere_uv(h.point, g);
+        Rgb a = texture_albedo(sc, sc.mat[idx], uv.u, uv.v, tex_oob);
         att[0] = a.r; att[1] = a.g; att[2] = a.b;
       }
       return SCATTER_RAY;

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         for (uint32_t idx = 0; idx < sc.n_spheres; ++idx) {
           const F64PtrK gp = geom_k + (size_t)idx * 4u;
           SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
-          if (mode == GRID_FALLBACK) exact_hit_slow(L.o, L.d, rk.a, g, idx, closest, best);
+          if (mode == GRID_FALLBACK) { const HitCB r = exact_hit_slow(L.o, L.d, rk.a, g, idx, closest, best); closest = r.closest; best = r.best; }
         }
         if (mode == GRID_FALLBACK) n_exact += sc.n_spheres;
       }
