@@ -29,6 +29,7 @@ VARIANTS = {
     "b1024_w3": (["-DRT_WAVES_PER_EU=3"], {}, {}),
     "b1024_w4_chunk4": (W4, {"chunk_spp": 4}, {}),
     "b1024_w4_chunk16": (W4, {"chunk_spp": 16}, {}),
+    "b1024_w4_chunk32": (W4, {"chunk_spp": 32}, {}),
     "b1024_w4_chunk128": (W4, {"chunk_spp": 128}, {}),
     "b1024_w4_cps2": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "2"}),
     "b1024_w4_cps8": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "8"}),
