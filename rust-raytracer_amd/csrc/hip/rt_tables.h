@@ -30,8 +30,11 @@ struct HostTables {
 };
 
 // Grid construction knobs (development tunables; the defaults are what ships).
+// Bytes the per-segment tables (geometry, material cores, cell entries, item lists) may take so
+// that the megakernel can keep them in LDS next to its tile slots (rt_kernel.hip: 160 KB per CU).
+constexpr size_t GRID_LDS_TABLE_BUDGET = 104u * 1024u;
 struct GridParams {
-  double cells_per_sphere = 4.0;   // target cell count = this * gridded spheres
+  double cells_per_sphere = 0.0;   // target cell count = this * gridded spheres; 0 = automatic (below)
   double large_radius_ratio = 16;  // |r| > ratio * median |r|  ->  `large` list
   uint32_t large_cell_limit = 512; // a sphere covering more cells than this -> `large` list
   uint32_t min_spheres = 24;       // fewer spheres than this: no grid, test them all
@@ -237,7 +240,20 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
     cp.cx[1] = cp.cx[0]; cp.cy[1] = cp.cy[0]; cp.cz[1] = cp.cz[0]; cp.R[1] = -INFINITY;
   }
   if (!t.lights.empty()) t.simple_colour = false;
-  build_grid(sc, t, grid_params_from_env());
+  GridParams gp = grid_params_from_env();
+  if (gp.cells_per_sphere > 0.0) build_grid(sc, t, gp);
+  else {
+    // Finer cells mean fewer exact tests per ray but more steps; measured on the headline scene
+    // (profiles/) 8 cells per sphere is best as long as the tables stay LDS-resident; scenes whose
+    // tables cannot fit anyway (thousands of spheres) walk a 4-cells-per-sphere grid out of L2.
+    const double tries[] = {8.0, 6.0, 4.0};
+    for (double c : tries) {
+      gp.cells_per_sphere = c;
+      build_grid(sc, t, gp);
+      const size_t bytes = (size_t)n * (sizeof(SphereGeom) + sizeof(MatCore)) + (size_t)t.grid.n_cells * 8u + (size_t)t.grid.n_items * 2u;
+      if (bytes <= GRID_LDS_TABLE_BUDGET || t.grid.n[0] == 0u) break;
+    }
+  }
   return "";
 }
 
