@@ -160,3 +160,9 @@ extern "C" int hostsim_hit_world(const RtScene* scene, const double o[3], const 
   out[0] = b1; out[1] = b2; t_out[0] = c1; t_out[1] = c2;
   return RT_OK;
 }
+
+// rt_core.h div_by_recip over arrays (property test against the IEEE quotient)
+extern "C" void hostsim_div_by_recip(const double* x, const double* b, double* out, uint64_t n) {
+#pragma omp parallel for
+  for (int64_t i = 0; i < (int64_t)n; ++i) out[i] = div_by_recip(x[i], b[i], 1.0 / b[i]);
+}

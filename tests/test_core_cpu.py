@@ -259,3 +259,28 @@ def test_any_order_hit_equals_object_order_scan(hostsim, abi):
         d = (c + rng.standard_normal(3) * 0.2) - o
         assert hostsim.hostsim_hit_world(C.byref(sc), dvec(*o), dvec(*d), out, t_out) == 0
         assert out[0] == out[1] and (out[0] < 0 or t_out[0] == t_out[1]), (trial, out[:], t_out[:])
+
+
+def test_div_by_recip_is_exact(hostsim):
+    """rt_core.h div_by_recip (Markstein's division through RN(1/b), two FMA corrections) must
+    equal the IEEE quotient bit for bit wherever the kernel uses it: random operands over the
+    supported range, plus divisors whose significand is all ones / just above a power of two."""
+    rng = np.random.default_rng(2024)
+    n = 10_000_000
+
+    def rnd(emin, emax, m):
+        mant = rng.integers(0, 1 << 52, m, dtype=np.uint64)
+        e = rng.integers(emin + 1023, emax + 1024, m, dtype=np.uint64)
+        sign = rng.integers(0, 2, m, dtype=np.uint64) << np.uint64(63)
+        return (sign | (e << np.uint64(52)) | mant).view(np.float64)
+
+    x = np.concatenate([rnd(-20, 20, n // 2), rnd(-140, 140, n // 4), rnd(-3, 3, n // 4)])
+    b = np.concatenate([rnd(-20, 20, n // 2), rnd(-140, 140, n // 4), rnd(-1, 1, n // 4)])
+    special = (np.uint64(1023) << np.uint64(52)) | np.concatenate([
+        (np.uint64((1 << 52) - 1) - rng.integers(0, 64, n // 8, dtype=np.uint64)), rng.integers(0, 64, n // 8, dtype=np.uint64)])
+    b[-(n // 4):] = special.view(np.float64)
+    out = np.empty_like(x)
+    hostsim.hostsim_div_by_recip(x.ctypes.data, b.ctypes.data, out.ctypes.data, len(x))
+    want = x / b
+    bad = out != want
+    assert not bad.any(), (int(bad.sum()), x[bad][:3], b[bad][:3])
