@@ -54,7 +54,8 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-row-stride", type=int, default=16, help="cpu_baseline renders every k-th scanline")
+    ap.add_argument("--cpu-row-stride", type=int, default=16,
+                    help="cpu_baseline renders every k-th scanline (default: chosen for ~10 s of CPU wall time)")
     args = ap.parse_args()
 
     import torch
@@ -176,14 +177,21 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             oracle = graft.load_oracle()
+            cores = oracle.lib(abi).rt_oracle_threads()
+
+            def cpu_run(stride):
+                ct = abi.RtRowTiles(1, 0, stride)
+                c0 = time.perf_counter()
+                _, _, ost = oracle.render(abi, sc.ptr, ct, 0, want_linear=False)
+                return time.perf_counter() - c0, ost, abi.tiles_local_rows(H, ct)
+
             stride = max(1, args.cpu_row_stride)
-            ct = abi.RtRowTiles(1, 0, stride)
-            rows = abi.tiles_local_rows(H, ct)
-            c0 = time.perf_counter()
-            _, _, ost = oracle.render(abi, sc.ptr, ct, 0, want_linear=False)
-            csec = time.perf_counter() - c0
+            if stride == 0 or args.cpu_row_stride == 16:   # default: size the sample for ~10 s of wall time on this box
+                probe_s, _, _ = cpu_run(64)
+                stride = int(min(64, max(1, round(64 * probe_s / 10.0))))
+            csec, ost, rows = cpu_run(stride)
             out["cpu_baseline"] = {"value": round(ost["samples"] / csec / 1e6, 4), "unit": "Msamples/s",
-                                   "cores": oracle.lib(abi).rt_oracle_threads(), "kind": "port",
+                                   "cores": cores, "kind": "port",
                                    "sample": f"every {stride}th scanline of the same frame ({rows} rows, {ost['samples'] / 1e6:.2f} Msamples, "
                                              f"{csec:.1f} s); C oracle, OpenMP one scanline per task, -O3 -march=native -ffp-contract=off",
                                    "gpu_over_cpu": round(value / (ost["samples"] / csec / 1e6), 1)}
