@@ -8,7 +8,7 @@
 A "step" is one frame of BASELINE configs[1] — cover_scene at 1200x800, spp 128, depth 50,
 484 spheres — rendered by the HIP megakernel through the C ABI (librt_hip.so), with the
 scene tables already resident in HBM.  With N > 1 the frame is sharded by interleaved
-8-scanline tiles (rank r renders tiles r, r+N, ...) and assembled on rank 0 by ONE gather
+2-scanline tiles (rank r renders tiles r, r+N, ...) and assembled on rank 0 by ONE gather
 over RCCL; total work is fixed, so scaling is "strong" (the north-star target is a >=6x
 speed-up of this frame at 8 GPUs).  Rank 0 prints ONE JSON line.
 
@@ -158,7 +158,7 @@ def main():
             "dtype": "f64", "data": "scene derived from the reference's data/cover_scene.json (committed under scenes/); Philox seed 0",
             "config": {"workload": f"{os.path.basename(args.scene)}: {W}x{H} spp {SPP} depth {sc.c.max_depth}, {N_SPH} spheres"
                                    + (" (BASELINE configs[1])" if headline else " (NON-HEADLINE run)"),
-                       "parallelism": f"{world} x interleaved 8-scanline tiles, one RCCL gather" if world > 1 else "single GPU",
+                       "parallelism": f"{world} x interleaved {rdist.TILE_ROWS}-scanline tiles, one RCCL gather" if world > 1 else "single GPU",
                        "inputs": "scene tables resident in HBM before the timed region"},
             "kernel_ms": round(kernel_ms, 4), "segments_per_sample": round(segments / samples, 4),
             "exact_tests_per_segment": round(exact / max(1.0, segments), 3),

@@ -198,7 +198,8 @@ int rt_hip_render(RtHipScene*, const RtRowTiles* tiles, void* d_rgb8, void* d_li
 int rt_hip_wait(RtHipScene*, RtStats* stats);
 /* Tunables / A-B arms.  Keys: "variant" 0 = grid walk (default), 1 = the
  * reference's brute force (exact test on every sphere), 2 = round-1 f32 cull-scan kernel;
- * "chunk_spp" samples of a pixel per work item (0 = automatic); "samples_per_pixel",
+ * "chunk_spp" samples of a pixel per work item (0 = automatic); "tile_log2" pixel tiles of
+ * 2^k x 2^k (k = 0..3, -1 = automatic); "samples_per_pixel",
  * "max_depth", "seed" override the scene's values. */
 int rt_hip_set_option(RtHipScene*, const char* key, int64_t value);
 /* Convenience = the drop-in for render()'s parallel loop: host buffers in, host RGB8 out.

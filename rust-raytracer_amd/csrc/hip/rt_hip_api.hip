@@ -42,6 +42,7 @@ struct RtHipScene {
   unsigned long long* d_counters = nullptr;  // 4 counters + the work-queue cursor
   int num_cus = 0;
   int chunk_spp = 0;       // 0 = automatic
+  int tile_log2 = -1;      // -1 = automatic; else tiles of 2^k x 2^k pixels, k = 0..3
 
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   hipStream_t last_stream = nullptr;
@@ -162,6 +163,7 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
   if (!s || !key) return fail(RT_ERR_INVALID, "null argument");
   if (!std::strcmp(key, "variant")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "variant must be 0, 1 or 2"); s->variant = (int)value; return RT_OK; }
   if (!std::strcmp(key, "pool")) { s->pool = value != 0; return RT_OK; }
+  if (!std::strcmp(key, "tile_log2")) { if (value < -1 || value > 3) return fail(RT_ERR_INVALID, "tile_log2 must be -1..3"); s->tile_log2 = (int)value; return RT_OK; }
   if (!std::strcmp(key, "chunk_spp")) { if (value < 0) return fail(RT_ERR_INVALID, "chunk_spp must be >= 0"); s->chunk_spp = (int)value; return RT_OK; }
   if (!std::strcmp(key, "samples_per_pixel")) { s->host.samples_per_pixel = s->dev.spp = (uint32_t)value; return RT_OK; }
   if (!std::strcmp(key, "max_depth")) { s->host.max_depth = s->dev.max_depth = (uint32_t)value; return RT_OK; }
@@ -243,19 +245,28 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   const bool tiled = tiles && tiles->tile_rows && tiles->tile_stride;
   ka.tile_rows = tiled ? tiles->tile_rows : 0; ka.first_tile = tiled ? tiles->first_tile : 0;
   ka.tile_stride = tiled ? tiles->tile_stride : 0;
-  ka.tiles_x = (s->host.width + rtk::TILE - 1) / rtk::TILE;
-  ka.n_tiles = ka.tiles_x * ((local_rows + rtk::TILE - 1) / rtk::TILE);
-  // A tile's samples are handed out to the waves of a workgroup in chunks: ~64 chunk items per
-  // resident wave over the frame (the last items to finish then cost ~1-2 % of it), at least 4
-  // samples per chunk.
+  // Pixel tile: the unit of the global queue, owned by ONE workgroup.  8x8 when the frame has
+  // >= ~100 tiles per workgroup; small frames (and the 1/8 shards of the multi-GPU run) use 4x4,
+  // 2x2 or 1x1 tiles, so that the heaviest tile (glass: 10x the mean) is a small part of a
+  // workgroup's share and the long-path regions spread over many workgroups.
+  const uint64_t want_tiles = (uint64_t)s->num_cus * 100u;
+  uint32_t tl = (uint32_t)s->tile_log2;
+  if (s->tile_log2 < 0) {
+    tl = 3;
+    while (tl > 0 && (uint64_t)((s->host.width + (1u << tl) - 1) >> tl) * ((local_rows + (1u << tl) - 1) >> tl) < want_tiles) tl--;
+  }
+  ka.tile_log2 = tl;
+  ka.tiles_x = (s->host.width + (1u << tl) - 1) >> tl;
+  ka.n_tiles = ka.tiles_x * ((local_rows + (1u << tl) - 1) >> tl);
+  // A tile's samples are handed out to the waves of its workgroup in chunks: an item's latency
+  // is what the last wave of a frame waits for, but below ~128 samples per item the acquire /
+  // finish overhead shows (measured, profiles/r01_run4_tiles.log): 8x8 -> 8 samples per pixel,
+  // 4x4 -> 16, 2x2 -> 32, 1x1 -> 128.
   const uint32_t spp = s->host.samples_per_pixel;
   uint32_t chunk_spp = (uint32_t)s->chunk_spp;
   if (chunk_spp == 0) {
-    const uint64_t target_items = (uint64_t)s->num_cus * 16u * 64u;
-    uint64_t chunks = (target_items + ka.n_tiles - 1) / ka.n_tiles;
-    if (chunks < 1) chunks = 1;
-    chunk_spp = (uint32_t)((spp + chunks - 1) / chunks);
-    if (chunk_spp < 4) chunk_spp = 4;
+    static const uint32_t by_tile[4] = {128u, 32u, 16u, 8u};
+    chunk_spp = by_tile[tl];
   }
   if (chunk_spp > spp || spp == 0) chunk_spp = spp ? spp : 1;
   ka.chunk_spp = chunk_spp;

@@ -35,6 +35,7 @@ struct KArgs {
   uint32_t* queue;               // tile cursor (zeroed before the launch)
   uint32_t local_rows, tile_rows, first_tile, tile_stride;
   uint32_t tiles_x, n_tiles, n_chunks, chunk_spp;  // a tile's samples are handed out in n_chunks chunks
+  uint32_t tile_log2;  // a tile is 2^tile_log2 x 2^tile_log2 pixels (8x8, 4x4, 2x2 or 1x1)
 };
 
 #ifndef RT_BLOCK
@@ -64,7 +65,7 @@ struct KArgs {
 
 constexpr int BLOCK = RT_BLOCK;
 constexpr int WAVES = BLOCK / 64;
-constexpr int TILE = 8;  // wave tile = 8x8 pixels
+constexpr int TILE_MAX = 8;  // largest pixel tile = 8x8 (one pixel per lane); smaller tiles for small frames
 
 // constant-address-space views: a wave-uniform index into these becomes an s_load
 typedef const double __attribute__((address_space(4))) * F64PtrK;
@@ -262,18 +263,19 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     const KArgs& ka = fresh_args();
     const DevScene& sc = ka.sc;
     const uint32_t by = tile / ka.tiles_x, bx = tile - by * ka.tiles_x;
-    const uint32_t px = bx * TILE + (lane & 7u);
-    const uint32_t lr = by * TILE + (lane >> 3);  // local (packed) row
+    const uint32_t tl = ka.tile_log2, tw = 1u << tl, npx = 1u << (2u * tl);  // pixel slots of the tile: lanes 0..npx-1
+    const uint32_t px = (bx << tl) + (lane & (tw - 1u));
+    const uint32_t lr = (by << tl) + (lane >> tl);  // local (packed) row
     uint32_t py = lr;  // global scanline (raytracer.rs:255: band index, 0 = top)
     if (ka.tile_rows != 0u) py = (ka.first_tile + (lr / ka.tile_rows) * ka.tile_stride) * ka.tile_rows + lr % ka.tile_rows;
     const uint32_t s_begin = chunk * ka.chunk_spp;
     const uint32_t s_left = sc.spp - s_begin;
     const uint32_t s_count = s_left < ka.chunk_spp ? s_left : ka.chunk_spp;
     s_k[j] = k; s_bx[j] = bx; s_by[j] = by; s_sbeg[j] = s_begin; s_next[j] = 0; s_out[j] = 0; s_active[j] = true;
-    // pool item w = (pixel slot w & 63, sample s_begin + (w >> 6)); max_depth == 0: ray_color
+    // pool item w = (pixel slot w % npx, sample s_begin + w / npx); max_depth == 0: ray_color
     // returns black before tracing anything (raytracer.rs:80-82), so nothing is handed out
-    s_total[j] = sc.max_depth != 0u ? 64u * s_count : 0u;
-    py_slot[j] = py; ok_slot[j] = px < sc.width && lr < ka.local_rows;
+    s_total[j] = sc.max_depth != 0u ? npx * s_count : 0u;
+    py_slot[j] = py; ok_slot[j] = lane < npx && px < sc.width && lr < ka.local_rows;
     RT_PROF_COUNT(cnt_items);
   };
   // all samples of item slot j are in their tile's pixel sums; the last chunk of a tile writes its pixels
@@ -287,9 +289,10 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     if (lane == 0) d = atomicAdd(&hdr[k].done, 1u) + 1u;
     if (bcast(d) != ka.n_chunks) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const uint32_t px = s_bx[j] * TILE + (lane & 7u), lr = s_by[j] * TILE + (lane >> 3);
+    const uint32_t tl = ka.tile_log2, tw = 1u << tl;
+    const uint32_t px = (s_bx[j] << tl) + (lane & (tw - 1u)), lr = (s_by[j] << tl) + (lane >> tl);
     const unsigned long long* acc = tile_acc + k * 192u;
-    if (px < sc.width && lr < ka.local_rows) {  // raytracer.rs:207-216: mean, sqrt gamma, f32 -> u8, store
+    if (lane < (1u << (2u * tl)) && px < sc.width && lr < ka.local_rows) {  // raytracer.rs:207-216: mean, sqrt gamma, f32 -> u8, store
       const size_t o = ((size_t)lr * sc.width + px) * 3;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -318,7 +321,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   for (;;) {
     // ------------------------------------------------------------ refill lanes that hold no path
     {
-      const DevScene& sc = fresh_args().sc;
+      const KArgs& kr = fresh_args();
+      const DevScene& sc = kr.sc;
+      const uint32_t tl = kr.tile_log2, tw = 1u << tl, pl = 2u * tl, pmask = (1u << pl) - 1u;
       bool want = !has_ray;
       for (;;) {
         const unsigned long long m = __ballot(want);
@@ -328,13 +333,13 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
           const uint32_t w = s_next[cur] + rank;
           const uint32_t left = s_total[cur] - s_next[cur], asked = (uint32_t)__builtin_popcountll(m);
           s_next[cur] += asked < left ? asked : left;
-          const uint32_t p = w & 63u;
+          const uint32_t p = w & pmask;
           const uint32_t p_py = (uint32_t)__shfl((int)py_slot[cur], (int)p);
           const int p_ok = __shfl((int)ok_slot[cur], (int)p);
           bool took = false;
           if (want && w < s_total[cur] && p_ok) {  // (a slot outside the image consumes its index and asks again)
-            const uint32_t p_px = s_bx[cur] * TILE + (p & 7u);
-            cur_p = p; my_slot = cur; L.s = s_sbeg[cur] + (w >> 6); L.ra.pixel = p_py * sc.width + p_px;
+            const uint32_t p_px = (s_bx[cur] << tl) + (p & (tw - 1u));
+            cur_p = p; my_slot = cur; L.s = s_sbeg[cur] + (w >> pl); L.ra.pixel = p_py * sc.width + p_px;
             lane_begin_sample(sc, L, p_px, p_py);
             has_ray = true; want = false; took = true;
           }

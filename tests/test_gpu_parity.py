@@ -37,11 +37,12 @@ def torch_cuda():
 def gpu_render(pkg, abi, torch_cuda):
     torch = torch_cuda
 
-    def _render(scene, tiles=None, variant=0, want_linear=True, pool=None, chunk_spp=None):
-        """variant 0: the product kernel (grid walk, work queue, exact fixed-point pixel sums);
+    def _render(scene, tiles=None, variant=0, want_linear=True, pool=None, chunk_spp=None, tile_log2=None):
+        """variant 0: the product kernel (grid walk, tile queue, exact fixed-point pixel sums);
         variant 1: same kernel, brute force over all spheres; variant 2: the round-1 cull-scan
         kernel, where pool=0 selects one lane per pixel with sequential f32 sums (the
-        reference's summation order).  chunk_spp: samples of a pixel per work item."""
+        reference's summation order).  chunk_spp: samples of a pixel per work item; tile_log2:
+        pixel tiles of 2^k x 2^k."""
         sc = scene.c
         rows = abi.tiles_local_rows(sc.height, tiles)
         gs = pkg.hip.HipScene(scene.ptr, 0)
@@ -51,6 +52,8 @@ def gpu_render(pkg, abi, torch_cuda):
             gs.set_option("pool", pool)
         if chunk_spp is not None:
             gs.set_option("chunk_spp", chunk_spp)
+        if tile_log2 is not None:
+            gs.set_option("tile_log2", tile_log2)
         rgb = torch.zeros((rows, sc.width, 3), dtype=torch.uint8, device="cuda:0")
         lin = torch.zeros((rows, sc.width, 3), dtype=torch.float32, device="cuda:0") if want_linear else None
         gs.render(rgb.data_ptr(), lin.data_ptr() if want_linear else 0, tiles, torch.cuda.current_stream().cuda_stream)
@@ -106,9 +109,9 @@ def test_matches_oracle_and_golden(name, gpu_render, oracle, hostsim, abi, load_
         assert np.array_equal(p_lin, h_lin) and np.array_equal(p_rgb, h_rgb)
         assert p_st["exact_tests"] == h_st["exact_tests"] and p_st["grid_steps"] == h_st["grid_steps"]
     # splitting a pixel's samples over several work items (HBM accumulator + epilogue) changes no bit
-    for cs in (1, 3, spp):
-        c_rgb, c_lin, c_st = gpu_render(sc, chunk_spp=cs)
-        assert np.array_equal(c_rgb, p_rgb) and np.array_equal(c_lin, p_lin) and c_st["segments"] == p_st["segments"]
+    for cs, tl in ((1, 3), (3, 2), (spp, 1), (2, 0), (spp, 3)):  # chunking and pixel-tile size change no bit either
+        c_rgb, c_lin, c_st = gpu_render(sc, chunk_spp=cs, tile_log2=tl)
+        assert np.array_equal(c_rgb, p_rgb) and np.array_equal(c_lin, p_lin) and c_st["segments"] == p_st["segments"], (cs, tl)
     for s_ in (st, p_st):
         assert s_["samples"] == w * h * spp == o_st["samples"]
         if sc.lights():

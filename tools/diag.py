@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--lib", default="", help="alternative librt_hip .so (an A/B build)")
+    ap.add_argument("--shard", default="", help="rank,world: render only that rank's interleaved 8-row tiles (multi-GPU emulation)")
     ap.add_argument("--procedural", type=int, default=0, help="use the procedural world with this `half` (50 -> ~10 000 spheres)")
     a = ap.parse_args()
     import torch
@@ -45,9 +46,14 @@ def main():
         k, v = kv.split("=")
         gs.set_option(k, int(v))
     rgb = torch.zeros((sc.c.height, sc.c.width, 3), dtype=torch.uint8, device="cuda:0")
+    tiles = None
+    if a.shard:
+        parts = [int(v) for v in a.shard.split(",")]
+        r, w = parts[0], parts[1]
+        tiles = pkg.abi.RtRowTiles(parts[2] if len(parts) > 2 else 8, r, w)
     best = None
     for _ in range(a.reps):
-        gs.render(rgb.data_ptr(), 0, None, torch.cuda.current_stream().cuda_stream)
+        gs.render(rgb.data_ptr(), 0, tiles, torch.cuda.current_stream().cuda_stream)
         st = gs.wait()
         if best is None or st["kernel_ms"] < best["kernel_ms"]:
             best = st
@@ -69,6 +75,7 @@ def main():
     if pc[6]:
         names = ["refill", "large", "grid_begin", "walk", "shade", "item", "total"]
         out["prof_share"] = {n: round(pc[i] / pc[6], 4) for i, n in enumerate(names[:6])}
+        out["wave_busy_frac_at_2.4GHz"] = round(pc[6] / (4096 * st["kernel_ms"] * 2.4e6), 3)
         out["prof_cycles_per_wave_iter"] = {n: round(pc[i] / max(1, wi[0]), 1) for i, n in enumerate(names)}
     print(json.dumps(out))
 
