@@ -256,6 +256,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
     while (tl > 0 && (uint64_t)((s->host.width + (1u << tl) - 1) >> tl) * ((local_rows + (1u << tl) - 1) >> tl) < want_tiles) tl--;
   }
   ka.tile_log2 = tl;
+  ka.t_slots = rtk::tile_slots(tl);
   ka.tiles_x = (s->host.width + (1u << tl) - 1) >> tl;
   ka.n_tiles = ka.tiles_x * ((local_rows + (1u << tl) - 1) >> tl);
   // A tile's samples are handed out to the waves of its workgroup in chunks: an item's latency

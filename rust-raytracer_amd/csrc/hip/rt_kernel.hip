@@ -36,6 +36,7 @@ struct KArgs {
   uint32_t local_rows, tile_rows, first_tile, tile_stride;
   uint32_t tiles_x, n_tiles, n_chunks, chunk_spp;  // a tile's samples are handed out in n_chunks chunks
   uint32_t tile_log2;  // a tile is 2^tile_log2 x 2^tile_log2 pixels (8x8, 4x4, 2x2 or 1x1)
+  uint32_t t_slots;    // tile slots per workgroup (tile_slots() of tile_log2)
 };
 
 #ifndef RT_BLOCK
@@ -71,29 +72,38 @@ constexpr int TILE_MAX = 8;  // largest pixel tile = 8x8 (one pixel per lane); s
 typedef const double __attribute__((address_space(4))) * F64PtrK;
 typedef const uint32_t __attribute__((address_space(4))) * U32PtrK;
 
-// ---- dynamic LDS layout: [tile slot headers: T_SLOTS x 16 B + flags][pixel sums: T_SLOTS x 64 x 3 u64]
-//                          [geom][matc][cell entries][cell items]
+// ---- dynamic LDS layout: [flags][tile slots: headers, then pixel sums][geom][matc][cell entries][cell items]
 // one resident set of workgroups per CU must fit 160 KB of LDS
 constexpr uint32_t LDS_TABLES_MAX_BYTES = BLOCK >= 1024 ? 156u * 1024u : (BLOCK >= 512 ? 78u * 1024u : 52u * 1024u);
-// Tile slots are shared by the workgroup: every wave holds at most two work items, so 2*WAVES
-// slots can never run out while a wave has room for another item.
-constexpr uint32_t T_SLOTS = 2u * WAVES;
-static_assert(T_SLOTS <= 64u, "one lane per tile slot in the slot scans");
+// Tile slots are shared by the workgroup.  A slot holds one open tile: header + the exact
+// fixed-point sums of its pixels.  It is freed when ALL samples of the tile have been added —
+// counted per tile, whichever waves traced them — so a long path only keeps its own tile's
+// slot busy; small tiles get proportionally more slots out of the same LDS budget.
 struct SlotHdr {
-  uint32_t tile;   // tile index of the frame
-  uint32_t next;   // next chunk to hand out (may overshoot n_chunks)
-  uint32_t done;   // chunks whose samples are all in the pixel sums
-  uint32_t state;  // SLOT_*
+  uint32_t tile_xy;   // tile column | tile row << 16
+  uint32_t next;      // next chunk to hand out (may overshoot n_chunks)
+  uint32_t finished;  // samples of this tile added to the pixel sums so far
+  uint32_t expected;  // valid pixels of the tile x samples_per_pixel
+  uint32_t state;     // SLOT_*
+  uint32_t pad[3];
 };
+static_assert(sizeof(SlotHdr) == 32, "slot header is 32 B");
 enum { SLOT_FREE = 0, SLOT_OPEN = 1, SLOT_OPENING = 2 };
-constexpr uint32_t LDS_HDR_BYTES = T_SLOTS * 16u + 16u;  // + {queue_empty flag, pad}
+constexpr uint32_t LDS_FLAGS_BYTES = 32u;                    // {queue_empty, hint} + pad
+constexpr uint32_t LDS_SLOT_BUDGET = WAVES * 3u * 1024u;     // 48 KB at 16 waves (3 KB per wave)
+constexpr uint32_t T_SLOTS_MAX = 512u;
+__host__ __device__ inline uint32_t tile_slots(uint32_t tile_log2) {
+  const uint32_t per_slot = 32u + (1u << (2u * tile_log2)) * 24u;
+  const uint32_t t = LDS_SLOT_BUDGET / per_slot;
+  return t > T_SLOTS_MAX ? T_SLOTS_MAX : t;
+}
 struct LdsLayout {
-  uint32_t acc_off, geom_off, matc_off, cell_off, item_off, total;
+  uint32_t hdr_off, geom_off, matc_off, cell_off, item_off, total;
 };
 __host__ __device__ inline LdsLayout lds_layout(uint32_t n_spheres, uint32_t n_cells, uint32_t n_items, bool tables) {
   LdsLayout l;
-  uint32_t o = LDS_HDR_BYTES;
-  l.acc_off = o; o += T_SLOTS * 64u * 3u * (uint32_t)sizeof(unsigned long long);
+  uint32_t o = LDS_FLAGS_BYTES;
+  l.hdr_off = o; o += LDS_SLOT_BUDGET;  // [t_slots headers][t_slots x npx x 3 u64 sums], sized by tile_slots()
   l.geom_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(SphereGeom);
   l.matc_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(MatCore);
   l.cell_off = o; if (tables) o += n_cells * 8u;
@@ -131,11 +141,15 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const LdsLayout lay = lds_layout(sc.n_spheres, G.n_cells, G.n_items, LDS_TABLES);
-  SlotHdr* const hdr = reinterpret_cast<SlotHdr*>(lds_raw);
-  uint32_t* const wg_q_empty = reinterpret_cast<uint32_t*>(lds_raw + T_SLOTS * 16u);
-  unsigned long long* const tile_acc = reinterpret_cast<unsigned long long*>(lds_raw + lay.acc_off);  // [T_SLOTS][64 px][3]
-  if (threadIdx.x < T_SLOTS) { SlotHdr h; h.tile = 0; h.next = 0; h.done = 0; h.state = SLOT_FREE; hdr[threadIdx.x] = h; }
-  if (threadIdx.x == 0) *wg_q_empty = 0u;
+  uint32_t* const wg_flags = reinterpret_cast<uint32_t*>(lds_raw);  // [0] the frame's tile queue is empty, [1] slot opened last
+  SlotHdr* const hdr = reinterpret_cast<SlotHdr*>(lds_raw + lay.hdr_off);
+  const uint32_t T = ka.t_slots, acc_stride = 3u << (2u * ka.tile_log2);  // u64 words of pixel sums per slot
+  unsigned long long* const tile_acc = reinterpret_cast<unsigned long long*>(lds_raw + lay.hdr_off + T * 32u);
+  for (uint32_t i = threadIdx.x; i < T; i += BLOCK) {
+    SlotHdr h; h.tile_xy = 0; h.next = 0x80000000u; h.finished = 0; h.expected = 0; h.state = SLOT_FREE; h.pad[0] = h.pad[1] = h.pad[2] = 0;
+    hdr[i] = h;
+  }
+  if (threadIdx.x == 0) { wg_flags[0] = 0u; wg_flags[1] = 0u; }
   if constexpr (!LDS_TABLES) __syncthreads();
 
   if constexpr (LDS_TABLES) {  // stage the tables once per (persistent) workgroup
@@ -187,112 +201,35 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 
   RT_PROF_DECL
   // ---- work distribution, two levels.
-  // Global: a queue of TILES (8x8 pixels, all their samples).  Workgroup: an open tile lives in
-  // one of T_SLOTS shared LDS slots (header + exact fixed-point pixel sums); its samples are
-  // handed out to the workgroup's waves in n_chunks chunks, and the wave that completes the last
-  // chunk converts the sums and writes the tile's pixels — the only HBM traffic of the frame.
-  // Wave: holds up to two chunk items at a time: the CURRENT one hands out samples, the PREVIOUS
-  // one only waits for its last paths to finish; when the current item has no samples left the
-  // lanes go straight on with the next item, so no lane idles while a neighbour finishes a long
-  // path, and all 16 waves of a workgroup converge on the last tiles of the frame.
-  uint32_t s_k[2] = {0, 0}, s_bx[2] = {0, 0}, s_by[2] = {0, 0}, s_sbeg[2] = {0, 0}, s_total[2] = {0, 0}, s_next[2] = {0, 0}, s_out[2] = {0, 0};
-  bool s_active[2] = {false, false};
-  uint32_t cur = 0;
+  // Global: a queue of pixel TILES (2^k x 2^k pixels, all their samples).  Workgroup: an open tile
+  // lives in one of T shared LDS slots (header + exact fixed-point pixel sums); its samples are
+  // handed out to the workgroup's waves in n_chunks chunks, every finished sample is counted per
+  // tile, and the wave that adds a tile's last sample converts the sums and writes its pixels —
+  // the only HBM traffic of the frame.  Wave: hands out one chunk item at a time; a lane that
+  // finishes a sample takes the next one at once (of the next item, if this one ran dry), so no
+  // lane idles while a neighbour finishes a long path, and all 16 waves of a workgroup converge
+  // on the last tiles of the frame.
+  uint32_t it_k = 0, it_bx = 0, it_by = 0, it_sbeg = 0, it_total = 0, it_next = 0;  // the wave's current item (uniform)
   bool q_done = false;            // no more items will ever be available to this wave
-  uint32_t py_slot[2] = {0, 0};   // per lane: global scanline of this lane's pixel slot in item slot j
-  bool ok_slot[2] = {false, false};  // per lane: that pixel slot is inside the image
-  uint32_t my_slot = 0, cur_p = lane;
+  uint32_t py_slot = 0;           // per lane: global scanline of this lane's pixel slot in the current item
+  bool ok_slot = false;           // per lane: that pixel slot is inside the image
+  uint32_t my_k = 0, cur_p = lane;  // tile slot and pixel slot of the lane's sample
   bool has_ray = false;
   auto bcast = [&](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+  auto lds_load = [&](const uint32_t* p) -> uint32_t { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  auto lds_store = [&](uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
-  // Take a chunk of an open tile, or open the next tile of the frame.  1: got (k, chunk, tile);
-  // 0: nothing right now (every slot is busy draining); -1: the frame has nothing left to hand out.
-  auto acquire = [&](uint32_t& k_out, uint32_t& chunk_out, uint32_t& tile_out) -> int {
-    const KArgs& ka = fresh_args();
-    const uint32_t n_chunks = ka.n_chunks;
-    for (int tries = 0; tries < 8; ++tries) {
-      const bool mine = lane < T_SLOTS;
-      const uint32_t st = mine ? __hip_atomic_load(&hdr[mine ? lane : 0].state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : (uint32_t)SLOT_OPENING;
-      const uint32_t nx = mine ? __hip_atomic_load(&hdr[mine ? lane : 0].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0xFFFFFFFFu;
-      unsigned long long mo = __ballot(mine && st == SLOT_OPEN && nx < n_chunks);
-      while (mo) {  // open tiles with chunks left: take one
-        const uint32_t k = (uint32_t)__builtin_ctzll(mo);
-        mo &= mo - 1ull;
-        uint32_t c = 0;
-        if (lane == 0) c = atomicAdd(&hdr[k].next, 1u);
-        c = bcast(c);
-        if (c < n_chunks) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          k_out = k; chunk_out = c; tile_out = bcast(__hip_atomic_load(&hdr[k].tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-          return 1;
-        }
-      }
-      if (bcast(__hip_atomic_load(wg_q_empty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u)
-        return __ballot(mine && st == SLOT_OPENING) ? 0 : -1;  // (a tile being opened right now will still offer chunks)
-      const unsigned long long mf = __ballot(mine && st == SLOT_FREE);
-      if (!mf) return 0;
-      const uint32_t k = (uint32_t)__builtin_ctzll(mf);
-      uint32_t ok = 0;
-      if (lane == 0) ok = atomicCAS(&hdr[k].state, (uint32_t)SLOT_FREE, (uint32_t)SLOT_OPENING) == (uint32_t)SLOT_FREE ? 1u : 0u;
-      if (!bcast(ok)) continue;  // another wave claimed it: rescan
-      uint32_t tile = 0;
-      if (lane == 0) tile = atomicAdd(ka.queue, 1u);
-      tile = bcast(tile);
-      if (tile >= ka.n_tiles) {  // the frame's queue is empty
-        if (lane == 0) {
-          __hip_atomic_store(wg_q_empty, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_store(&hdr[k].state, (uint32_t)SLOT_FREE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        continue;
-      }
-      unsigned long long* acc = tile_acc + k * 192u;
-      acc[lane * 3u] = 0ull; acc[lane * 3u + 1u] = 0ull; acc[lane * 3u + 2u] = 0ull;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) {  // publish: tile and done before next, next before state
-        __hip_atomic_store(&hdr[k].tile, tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_store(&hdr[k].done, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_store(&hdr[k].next, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // this wave takes chunk 0
-        __hip_atomic_store(&hdr[k].state, (uint32_t)SLOT_OPEN, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      k_out = k; chunk_out = 0; tile_out = tile;
-      return 1;
-    }
-    return 0;
-  };
-  auto open_item = [&](uint32_t j, uint32_t k, uint32_t chunk, uint32_t tile) {
+  // every sample of tile slot k is in its pixel sums: mean, sqrt gamma, f32 -> u8, store
+  // (raytracer.rs:207-216), then free the slot
+  auto flush_tile = [&](uint32_t k) {
     const KArgs& ka = fresh_args();
     const DevScene& sc = ka.sc;
-    const uint32_t by = tile / ka.tiles_x, bx = tile - by * ka.tiles_x;
-    const uint32_t tl = ka.tile_log2, tw = 1u << tl, npx = 1u << (2u * tl);  // pixel slots of the tile: lanes 0..npx-1
-    const uint32_t px = (bx << tl) + (lane & (tw - 1u));
-    const uint32_t lr = (by << tl) + (lane >> tl);  // local (packed) row
-    uint32_t py = lr;  // global scanline (raytracer.rs:255: band index, 0 = top)
-    if (ka.tile_rows != 0u) py = (ka.first_tile + (lr / ka.tile_rows) * ka.tile_stride) * ka.tile_rows + lr % ka.tile_rows;
-    const uint32_t s_begin = chunk * ka.chunk_spp;
-    const uint32_t s_left = sc.spp - s_begin;
-    const uint32_t s_count = s_left < ka.chunk_spp ? s_left : ka.chunk_spp;
-    s_k[j] = k; s_bx[j] = bx; s_by[j] = by; s_sbeg[j] = s_begin; s_next[j] = 0; s_out[j] = 0; s_active[j] = true;
-    // pool item w = (pixel slot w % npx, sample s_begin + w / npx); max_depth == 0: ray_color
-    // returns black before tracing anything (raytracer.rs:80-82), so nothing is handed out
-    s_total[j] = sc.max_depth != 0u ? npx * s_count : 0u;
-    py_slot[j] = py; ok_slot[j] = lane < npx && px < sc.width && lr < ka.local_rows;
-    RT_PROF_COUNT(cnt_items);
-  };
-  // all samples of item slot j are in their tile's pixel sums; the last chunk of a tile writes its pixels
-  auto finish_item = [&](uint32_t j) {
-    const KArgs& ka = fresh_args();
-    const DevScene& sc = ka.sc;
-    const uint32_t k = s_k[j];
-    s_active[j] = false;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    uint32_t d = 0;
-    if (lane == 0) d = atomicAdd(&hdr[k].done, 1u) + 1u;
-    if (bcast(d) != ka.n_chunks) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t xy = bcast(lds_load(&hdr[k].tile_xy));
     const uint32_t tl = ka.tile_log2, tw = 1u << tl;
-    const uint32_t px = (s_bx[j] << tl) + (lane & (tw - 1u)), lr = (s_by[j] << tl) + (lane >> tl);
-    const unsigned long long* acc = tile_acc + k * 192u;
-    if (lane < (1u << (2u * tl)) && px < sc.width && lr < ka.local_rows) {  // raytracer.rs:207-216: mean, sqrt gamma, f32 -> u8, store
+    const uint32_t px = ((xy & 0xFFFFu) << tl) + (lane & (tw - 1u)), lr = ((xy >> 16) << tl) + (lane >> tl);
+    const unsigned long long* acc = tile_acc + k * (3u << (2u * tl));
+    if (lane < (1u << (2u * tl)) && px < sc.width && lr < ka.local_rows) {
       const size_t o = ((size_t)lr * sc.width + px) * 3;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -302,7 +239,100 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_store(&hdr[k].state, (uint32_t)SLOT_FREE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) {
+      lds_store(&hdr[k].next, 0x80000000u);  // nothing to hand out from a free slot
+      lds_store(&hdr[k].state, (uint32_t)SLOT_FREE);
+    }
+  };
+
+  // Take a chunk of an open tile, or open the next tile of the frame.  1: got (k, chunk);
+  // 0: nothing right now (every slot is busy); -1: the frame has nothing left to hand out.
+  auto acquire = [&](uint32_t& k_out, uint32_t& chunk_out) -> int {
+    const KArgs& ka = fresh_args();
+    const DevScene& sc = ka.sc;
+    const uint32_t n_chunks = ka.n_chunks;
+    for (int tries = 0; tries < 8; ++tries) {
+      {  // fast path: the tile opened last usually still has chunks
+        const uint32_t h = bcast(lds_load(&wg_flags[1]));
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(&hdr[h].next, 1u);
+        c = bcast(c);
+        if (c < n_chunks) { k_out = h; chunk_out = c; return 1; }
+      }
+      // any other open tile with chunks left (two waves may have opened tiles at the same moment)
+      bool any_opening = false;
+      unsigned long long free_mask = 0ull; uint32_t free_base = 0;
+      for (uint32_t base = 0; base < T; base += 64u) {
+        const uint32_t k = base + lane;
+        const bool mine = k < T;
+        const uint32_t st = mine ? lds_load(&hdr[mine ? k : 0].state) : (uint32_t)SLOT_OPEN;
+        const uint32_t nx = mine ? lds_load(&hdr[mine ? k : 0].next) : 0xFFFFFFFFu;
+        unsigned long long mo = __ballot(mine && st == SLOT_OPEN && nx < n_chunks);
+        while (mo) {
+          const uint32_t kk = base + (uint32_t)__builtin_ctzll(mo);
+          mo &= mo - 1ull;
+          uint32_t c = 0;
+          if (lane == 0) c = atomicAdd(&hdr[kk].next, 1u);
+          c = bcast(c);
+          if (c < n_chunks) { k_out = kk; chunk_out = c; return 1; }
+        }
+        any_opening = any_opening || __any(mine && st == SLOT_OPENING);
+        const unsigned long long mf = __ballot(mine && st == SLOT_FREE);
+        if (mf && !free_mask) { free_mask = mf; free_base = base; }
+      }
+      if (bcast(lds_load(&wg_flags[0])) != 0u) return any_opening ? 0 : -1;  // (a tile being opened right now will still offer chunks)
+      if (!free_mask) return 0;
+      const uint32_t k = free_base + (uint32_t)__builtin_ctzll(free_mask);
+      uint32_t ok = 0;
+      if (lane == 0) ok = atomicCAS(&hdr[k].state, (uint32_t)SLOT_FREE, (uint32_t)SLOT_OPENING) == (uint32_t)SLOT_FREE ? 1u : 0u;
+      if (!bcast(ok)) continue;  // another wave claimed it: rescan
+      uint32_t tile = 0;
+      if (lane == 0) tile = atomicAdd(ka.queue, 1u);
+      tile = bcast(tile);
+      if (tile >= ka.n_tiles) {  // the frame's queue is empty
+        if (lane == 0) { lds_store(&wg_flags[0], 1u); lds_store(&hdr[k].state, (uint32_t)SLOT_FREE); }
+        continue;
+      }
+      const uint32_t tl = ka.tile_log2, tw = 1u << tl, npx = 1u << (2u * tl);
+      const uint32_t by = tile / ka.tiles_x, bx = tile - by * ka.tiles_x;
+      const uint32_t px = (bx << tl) + (lane & (tw - 1u)), lr = (by << tl) + (lane >> tl);
+      const uint32_t n_valid = (uint32_t)__builtin_popcountll(__ballot(lane < npx && px < sc.width && lr < ka.local_rows));
+      // max_depth == 0: ray_color returns black before tracing anything (raytracer.rs:80-82)
+      const uint32_t expected = sc.max_depth != 0u ? n_valid * sc.spp : 0u;
+      unsigned long long* acc = tile_acc + k * acc_stride;
+      if (lane < npx) { acc[lane * 3u] = 0ull; acc[lane * 3u + 1u] = 0ull; acc[lane * 3u + 2u] = 0ull; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) {  // publish: everything before next, next before state
+        lds_store(&hdr[k].tile_xy, bx | (by << 16));
+        lds_store(&hdr[k].finished, 0u);
+        lds_store(&hdr[k].expected, expected);
+        lds_store(&hdr[k].next, expected ? 1u : 0x80000000u);  // this wave takes chunk 0
+        lds_store(&hdr[k].state, (uint32_t)SLOT_OPEN);
+        lds_store(&wg_flags[1], k);
+      }
+      if (!expected) { flush_tile(k); continue; }  // nothing to trace: write the (black) pixels now
+      k_out = k; chunk_out = 0;
+      return 1;
+    }
+    return 0;
+  };
+  auto open_item = [&](uint32_t k, uint32_t chunk) {
+    const KArgs& ka = fresh_args();
+    const DevScene& sc = ka.sc;
+    const uint32_t xy = bcast(lds_load(&hdr[k].tile_xy));
+    const uint32_t bx = xy & 0xFFFFu, by = xy >> 16;
+    const uint32_t tl = ka.tile_log2, tw = 1u << tl, npx = 1u << (2u * tl);  // pixel slots of the tile: lanes 0..npx-1
+    const uint32_t px = (bx << tl) + (lane & (tw - 1u));
+    const uint32_t lr = (by << tl) + (lane >> tl);  // local (packed) row
+    uint32_t py = lr;  // global scanline (raytracer.rs:255: band index, 0 = top)
+    if (ka.tile_rows != 0u) py = (ka.first_tile + (lr / ka.tile_rows) * ka.tile_stride) * ka.tile_rows + lr % ka.tile_rows;
+    const uint32_t s_begin = chunk * ka.chunk_spp;
+    const uint32_t s_left = sc.spp - s_begin;
+    const uint32_t s_count = s_left < ka.chunk_spp ? s_left : ka.chunk_spp;
+    it_k = k; it_bx = bx; it_by = by; it_sbeg = s_begin; it_next = 0;
+    it_total = npx * s_count;  // pool item w = (pixel slot w % npx, sample s_begin + w / npx)
+    py_slot = py; ok_slot = lane < npx && px < sc.width && lr < ka.local_rows;
+    RT_PROF_COUNT(cnt_items);
   };
 
   // Per-lane hit_world state.  With RT_WALK_TRIPS > 0 a lane's grid walk may span several
@@ -328,41 +358,35 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       for (;;) {
         const unsigned long long m = __ballot(want);
         if (!m) break;
-        if (s_active[cur] && s_next[cur] < s_total[cur]) {  // hand out samples of the current item
+        if (it_next < it_total) {  // hand out samples of the current item
           const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          const uint32_t w = s_next[cur] + rank;
-          const uint32_t left = s_total[cur] - s_next[cur], asked = (uint32_t)__builtin_popcountll(m);
-          s_next[cur] += asked < left ? asked : left;
+          const uint32_t w = it_next + rank;
+          const uint32_t left = it_total - it_next, asked = (uint32_t)__builtin_popcountll(m);
+          it_next += asked < left ? asked : left;
           const uint32_t p = w & pmask;
-          const uint32_t p_py = (uint32_t)__shfl((int)py_slot[cur], (int)p);
-          const int p_ok = __shfl((int)ok_slot[cur], (int)p);
-          bool took = false;
-          if (want && w < s_total[cur] && p_ok) {  // (a slot outside the image consumes its index and asks again)
-            const uint32_t p_px = (s_bx[cur] << tl) + (p & (tw - 1u));
-            cur_p = p; my_slot = cur; L.s = s_sbeg[cur] + (w >> pl); L.ra.pixel = p_py * sc.width + p_px;
+          const uint32_t p_py = (uint32_t)__shfl((int)py_slot, (int)p);
+          const int p_ok = __shfl((int)ok_slot, (int)p);
+          if (want && w < it_total && p_ok) {  // (a slot outside the image consumes its index and asks again)
+            const uint32_t p_px = (it_bx << tl) + (p & (tw - 1u));
+            cur_p = p; my_k = it_k; L.s = it_sbeg + (w >> pl); L.ra.pixel = p_py * sc.width + p_px;
             lane_begin_sample(sc, L, p_px, p_py);
-            has_ray = true; want = false; took = true;
+            has_ray = true; want = false;
           }
-          s_out[cur] += (uint32_t)__builtin_popcountll(__ballot(took));
           continue;
         }
-        // the current item has nothing (more) to hand out
-        if (s_active[cur] && s_out[cur] == 0u) finish_item(cur);  // and nothing in flight: done with it
-        if (s_active[cur]) {             // it still drains: the next item goes into the other slot
-          if (s_active[cur ^ 1u]) break;  // both item slots busy: these lanes wait
-          cur ^= 1u;
-        }
+        // the current item has nothing (more) to hand out: on to the next one
         if (q_done) break;
-        uint32_t k = 0, chunk = 0, tile = 0;
-        const int got = acquire(k, chunk, tile);
+        uint32_t k = 0, chunk = 0;
+        const int got = acquire(k, chunk);
         if (got < 0) { q_done = true; break; }
-        if (got == 0) break;
-        open_item(cur, k, chunk, tile);
+        if (got == 0) break;  // every tile slot is busy: these lanes wait
+        open_item(k, chunk);
       }
     }
     if (!__any(has_ray)) {
       // nothing in flight.  Done when the frame has nothing left; otherwise (all tile slots are
-      // draining in other waves) wait a little and ask again — bounded, a wave may always retire.
+      // busy with other waves' long paths) wait a little and ask again — bounded, a wave may
+      // always retire: the samples it traced are already counted in their tiles.
       if (q_done || ++idle_spins > (1u << 16)) break;
       __builtin_amdgcn_s_sleep(32);
       continue;
@@ -494,19 +518,24 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       if (ready) {
         finished = lane_shade(fresh_args().sc, tb, L, hit_idx, hit_t);
         if (finished) {  // sample finished: add it to its pixel (raytracer.rs:203-205)
-          unsigned long long* acc = tile_acc + (my_slot ? s_k[1] : s_k[0]) * 192u + cur_p * 3u;
+          unsigned long long* acc = tile_acc + my_k * acc_stride + cur_p * 3u;
           atomicAdd(&acc[0], sample_to_fixed(L.val[0]));
           atomicAdd(&acc[1], sample_to_fixed(L.val[1]));
           atomicAdd(&acc[2], sample_to_fixed(L.val[2]));
           has_ray = false;
         }
       }
-      const unsigned long long mf = __ballot(finished);
-      if (mf) {
-#pragma unroll
-        for (uint32_t j = 0; j < 2u; ++j) {
-          s_out[j] -= (uint32_t)__builtin_popcountll(__ballot(finished && my_slot == j));
-          if (s_active[j] && s_out[j] == 0u && s_next[j] >= s_total[j]) finish_item(j);
+      unsigned long long mf = __ballot(finished);
+      if (mf) {  // count the finished samples per tile; whoever adds a tile's last sample writes its pixels
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        while (mf) {
+          const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)my_k, (int)__builtin_ctzll(mf));
+          const unsigned long long same = __ballot(finished && my_k == k);
+          mf &= ~same;
+          const uint32_t cnt = (uint32_t)__builtin_popcountll(same);
+          uint32_t total = 0, expected = 1;
+          if (lane == 0) { total = atomicAdd(&hdr[k].finished, cnt) + cnt; expected = lds_load(&hdr[k].expected); }
+          if (bcast(total) == bcast(expected)) flush_tile(k);
         }
       }
       RT_PROF(4);
