@@ -392,6 +392,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       continue;
     }
 
+    idle_spins = 0;
     RT_PROF_COUNT(cnt_w_iter);
     RT_PROF(0);
     {
