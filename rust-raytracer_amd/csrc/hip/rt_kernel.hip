@@ -2,16 +2,18 @@
 // (raytracer/src/raytracer.rs:191-218, 71-165, 44-59) as ONE persistent launch.
 //
 // Shape (CDNA4-first):
-//   * persistent workgroups (one per CU, 16 waves) pull 8x8-pixel TILES from a global queue; a
-//     tile's samples are handed out to the workgroup's waves in small chunks through shared LDS
-//     slots, so the frame has no tail even though paths differ 50x in length, and a pixel's
-//     samples meet in LDS: the only HBM traffic of a frame is the framebuffer write;
+//   * persistent workgroups (one per CU, 16 waves) pull pixel TILES (8x8 ... 1x1, by frame size)
+//     from a global queue; a tile's samples are handed out to the workgroup's waves in small
+//     chunks through shared LDS slots and counted per tile, so the frame has no tail even though
+//     paths differ 50x in length, and a pixel's samples meet in LDS: the only HBM traffic of a
+//     frame is the framebuffer write;
 //   * the scene tables a ray touches per segment — f64 sphere geometry, material cores, the
 //     uniform grid's cell words and item lists — are staged ONCE per workgroup into LDS and
 //     gathered from there by lane (ds_read_b64), never from HBM;
-//   * inside an item the wave's 64 x chunk samples form one pool: a lane that finishes a
-//     sample takes the next (pixel, sample) by ballot + prefix rank, so all 64 lanes enter
-//     hit_world together every iteration (active-ray compaction without moving any state);
+//   * the samples of a wave's current chunk item form a pool: a lane that finishes a sample
+//     takes the next (pixel, sample) by ballot + prefix rank — from the next item if this one ran
+//     dry — so all 64 lanes enter hit_world together every iteration (active-ray compaction
+//     without moving any state);
 //   * hit_world = `large` spheres (the ground) tested by every lane through scalar loads, then
 //     a per-lane 3D-DDA through the uniform grid (f32, conservative) whose cells list the
 //     spheres that get the reference's exact f64 Sphere::hit.  The closest hit is the
