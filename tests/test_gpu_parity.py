@@ -139,13 +139,26 @@ def test_grid_variant_equals_bruteforce_variant(gpu_render, load_scene, scene, w
         assert a_st["grid_steps"] > 0 and a_st["exact_tests"] < 0.05 * a_st["sphere_tests"]
 
 
+def test_work_distribution_stress(gpu_render, load_scene):
+    """The tile-slot protocol under contention: thousands of one-pixel tiles with one-sample chunks
+    (every acquire opens or re-opens a slot), big tiles with tiny chunks, ragged image edges — the
+    frame and the path count never change, run after run."""
+    sc = load_scene("cover", 203, 117, 5, 50)  # neither dimension a multiple of any tile size
+    ref_rgb, ref_lin, ref_st = gpu_render(sc)
+    for tl, cs in ((0, 1), (0, 5), (1, 1), (2, 2), (3, 1), (3, 5), (1, 3)):
+        for _ in range(2):
+            rgb, lin, st = gpu_render(sc, chunk_spp=cs, tile_log2=tl)
+            assert np.array_equal(rgb, ref_rgb) and np.array_equal(lin, ref_lin), (tl, cs)
+            assert st["segments"] == ref_st["segments"] and st["samples"] == 203 * 117 * 5
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_row_tile_shards_reassemble_bit_identically(gpu_render, abi, load_scene, world):
     sc = load_scene("cover", 72, 45, 3, 50)
     full_rgb, full_lin, _ = gpu_render(sc)
     seen = 0
     for rank in range(world):
-        t = abi.RtRowTiles(8, rank, world)
+        t = abi.RtRowTiles(2 if world == 8 else 8, rank, world)
         rows = abi.tiles_global_rows(45, t)
         rgb, lin, st = gpu_render(sc, tiles=t)
         assert np.array_equal(rgb, full_rgb[rows]) and np.array_equal(lin, full_lin[rows])
