@@ -635,12 +635,18 @@ RT_HD V3 unit_vector_fast(V3 a) {
   double y = 1.0 / l;
   return v3(div_by_recip(a.x, l, y), div_by_recip(a.y, l, y), div_by_recip(a.z, l, y));
 }
+RT_HD bool material_draws_unit_sphere(uint32_t kind) {
+  return kind == RT_MAT_LAMBERTIAN || kind == RT_MAT_TEXTURE || kind == RT_MAT_METAL;
+}
+// rnd_pre: the random_in_unit_sphere(ra, node) point if the caller already drew it (the kernel
+// draws it for all lanes of a wave together, rt_kernel.hip::coop_random_in_unit_sphere), or null
 RT_HD int scatter(const DevScene& sc, const RngAddr& ra, uint32_t node, V3 in_dir, const Surface& h,
-                  const SphereGeom& g, const MatCore& m, uint32_t idx, V3& out_dir, float att[3], uint32_t& tex_oob) {
+                  const SphereGeom& g, const MatCore& m, uint32_t idx, V3& out_dir, float att[3], uint32_t& tex_oob,
+                  const V3* rnd_pre = nullptr) {
   // Lambertian, Texture and Metal all draw random_in_unit_sphere (Metal even with fuzz = 0,
   // materials.rs:120); one shared rejection loop instead of one per material branch.
   V3 rnd = v3(0.0, 0.0, 0.0);
-  if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_TEXTURE || m.kind == RT_MAT_METAL) rnd = random_in_unit_sphere(ra, node);
+  if (material_draws_unit_sphere(m.kind)) rnd = rnd_pre ? *rnd_pre : random_in_unit_sphere(ra, node);
   att[0] = m.albedo[0]; att[1] = m.albedo[1]; att[2] = m.albedo[2];
   switch (m.kind) {
     case RT_MAT_LIGHT:  // :65-69
@@ -808,7 +814,7 @@ RT_HD bool lane_light_return(const DevScene& sc, const Tables& tb, Lane<true>& L
 // Consume the closest hit (idx < 0: miss) of the lane's current ray.  Returns true when the
 // lane's current sample finished (its radiance is in L.val; the caller starts the next one).
 template <class LaneT, class Tables>
-RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, double t) {
+RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, double t, const V3* rnd_pre = nullptr) {
   constexpr bool HL = LaneT::kLights;
   if (idx < 0) {  // raytracer.rs:133-163
     Rgb sky = sky_color(sc, L.d, L.n_tex_oob);
@@ -823,7 +829,7 @@ RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, d
   Surface h = surface_at(L.o, L.d, t, g, m.inv_r);
   V3 out_dir = v3(0, 0, 0);
   float att[3];
-  int st = scatter(sc, L.ra, L.node, L.d, h, g, m, (uint32_t)idx, out_dir, att, L.n_tex_oob);
+  int st = scatter(sc, L.ra, L.node, L.d, h, g, m, (uint32_t)idx, out_dir, att, L.n_tex_oob, rnd_pre);
   const float zero3[3] = {0.0f, 0.0f, 0.0f};
 
   if constexpr (HL) {

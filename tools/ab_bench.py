@@ -23,18 +23,19 @@ BASE = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=of
 # name -> (extra compile flags, runtime options, environment at scene creation)
 W4 = ["-DRT_WAVES_PER_EU=4"]
 VARIANTS = {
-    "b1024_w4": (W4, {}, {}),
-    "b512_w4": (W4 + ["-DRT_BLOCK=512"], {}, {}),
-    "b256_w4": (W4 + ["-DRT_BLOCK=256"], {}, {}),
-    "b1024_w3": (["-DRT_WAVES_PER_EU=3"], {}, {}),
-    "b1024_w4_chunk4": (W4, {"chunk_spp": 4}, {}),
-    "b1024_w4_chunk16": (W4, {"chunk_spp": 16}, {}),
-    "b1024_w4_chunk32": (W4, {"chunk_spp": 32}, {}),
-    "b1024_w4_chunk128": (W4, {"chunk_spp": 128}, {}),
-    "b1024_w4_cps2": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "2"}),
-    "b1024_w4_cps8": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "8"}),
-    "b1024_w4_brute": (W4, {"variant": 1}, {}),
-    "round1_scan": (W4, {"variant": 2}, {}),
+    "default": (W4, {}, {}),
+    "b512": (W4 + ["-DRT_BLOCK=512"], {}, {}),
+    "b256": (W4 + ["-DRT_BLOCK=256"], {}, {}),
+    "waves3": (["-DRT_WAVES_PER_EU=3"], {}, {}),
+    "no_coop_random": (W4 + ["-DRT_COOP_RANDOM=0"], {}, {}),
+    "walk_trips12": (W4 + ["-DRT_WALK_TRIPS=12"], {}, {}),
+    "tile8x8_chunk8": (W4, {"tile_log2": 3, "chunk_spp": 8}, {}),
+    "tile8x8_unchunked": (W4, {"tile_log2": 3, "chunk_spp": 128}, {}),
+    "tile2x2_chunk32": (W4, {"tile_log2": 1, "chunk_spp": 32}, {}),
+    "cells_per_sphere2": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "2"}),
+    "cells_per_sphere4": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "4"}),
+    "brute_force_on_gpu": (W4, {"variant": 1}, {}),
+    "round1_scan_kernel": (W4, {"variant": 2}, {}),
 }
 
 
