@@ -638,8 +638,7 @@ RT_HD V3 unit_vector_fast(V3 a) {
 RT_HD bool material_draws_unit_sphere(uint32_t kind) {
   return kind == RT_MAT_LAMBERTIAN || kind == RT_MAT_TEXTURE || kind == RT_MAT_METAL;
 }
-// rnd_pre: the random_in_unit_sphere(ra, node) point if the caller already drew it (the kernel
-// draws it for all lanes of a wave together, rt_kernel.hip::coop_random_in_unit_sphere), or null
+// rnd_pre: the random_in_unit_sphere(ra, node) point if the caller already drew it, or null
 RT_HD int scatter(const DevScene& sc, const RngAddr& ra, uint32_t node, V3 in_dir, const Surface& h,
                   const SphereGeom& g, const MatCore& m, uint32_t idx, V3& out_dir, float att[3], uint32_t& tex_oob,
                   const V3* rnd_pre = nullptr) {

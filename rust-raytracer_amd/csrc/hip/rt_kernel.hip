@@ -125,67 +125,6 @@ __device__ __forceinline__ const KArgs& fresh_args() {
   return *(const KArgs*)p;
 }
 
-// random_in_unit_sphere (point3d.rs:31-38) for a whole wave.  Per lane the rejection loop takes
-// 1.9 attempts on average but a wave would run max-over-lanes (~6) rounds of it.  Here every lane
-// makes attempt 0 for itself; after that ALL 64 lanes (also those that need no point) work for
-// the lanes still failing: helper lane h makes attempt base + h / nf of failing lane #(h % nf)
-// (its RNG address fetched with ds_bpermute), and each failing lane takes the words of its
-// lowest-numbered accepted attempt.  Attempt a is Philox slot 1+a whoever computes it, so the
-// result is bit-identical to the sequential loop — in ~2.3 rounds instead of ~6.
-#ifndef RT_COOP_RANDOM
-#define RT_COOP_RANDOM 1
-#endif
-__device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, const RngAddr& ra, uint32_t node, uint32_t lane) {
-  auto point = [](U4 w) { return v3(range_m1_1(w.x), range_m1_1(w.y), range_m1_1(w.z)); };
-  U4 w; w.x = w.y = w.z = w.w = 0u;
-  bool pending = false;
-  if (need) {
-    w = rng(ra, node, 1u);
-    pending = !(length_squared(point(w)) < 1.0);
-  }
-  uint32_t base = 1;  // next attempt of every lane still pending (wave-uniform)
-  for (;;) {
-    const unsigned long long F = __ballot(pending);
-    if (!F) break;
-    const uint32_t nf = (uint32_t)__builtin_popcountll(F);
-    uint32_t layers = 64u / nf;
-    if (layers > 8u) layers = 8u;
-    // failing lane #r publishes its lane id to lane r (forward permute), helpers read entry h % nf
-    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(F >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)F, 0u));
-    const int ids = __builtin_amdgcn_ds_permute((int)((pending ? r : nf + (lane - r)) << 2), (int)lane);  // (a full permutation: the others fill nf..63)
-    const uint32_t m = (65536u + nf - 1u) / nf;          // j = h / nf for h < 64 by multiplication
-    const uint32_t j = (lane * m) >> 16, q = lane - j * nf;
-    const int src = __builtin_amdgcn_ds_bpermute((int)(q << 2), ids);
-    RngAddr ha;
-    ha.pixel = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)ra.pixel);
-    ha.sample = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)ra.sample);
-    ha.k0 = ra.k0; ha.k1 = ra.k1;
-    const uint32_t hnode = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)node);
-    const bool helping = j < layers;
-    U4 hw; hw.x = hw.y = hw.z = hw.w = 0u;
-    bool acc = false;
-    if (helping) {
-      hw = rng(ha, hnode, 1u + base + j);
-      acc = length_squared(point(hw)) < 1.0;
-    }
-    const unsigned long long A = __ballot(acc);
-    // failing lane #r: lowest layer whose helper (lane r + layer * nf) accepted
-    uint32_t from = lane;
-    bool found = false;
-    for (uint32_t l = 0; l < layers; ++l) {
-      const uint32_t hl = r + l * nf;
-      const bool hit = pending && !found && hl < 64u && ((A >> hl) & 1ull);
-      if (hit) { from = hl; found = true; }
-    }
-    const uint32_t gx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)hw.x);
-    const uint32_t gy = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)hw.y);
-    const uint32_t gz = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)hw.z);
-    if (found) { w.x = gx; w.y = gy; w.z = gz; pending = false; }
-    base += layers;
-  }
-  return point(w);
-}
-
 struct LdsTables {  // per-lane gathers from the workgroup's LDS copies
   const double* g;
   const MatCore* m;
@@ -579,16 +518,8 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         it = end = 0; pend = last = 0xFFFFFFFFu;
       }
       bool finished = false;
-#if RT_COOP_RANDOM
-      // the unit-sphere point most hits need is drawn by the whole wave together
-      const bool need_rnd = ready && hit_idx >= 0 && material_draws_unit_sphere(tb.mat((uint32_t)(hit_idx >= 0 ? hit_idx : 0)).kind);
-      const V3 rnd = coop_random_in_unit_sphere(need_rnd, L.ra, L.node, lane);
-      const V3* const rnd_pre = &rnd;
-#else
-      const V3* const rnd_pre = nullptr;
-#endif
       if (ready) {
-        finished = lane_shade(fresh_args().sc, tb, L, hit_idx, hit_t, rnd_pre);
+        finished = lane_shade(fresh_args().sc, tb, L, hit_idx, hit_t);
         if (finished) {  // sample finished: add it to its pixel (raytracer.rs:203-205)
           unsigned long long* acc = tile_acc + my_k * acc_stride + cur_p * 3u;
           atomicAdd(&acc[0], sample_to_fixed(L.val[0]));
