@@ -18,9 +18,9 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
                  float* linear, RtStats* stats, int use_cull_flags) {
   const int use_cull = use_cull_flags & 15;
   const uint32_t rows = rt_tiles_local_rows(sc.height, tiles);
-  uint64_t segs = 0, exact = 0, oob = 0, cull_false_reject = 0, steps = 0;
+  uint64_t segs = 0, exact = 0, oob = 0, cull_false_reject = 0, steps = 0, cam_steps = 0, cam_segs = 0, cam_exact = 0;
   const GlobalTables tb{ds.geom, ds.matc};
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : segs, exact, oob, cull_false_reject, steps)
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : segs, exact, oob, cull_false_reject, steps, cam_steps, cam_segs, cam_exact)
   for (uint32_t lr = 0; lr < rows; ++lr) {
     const uint32_t y = rt_tiles_global_row(tiles, lr);
     for (uint32_t x = 0; x < sc.width; ++x) {
@@ -43,8 +43,10 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
         L.n_segments++;
         if (use_cull == 3 || use_cull == 4) {  // the product's hit_world: `large` list + grid walk
           uint32_t n_steps = 0;
+          const uint32_t e0 = L.n_exact;
           hit_world_grid(ds, tb, L.o, L.d, closest, best, L.n_exact, n_steps);
           steps += n_steps;
+          if (L.k == 0 && !L.in_light) { cam_steps += n_steps; cam_segs++; cam_exact += L.n_exact - e0; }
           if (use_cull == 4) {  // audit: the reference's brute force must agree on (t, sphere), bit for bit
             double c2 = T_MAX; int b2 = -1;
             for (uint32_t i = 0; i < sc.n_spheres; ++i) {
@@ -89,6 +91,7 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
     stats->samples = (uint64_t)rows * sc.width * sc.samples_per_pixel;
     stats->segments = segs; stats->sphere_tests = segs * sc.n_spheres; stats->exact_tests = exact;
     stats->tex_oob = oob; stats->kernel_ms = (double)cull_false_reject; stats->frame_ms = 0; stats->grid_steps = steps;
+    stats->wave_iters[0] = cam_steps; stats->wave_iters[1] = cam_segs; stats->wave_iters[2] = cam_exact;  // camera-ray share (diagnostics)
   }
 }
 }  // namespace
