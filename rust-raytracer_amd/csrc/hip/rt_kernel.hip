@@ -44,9 +44,10 @@ struct KArgs {
 #ifndef RT_BLOCK
 #define RT_BLOCK 1024
 #endif
-// a test round runs when at least this many lanes have a sphere queued (or nobody can step)
-#ifndef RT_TEST_BATCH
-#define RT_TEST_BATCH 32
+// walk rounds per path-loop iteration before the wave shades the lanes that are ready (0 = no cap:
+// every lane finishes its walk first)
+#ifndef RT_WALK_TRIPS
+#define RT_WALK_TRIPS 0
 #endif
 
 #ifndef RT_WAVES_PER_EU
@@ -336,6 +337,17 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     RT_PROF_COUNT(cnt_items);
   };
 
+  // Per-lane hit_world state.  With RT_WALK_TRIPS > 0 a lane's grid walk may span several
+  // iterations of the path loop: the wave leaves the walk after that many rounds, shades the lanes
+  // whose closest hit is known, and the stragglers carry on next to the freshly scattered rays.
+  bool walking = false;
+  float tm0 = 0.f, tm1 = 0.f, tm2 = 0.f;  // GridWalk.tmax
+  float iv0 = 0.f, iv1 = 0.f, iv2 = 0.f;  // GridWalk.delta with the sign of GridWalk.dl
+  int lin = 0;
+  double t0 = 0.0, closest = T_MAX;
+  int best = -1;
+  uint32_t it = 0, end = 0, pend = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
+
   RT_PROF(5);
   uint32_t idle_spins = 0;
   for (;;) {
@@ -394,86 +406,65 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       const uint32_t n_large = G.n_large;
       const bool has_grid = G.n[0] != 0u;
       const RayK rk = ray_consts(L.d);
-      double closest = T_MAX;
-      int best = -1;
-      if (has_ray) n_segments++;
-      // (1) spheres outside the grid: every lane tests them; the record is wave-uniform -> SGPRs
-      for (uint32_t i = 0; i < n_large; ++i) {
-        const uint32_t idx = large_k[i];
-        const F64PtrK gp = geom_k + (size_t)idx * 4u;
-        SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
-        if (has_ray && rk.fast) exact_hit_any_order_t<true>(L.o, L.d, rk, g, idx, closest, best);
-      }
-      if (has_ray && rk.fast) n_exact += n_large;
-      RT_PROF(1);
-      // (2) enter the grid
-      GridWalk w;
-      const int mode = !has_ray ? GRID_MISS : (!rk.fast ? GRID_FALLBACK : (has_grid ? grid_begin(G, L.o, L.d, w) : GRID_MISS));
-      if (__any(mode == GRID_FALLBACK)) {  // numerically unsafe ray: the reference's full scan, real divisions
-        for (uint32_t idx = 0; idx < sc.n_spheres; ++idx) {
+      const bool fresh = has_ray && !walking;  // a new ray (camera or scattered) starts its hit_world here
+      if (fresh) { closest = T_MAX; best = -1; n_segments++; }
+      if (RT_WALK_TRIPS == 0 || __any(fresh)) {
+        // (1) spheres outside the grid: every fresh lane tests them; the record is wave-uniform -> SGPRs
+        for (uint32_t i = 0; i < n_large; ++i) {
+          const uint32_t idx = large_k[i];
           const F64PtrK gp = geom_k + (size_t)idx * 4u;
           SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
-          if (mode == GRID_FALLBACK) { const HitCB r = exact_hit_slow(L.o, L.d, rk.a, g, idx, closest, best); closest = r.closest; best = r.best; }
+          if (fresh && rk.fast) exact_hit_any_order_t<true>(L.o, L.d, rk, g, idx, closest, best);
         }
-        if (mode == GRID_FALLBACK) n_exact += sc.n_spheres;
+        if (fresh && rk.fast) n_exact += n_large;
+        RT_PROF(1);
+        // (2) enter the grid
+        GridWalk w;
+        const int mode = !fresh ? GRID_MISS : (!rk.fast ? GRID_FALLBACK : (has_grid ? grid_begin(G, L.o, L.d, w) : GRID_MISS));
+        if (__any(mode == GRID_FALLBACK)) {  // numerically unsafe ray: the reference's full scan, real divisions
+          for (uint32_t idx = 0; idx < sc.n_spheres; ++idx) {
+            const F64PtrK gp = geom_k + (size_t)idx * 4u;
+            SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
+            if (mode == GRID_FALLBACK) { const HitCB r = exact_hit_slow(L.o, L.d, rk.a, g, idx, closest, best); closest = r.closest; best = r.best; }
+          }
+          if (mode == GRID_FALLBACK) n_exact += sc.n_spheres;
+        }
+        if (mode == GRID_WALK) {
+          walking = true;
+          tm0 = w.tmax[0]; tm1 = w.tmax[1]; tm2 = w.tmax[2];
+          iv0 = w.dl[0] < 0 ? -w.delta[0] : w.delta[0]; iv1 = w.dl[1] < 0 ? -w.delta[1] : w.delta[1];
+          iv2 = w.dl[2] < 0 ? -w.delta[2] : w.delta[2];
+          lin = w.lin; t0 = w.t0; last = 0xFFFFFFFFu;
+          const uint2 e = cell_word[lin];
+          it = e.x & CELL_START_MASK; end = it + (e.x >> CELL_COUNT_SHIFT); pend = e.y;
+        }
       }
       if (has_grid) {
-        // (3) the walk.  Stepping and testing are decoupled: a lane steps through its cells (two per
-        // round, fetched together) and only QUEUES the spheres they list (up to four u16 indices);
-        // exact Sphere::hit tests run in rounds of their own, when at least RT_TEST_BATCH lanes have
-        // one waiting or nobody can step any more — so a test round is executed by many lanes at
-        // once instead of by whichever few happen to stand in an occupied cell.  The exact test does
-        // not depend on the cell it came from, and any order of tests gives the same (t, sphere);
-        // a lane stops stepping when its closest hit so far lies inside the current cell (the final
-        // closest can only be nearer), and is done when its queue is empty too.
-        bool stepping = mode == GRID_WALK;
-        float tm0 = w.tmax[0], tm1 = w.tmax[1], tm2 = w.tmax[2];
-        const float dt0 = w.delta[0], dt1 = w.delta[1], dt2 = w.delta[2];
-        const int dl0 = w.dl[0], dl1 = w.dl[1], dl2 = w.dl[2];
-        int lin = stepping ? w.lin : 0;
-        const double t0 = w.t0;
+        // (3) walk rounds: every walking lane moves on by up to two cells and/or tests one sphere.
+        // Per-lane walk state: tm = GridWalk.tmax, dt = GridWalk.delta, dl = GridWalk.dl, lin;
+        // the current cell's untested spheres are items [it, end), the next two of them also in `pend`.
+        const float dt0 = fabsf(iv0), dt1 = fabsf(iv1), dt2 = fabsf(iv2);
+        const int pxs = (int)G.n[0] + 2, pxys = pxs * ((int)G.n[1] + 2);
+        const int dl0 = iv0 < 0.0f ? -1 : 1, dl1 = iv1 < 0.0f ? -pxs : pxs, dl2 = iv2 < 0.0f ? -pxys : pxys;
         const int lin_max = (int)G.n_cells - 1;
-        uint32_t it = 0, end = 0;     // items of the current cell not queued yet (cells listing more than two)
-        unsigned long long qv = 0ull;  // the queue: up to four sphere indices, 16 bits each, oldest lowest
-        uint32_t qn = 0, last = 0xFFFFFFFFu;
-        auto enter = [&](uint2 e) {    // arrive in a cell (qn <= 2): queue its first two spheres, remember the rest
-          const uint32_t cnt = e.x >> CELL_COUNT_SHIFT, first = e.x & CELL_START_MASK;
-          if (cnt != 0u) { qv |= (unsigned long long)(e.y & 0xFFFFu) << (16u * qn); qn++; }
-          if (cnt > 1u) { qv |= (unsigned long long)(e.y >> 16) << (16u * qn); qn++; }
-          it = first + 2u; end = cnt > 2u ? first + cnt : first + 2u;
-        };
-        if (stepping) enter(cell_word[lin]);
+        uint32_t trips = 0;
         for (;;) {
-          const bool more = stepping && it < end;             // the current cell still has unqueued spheres
-          const bool can_more = more && qn < 4u;
-          const bool can_step = stepping && !more && qn <= 2u;
-          const bool has_test = qn != 0u;
-          const unsigned long long m_adv = __ballot(can_more || can_step), m_test = __ballot(has_test);
-          if (!m_adv && !m_test) break;
-          if (m_test && (!m_adv || (uint32_t)__builtin_popcountll(m_test) >= (uint32_t)RT_TEST_BATCH)) {
-            // ---- test round: one exact Sphere::hit per lane with a queued sphere
-            RT_PROF_COUNT(cnt_w_test);
-            if (has_test) {
-              const uint32_t idx = (uint32_t)qv & 0xFFFFu;
-              qv >>= 16; qn--;
-              if (idx != last) {  // a sphere spanning consecutive cells is not re-tested
-                last = idx; n_exact++;
-                exact_hit_any_order_t<true>(L.o, L.d, rk, tb.geom(idx), idx, closest, best);
-              }
-            }
-          } else {
-            // ---- advance round
+          if (!__any(walking)) break;
+          if (RT_WALK_TRIPS != 0 && trips++ >= (uint32_t)RT_WALK_TRIPS) break;  // shade what is ready, resume after
+          // (a) lanes whose cell is exhausted: finished, or on to the next non-empty cell.  The next
+          // TWO cells along the ray are computed and fetched together (one LDS round trip), the
+          // second one is used only if the first is empty.
+          const bool moving = walking && it == end;
+          if (__any(moving)) {
             RT_PROF_COUNT(cnt_w_step);
-            if (can_more) { qv |= (unsigned long long)cell_items[it] << (16u * qn); qn++; it++; }
-            if (can_step) {
+            if (moving) {
               float tc = (float)(closest - t0);
               tc = tc + fabsf(tc) * 2.384185791015625e-07f;  // grid_done
               const bool hit = best >= 0;
               const float tminA = rt_min3f(tm0, tm1, tm2);
-              if (hit && tc < tminA) stepping = false;
+              if (hit && tc < tminA) walking = false;
               else {
-                // grid_step x 2: the next TWO cells along the ray are computed and fetched together (one
-                // LDS round trip); the second one is used only if the first is empty
+                // grid_step x 2
                 const bool ax = tm0 == tminA, ay = !ax && tm1 == tminA, az = !ax && !ay;
                 const float a0 = tm0 + (ax ? dt0 : 0.0f), a1 = tm1 + (ay ? dt1 : 0.0f), a2 = tm2 + (az ? dt2 : 0.0f);
                 const int linA = lin + (ax ? dl0 : (ay ? dl1 : dl2));
@@ -487,15 +478,30 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
                 n_steps++;
                 const bool exitA = eA.x == CELL_EXIT, emptyA = (eA.x >> CELL_COUNT_SHIFT) == 0u;
                 const bool doneA = hit && tc < tminB;  // the closest hit lies inside cell A
-                if (exitA) stepping = false;
-                else if (!emptyA || doneA) {  // stay in A (or stop there)
+                if (exitA || !emptyA || doneA) {  // stay in A (or stop there)
                   tm0 = a0; tm1 = a1; tm2 = a2; lin = linA;
-                  if (emptyA) stepping = false; else enter(eA);
-                } else {                       // A is empty: on to B
+                  it = eA.x & CELL_START_MASK; end = it + (eA.x >> CELL_COUNT_SHIFT); pend = eA.y;
+                  if (exitA || emptyA) { walking = false; end = it; }
+                } else {                           // A is empty: on to B
                   n_steps++;
                   tm0 = b0; tm1 = b1; tm2 = b2; lin = linB;
-                  if (eB.x == CELL_EXIT) stepping = false; else enter(eB);
+                  it = eB.x & CELL_START_MASK; end = it + (eB.x >> CELL_COUNT_SHIFT); pend = eB.y;
+                  if (eB.x == CELL_EXIT) { walking = false; end = it; }
                 }
+              }
+            }
+          }
+          const bool testing = walking && it != end;
+          if (__any(testing)) {  // (b) one exact Sphere::hit per lane standing in a cell with spheres left
+            RT_PROF_COUNT(cnt_w_test);
+            if (testing) {
+              uint32_t idx = pend & 0xFFFFu;
+              if (idx == 0xFFFFu) idx = cell_items[it];  // third and later items of a cell: from the list
+              pend = (pend >> 16) | 0xFFFF0000u;
+              it++;
+              if (idx != last) {  // a sphere spanning consecutive cells is not re-tested
+                last = idx; n_exact++;
+                exact_hit_any_order_t<true>(L.o, L.d, rk, tb.geom(idx), idx, closest, best);
               }
             }
           }
@@ -504,9 +510,16 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       RT_PROF(3);
 
       // ---------------------------------------------------------- ray_color body
+      const bool ready = has_ray && !walking;
+      const int hit_idx = best;
+      const double hit_t = closest;
+      if (RT_WALK_TRIPS == 0) {  // no walk survives the round: nothing of its state stays live while shading
+        walking = false; tm0 = tm1 = tm2 = iv0 = iv1 = iv2 = 0.f; lin = 0; t0 = 0.0; closest = T_MAX; best = -1;
+        it = end = 0; pend = last = 0xFFFFFFFFu;
+      }
       bool finished = false;
-      if (has_ray) {
-        finished = lane_shade(fresh_args().sc, tb, L, best, closest);
+      if (ready) {
+        finished = lane_shade(fresh_args().sc, tb, L, hit_idx, hit_t);
         if (finished) {  // sample finished: add it to its pixel (raytracer.rs:203-205)
           unsigned long long* acc = tile_acc + my_k * acc_stride + cur_p * 3u;
           atomicAdd(&acc[0], sample_to_fixed(L.val[0]));
