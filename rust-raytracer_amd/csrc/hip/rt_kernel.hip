@@ -44,11 +44,6 @@ struct KArgs {
 #ifndef RT_BLOCK
 #define RT_BLOCK 1024
 #endif
-// walk rounds per path-loop iteration before the wave shades the lanes that are ready (0 = no cap:
-// every lane finishes its walk first)
-#ifndef RT_WALK_TRIPS
-#define RT_WALK_TRIPS 0
-#endif
 
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_ATTR
@@ -337,17 +332,6 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     RT_PROF_COUNT(cnt_items);
   };
 
-  // Per-lane hit_world state.  With RT_WALK_TRIPS > 0 a lane's grid walk may span several
-  // iterations of the path loop: the wave leaves the walk after that many rounds, shades the lanes
-  // whose closest hit is known, and the stragglers carry on next to the freshly scattered rays.
-  bool walking = false;
-  float tm0 = 0.f, tm1 = 0.f, tm2 = 0.f;  // GridWalk.tmax
-  float iv0 = 0.f, iv1 = 0.f, iv2 = 0.f;  // GridWalk.delta with the sign of GridWalk.dl
-  int lin = 0;
-  double t0 = 0.0, closest = T_MAX;
-  int best = -1;
-  uint32_t it = 0, end = 0, pend = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
-
   RT_PROF(5);
   uint32_t idle_spins = 0;
   for (;;) {
@@ -406,51 +390,47 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       const uint32_t n_large = G.n_large;
       const bool has_grid = G.n[0] != 0u;
       const RayK rk = ray_consts(L.d);
-      const bool fresh = has_ray && !walking;  // a new ray (camera or scattered) starts its hit_world here
-      if (fresh) { closest = T_MAX; best = -1; n_segments++; }
-      if (RT_WALK_TRIPS == 0 || __any(fresh)) {
-        // (1) spheres outside the grid: every fresh lane tests them; the record is wave-uniform -> SGPRs
-        for (uint32_t i = 0; i < n_large; ++i) {
-          const uint32_t idx = large_k[i];
+      double closest = T_MAX;
+      int best = -1;
+      if (has_ray) n_segments++;
+      // (1) spheres outside the grid: every lane tests them; the record is wave-uniform -> SGPRs
+      for (uint32_t i = 0; i < n_large; ++i) {
+        const uint32_t idx = large_k[i];
+        const F64PtrK gp = geom_k + (size_t)idx * 4u;
+        SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
+        if (has_ray && rk.fast) exact_hit_any_order_t<true>(L.o, L.d, rk, g, idx, closest, best);
+      }
+      if (has_ray && rk.fast) n_exact += n_large;
+      RT_PROF(1);
+      // (2) enter the grid
+      GridWalk w;
+      const int mode = !has_ray ? GRID_MISS : (!rk.fast ? GRID_FALLBACK : (has_grid ? grid_begin(G, L.o, L.d, w) : GRID_MISS));
+      if (__any(mode == GRID_FALLBACK)) {  // numerically unsafe ray: the reference's full scan, real divisions
+        for (uint32_t idx = 0; idx < sc.n_spheres; ++idx) {
           const F64PtrK gp = geom_k + (size_t)idx * 4u;
           SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
-          if (fresh && rk.fast) exact_hit_any_order_t<true>(L.o, L.d, rk, g, idx, closest, best);
+          if (mode == GRID_FALLBACK) { const HitCB r = exact_hit_slow(L.o, L.d, rk.a, g, idx, closest, best); closest = r.closest; best = r.best; }
         }
-        if (fresh && rk.fast) n_exact += n_large;
-        RT_PROF(1);
-        // (2) enter the grid
-        GridWalk w;
-        const int mode = !fresh ? GRID_MISS : (!rk.fast ? GRID_FALLBACK : (has_grid ? grid_begin(G, L.o, L.d, w) : GRID_MISS));
-        if (__any(mode == GRID_FALLBACK)) {  // numerically unsafe ray: the reference's full scan, real divisions
-          for (uint32_t idx = 0; idx < sc.n_spheres; ++idx) {
-            const F64PtrK gp = geom_k + (size_t)idx * 4u;
-            SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
-            if (mode == GRID_FALLBACK) { const HitCB r = exact_hit_slow(L.o, L.d, rk.a, g, idx, closest, best); closest = r.closest; best = r.best; }
-          }
-          if (mode == GRID_FALLBACK) n_exact += sc.n_spheres;
-        }
-        if (mode == GRID_WALK) {
-          walking = true;
-          tm0 = w.tmax[0]; tm1 = w.tmax[1]; tm2 = w.tmax[2];
-          iv0 = w.dl[0] < 0 ? -w.delta[0] : w.delta[0]; iv1 = w.dl[1] < 0 ? -w.delta[1] : w.delta[1];
-          iv2 = w.dl[2] < 0 ? -w.delta[2] : w.delta[2];
-          lin = w.lin; t0 = w.t0; last = 0xFFFFFFFFu;
-          const uint2 e = cell_word[lin];
-          it = e.x & CELL_START_MASK; end = it + (e.x >> CELL_COUNT_SHIFT); pend = e.y;
-        }
+        if (mode == GRID_FALLBACK) n_exact += sc.n_spheres;
       }
       if (has_grid) {
         // (3) walk rounds: every walking lane moves on by up to two cells and/or tests one sphere.
         // Per-lane walk state: tm = GridWalk.tmax, dt = GridWalk.delta, dl = GridWalk.dl, lin;
         // the current cell's untested spheres are items [it, end), the next two of them also in `pend`.
-        const float dt0 = fabsf(iv0), dt1 = fabsf(iv1), dt2 = fabsf(iv2);
-        const int pxs = (int)G.n[0] + 2, pxys = pxs * ((int)G.n[1] + 2);
-        const int dl0 = iv0 < 0.0f ? -1 : 1, dl1 = iv1 < 0.0f ? -pxs : pxs, dl2 = iv2 < 0.0f ? -pxys : pxys;
+        bool walking = mode == GRID_WALK;
+        float tm0 = w.tmax[0], tm1 = w.tmax[1], tm2 = w.tmax[2];
+        const float dt0 = w.delta[0], dt1 = w.delta[1], dt2 = w.delta[2];
+        const int dl0 = w.dl[0], dl1 = w.dl[1], dl2 = w.dl[2];
+        int lin = walking ? w.lin : 0;
+        const double t0 = w.t0;
         const int lin_max = (int)G.n_cells - 1;
-        uint32_t trips = 0;
+        uint32_t it = 0, end = 0, pend = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
+        if (walking) {
+          const uint2 e = cell_word[lin];
+          it = e.x & CELL_START_MASK; end = it + (e.x >> CELL_COUNT_SHIFT); pend = e.y;
+        }
         for (;;) {
           if (!__any(walking)) break;
-          if (RT_WALK_TRIPS != 0 && trips++ >= (uint32_t)RT_WALK_TRIPS) break;  // shade what is ready, resume after
           // (a) lanes whose cell is exhausted: finished, or on to the next non-empty cell.  The next
           // TWO cells along the ray are computed and fetched together (one LDS round trip), the
           // second one is used only if the first is empty.
@@ -510,16 +490,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       RT_PROF(3);
 
       // ---------------------------------------------------------- ray_color body
-      const bool ready = has_ray && !walking;
-      const int hit_idx = best;
-      const double hit_t = closest;
-      if (RT_WALK_TRIPS == 0) {  // no walk survives the round: nothing of its state stays live while shading
-        walking = false; tm0 = tm1 = tm2 = iv0 = iv1 = iv2 = 0.f; lin = 0; t0 = 0.0; closest = T_MAX; best = -1;
-        it = end = 0; pend = last = 0xFFFFFFFFu;
-      }
       bool finished = false;
-      if (ready) {
-        finished = lane_shade(fresh_args().sc, tb, L, hit_idx, hit_t);
+      if (has_ray) {
+        finished = lane_shade(fresh_args().sc, tb, L, best, closest);
         if (finished) {  // sample finished: add it to its pixel (raytracer.rs:203-205)
           unsigned long long* acc = tile_acc + my_k * acc_stride + cur_p * 3u;
           atomicAdd(&acc[0], sample_to_fixed(L.val[0]));

@@ -27,7 +27,6 @@ VARIANTS = {
     "b512": (W4 + ["-DRT_BLOCK=512"], {}, {}),
     "b256": (W4 + ["-DRT_BLOCK=256"], {}, {}),
     "waves3": (["-DRT_WAVES_PER_EU=3"], {}, {}),
-    "walk_trips12": (W4 + ["-DRT_WALK_TRIPS=12"], {}, {}),
     "tile8x8_chunk8": (W4, {"tile_log2": 3, "chunk_spp": 8}, {}),
     "tile8x8_unchunked": (W4, {"tile_log2": 3, "chunk_spp": 128}, {}),
     "tile2x2_chunk32": (W4, {"tile_log2": 1, "chunk_spp": 32}, {}),
