@@ -35,7 +35,8 @@ struct HostTables {
 constexpr size_t GRID_LDS_TABLE_BUDGET = 104u * 1024u;
 struct GridParams {
   double cells_per_sphere = 0.0;   // target cell count = this * gridded spheres; 0 = automatic (below)
-  double large_radius_ratio = 16;  // |r| > ratio * median |r|  ->  `large` list
+  double large_radius_ratio = 4;   // |r| > ratio * median |r|  ->  `large` list (the biggest `max_large_by_radius` of them)
+  uint32_t max_large_by_radius = 8;
   uint32_t large_cell_limit = 512; // a sphere covering more cells than this -> `large` list
   uint32_t min_spheres = 24;       // fewer spheres than this: no grid, test them all
 };
@@ -43,6 +44,7 @@ inline GridParams grid_params_from_env() {
   GridParams p;
   if (const char* e = std::getenv("RT_GRID_CELLS_PER_SPHERE")) p.cells_per_sphere = std::atof(e);
   if (const char* e = std::getenv("RT_GRID_MIN_SPHERES")) p.min_spheres = (uint32_t)std::atoi(e);
+  if (const char* e = std::getenv("RT_GRID_LARGE_RATIO")) p.large_radius_ratio = std::atof(e);
   if (const char* e = std::getenv("RT_GRID_LARGE_CELLS")) p.large_cell_limit = (uint32_t)std::atoi(e);
   return p;
 }
@@ -74,9 +76,20 @@ inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
   const double r_med = radii[radii.size() / 2];
   double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   uint32_t n_grid = 0;
+  // Spheres much bigger than the bulk (the ground, the three r = 1 spheres of the cover scene)
+  // are tested by every ray instead of being gridded: without them the grid hugs the bulk (one
+  // flat layer of cells around the small spheres), rays from above enter it right where they
+  // come down, and a walk is ~2 steps instead of ~10 (measured 21.1 -> 16.1 ms).  Each one costs a
+  // wave-uniform exact test per ray, so only the biggest few qualify.
+  {
+    std::vector<std::pair<double, uint32_t>> big;
+    for (uint32_t i = 0; i < n; ++i)
+      if (!is_large[i] && std::fabs(sc.spheres[i].radius) > gp.large_radius_ratio * r_med) big.push_back({std::fabs(sc.spheres[i].radius), i});
+    std::sort(big.begin(), big.end(), [](const std::pair<double, uint32_t>& a, const std::pair<double, uint32_t>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+    for (size_t k = 0; k < big.size() && k < gp.max_large_by_radius; ++k) is_large[big[k].second] = 1;
+  }
   for (uint32_t i = 0; i < n; ++i) {
     const RtSphere& s = sc.spheres[i];
-    if (!is_large[i] && std::fabs(s.radius) > gp.large_radius_ratio * r_med) is_large[i] = 1;
     if (is_large[i]) continue;
     n_grid++;
     for (int k = 0; k < 3; ++k) {
@@ -98,8 +111,16 @@ inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
     if (!(c >= 1.0)) c = 1.0;
     if (c > (double)GRID_MAX_AXIS) c = (double)GRID_MAX_AXIS;
     G.n[k] = (uint32_t)c;
-    G.gmin[k] = lo[k];
-    G.inv_cell[k] = (double)G.n[k] / ext[k];
+  }
+  // The walk leaves a cell at exit planes pulled back by `pull` cells, so next to the grid's OUTER
+  // faces a sliver of that width is never walked: keep every sphere at least 2*pull (the
+  // registration margin) + 1e-3 cells away from them.
+  const double pull_cells = 8.0 * grid_walk_eps(std::max(G.n[0], std::max(G.n[1], G.n[2])));
+  const double edge = 2.0 * pull_cells + 1e-3;
+  for (int k = 0; k < 3; ++k) {
+    const double w = ext[k] / ((double)G.n[k] - 2.0 * edge);  // cell width such that the spheres span [edge, n - edge] cells
+    G.gmin[k] = lo[k] - edge * w;
+    G.inv_cell[k] = 1.0 / w;
   }
   G.pull = (float)(8.0 * grid_walk_eps(std::max(G.n[0], std::max(G.n[1], G.n[2]))));
   const uint32_t n_inner = G.n[0] * G.n[1] * G.n[2];

@@ -5,6 +5,8 @@
 // product never loads this; librt_hip.so has no CPU fallback.
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -53,7 +55,12 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
               double r = exact_root(L.o, L.d, a, t.geom[i], T_MIN, c2);
               if (r >= 0.0) { c2 = r; b2 = (int)i; }
             }
-            if (b2 != best || (b2 >= 0 && c2 != closest)) cull_false_reject++;
+            if (b2 != best || (b2 >= 0 && c2 != closest)) {
+              cull_false_reject++;
+              if (std::getenv("RT_AUDIT_VERBOSE"))
+                std::fprintf(stderr, "AUDIT px %u,%u s %u k %u: o=(%.17g,%.17g,%.17g) d=(%.17g,%.17g,%.17g) grid best %d t %.17g | brute best %d t %.17g\n",
+                             x, y, L.s, L.k, L.o.x, L.o.y, L.o.z, L.d.x, L.d.y, L.d.z, best, closest, b2, c2);
+            }
           }
         } else
         for (uint32_t i = 0; i < sc.n_spheres; ++i) {

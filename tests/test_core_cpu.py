@@ -64,7 +64,8 @@ def test_grid_walk_matches_brute_force_per_segment(hostsim, load_scene, host):
     sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "scenes"))
     import procedural
     cases = [load_scene("cover", 150, 100, 4, 50), load_scene("test", 80, 60, 4, 8), load_scene("cover4k_tex", 64, 36, 2, 50),
-             host.Scene.loads(procedural.make_json(width=48, height=27, spp=2, half=50, seed=0))]
+             host.Scene.loads(procedural.make_json(width=48, height=27, spp=2, half=50, seed=0)),
+             host.Scene.loads(procedural.make_json(width=64, height=36, spp=2, half=50, seed=0))]  # (once caught a ray grazing the grid's top face)
     for sc in cases:
         _, _, st = hostsim.render(sc.ptr, None, 4)
         assert st["kernel_ms"] == 0.0, f"{st['kernel_ms']} segments where the grid walk disagrees with brute force"
@@ -200,12 +201,17 @@ def test_grid_walk_adversarial_rays(hostsim, abi):
     t_out = (C.c_double * 2)()
     n_rays = n_hits = 0
     worlds = [dict(n=200, spread=5.0, r_lo=0.05, r_hi=0.6, big=None), dict(n=600, spread=20.0, r_lo=0.1, r_hi=0.3, big=1000.0),
-              dict(n=80, spread=1.0, r_lo=0.2, r_hi=0.5, big=None), dict(n=300, spread=8.0, r_lo=0.01, r_hi=2.5, big=None)]
+              dict(n=80, spread=1.0, r_lo=0.2, r_hi=0.5, big=None), dict(n=300, spread=8.0, r_lo=0.01, r_hi=2.5, big=None),
+              dict(n=900, spread=25.0, r_lo=0.2, r_hi=0.2, big=1000.0)]
     for wi, wd in enumerate(worlds):
         sc, spheres = _random_scene(abi, rng, **wd)
         if wi == 1:  # flat world: every centre near y = 0
             for i in range(wd["n"]):
                 spheres[i].center[1] = float(rng.uniform(0.0, 0.3))
+        if wi == 4:  # exactly one layer of equal spheres on the ground: the grid is a single cell high
+            for i in range(wd["n"]):
+                spheres[i].center[1] = 0.2
+                spheres[i].radius = 0.2
         if wi == 3:  # far from the origin: large coordinates, small spheres
             for i in range(wd["n"]):
                 for k in range(3):
@@ -216,7 +222,7 @@ def test_grid_walk_adversarial_rays(hostsim, abi):
         for trial in range(1500):
             i = int(rng.integers(n))
             c = np.array(spheres[i].center[:]); r = abs(spheres[i].radius)
-            kind = trial % 6
+            kind = trial % 7
             nrm = rng.standard_normal(3); nrm /= np.linalg.norm(nrm)
             if kind == 0:    # leaves a sphere surface in a random direction (a bounced ray)
                 o = c + nrm * r; d = rng.standard_normal(3)
@@ -232,8 +238,16 @@ def test_grid_walk_adversarial_rays(hostsim, abi):
             elif kind == 4:  # one direction component denormal / zero, the others diagonal
                 d = rng.choice([-1.0, 1.0], 3); d[int(rng.integers(3))] = rng.choice([0.0, -0.0, 1e-310, -1e-300, 1e-40])
                 o = c - d * rng.uniform(0.5, 10.0) + rng.uniform(-1, 1, 3) * r
-            else:            # starts inside a sphere
+            elif kind == 5:  # starts inside a sphere
                 o = c + nrm * r * rng.uniform(0.0, 0.999); d = rng.standard_normal(3) * 10.0 ** rng.uniform(-3, 3)
+            else:            # hits sphere i at (almost) its extreme point along an axis — for the outermost
+                             # spheres that is on the grid's outer face — coming in nearly parallel to that face
+                ax = int(rng.integers(3)); sgn = rng.choice([-1.0, 1.0])
+                e = np.zeros(3); e[ax] = sgn
+                p = c + e * r * (1.0 - 10.0 ** rng.uniform(-12, -2))
+                tdir = rng.standard_normal(3); tdir[ax] = 0.0; tdir /= np.linalg.norm(tdir)
+                d = tdir + e * 10.0 ** rng.uniform(-4, -1.5)
+                o = p - d * rng.uniform(0.5, 12.0)
             assert hostsim.hostsim_hit_world(C.byref(sc), dvec(*o), dvec(*d), out, t_out) == 0
             n_rays += 1
             n_hits += out[1] >= 0
