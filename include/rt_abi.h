@@ -126,7 +126,7 @@ typedef struct RtStats {
   uint64_t wave_iters[4];
   /* shader-clock cycles summed over waves per kernel section; only filled by builds with
    * -DRT_PROFILE (tools/ab_bench.py "prof" arm): [0] sample refill, [1] `large` list,
-   * [2] grid_begin, [3] grid walk, [4] shading, [5] item fetch + pixel flush, [6] whole wave */
+   * [2] lane_shade, [3] grid entry + walk, [4] pixel sums + tile bookkeeping, [5] item fetch, [6] whole wave */
   uint64_t prof_cycles[8];
 } RtStats;
 

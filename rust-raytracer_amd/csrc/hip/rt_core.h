@@ -118,6 +118,7 @@ struct DevScene {
   const uint32_t* cell_word;   // [n_cells][2]: {first item | count << 20, first two item indices (u16 | u16 << 16, 0xFFFF = none)}
   const uint16_t* cell_items;  // [n_items] sphere indices, object order inside a cell
   const uint32_t* large;       // [n_large] sphere indices, object order
+  const SphereGeom* large_geom;  // [n_large] their geometry, packed in the same order (streamed by scalar loads)
   const MatCore* matc;         // [n_spheres]
 };
 
@@ -218,6 +219,9 @@ RT_HD V3 random_in_unit_sphere(const RngAddr& a, uint32_t node) {
     U4 w = rng(a, node, 1u + attempt);
     V3 p = v3(range_m1_1(w.x), range_m1_1(w.y), range_m1_1(w.z));
     if (length_squared(p) < 1.0) return p;
+#ifdef RT_EXPERIMENT_ONE_ATTEMPT  // timing experiment only (changes the image): how much does the rejection loop cost?
+    return muls(p, 0.5);
+#endif
   }
 }
 

@@ -38,6 +38,7 @@ struct RtHipScene {
   void* d_tex = nullptr; void* d_sky = nullptr;
   void* d_matc = nullptr; void* d_cell_word = nullptr; void* d_cell_items = nullptr; void* d_large = nullptr;
   void* d_all = nullptr;   // 0..n-1: the `large` list of the brute-force arm (variant 1)
+  void* d_large_geom = nullptr;
   rtc::GridDesc grid{};    // the product grid (variant 0)
   unsigned long long* d_counters = nullptr;  // 4 counters + the work-queue cursor
   int num_cus = 0;
@@ -80,7 +81,7 @@ extern "C" void rt_hip_scene_destroy(RtHipScene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (void* p : {s->d_geom, s->d_mat, s->d_cull, s->d_lights, s->d_tex, s->d_sky, (void*)s->d_counters, s->d_matc,
-                  s->d_cell_word, s->d_cell_items, s->d_large, s->d_all})
+                  s->d_cell_word, s->d_cell_items, s->d_large, s->d_all, s->d_large_geom})
     if (p) (void)hipFree(p);
   if (s->ev_start) (void)hipEventDestroy(s->ev_start);
   if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
@@ -131,6 +132,7 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   if ((rc = upload(&s->d_cell_word, t.cell_word)) != RT_OK) return bail(rc);
   if ((rc = upload(&s->d_cell_items, t.cell_items)) != RT_OK) return bail(rc);
   if ((rc = upload(&s->d_large, t.large)) != RT_OK) return bail(rc);
+  if ((rc = upload(&s->d_large_geom, t.large_geom)) != RT_OK) return bail(rc);
   {
     std::vector<uint32_t> all(scene->n_spheres);
     for (uint32_t i = 0; i < scene->n_spheres; ++i) all[i] = i;
@@ -155,6 +157,7 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   s->dev.tex = (const uint8_t*)s->d_tex; s->dev.sky = (const uint8_t*)s->d_sky;
   s->dev.matc = (const rtc::MatCore*)s->d_matc; s->dev.cell_word = (const uint32_t*)s->d_cell_word;
   s->dev.cell_items = (const uint16_t*)s->d_cell_items; s->dev.large = (const uint32_t*)s->d_large;
+  s->dev.large_geom = (const rtc::SphereGeom*)s->d_large_geom;
   *out = s;
   return RT_OK;
 }
@@ -238,6 +241,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
     std::memset(&ka.sc.grid, 0, sizeof ka.sc.grid);
     ka.sc.grid.n_large = s->host.n_spheres;
     ka.sc.large = (const uint32_t*)s->d_all;
+    ka.sc.large_geom = (const rtc::SphereGeom*)s->d_geom;
   }
   ka.out_rgb8 = (uint8_t*)d_rgb8; ka.out_linear = (float*)d_linear; ka.counters = s->d_counters;
   ka.queue = (uint32_t*)(s->d_counters + 24);

@@ -69,7 +69,7 @@ constexpr int TILE_MAX = 8;  // largest pixel tile = 8x8 (one pixel per lane); s
 typedef const double __attribute__((address_space(4))) * F64PtrK;
 typedef const uint32_t __attribute__((address_space(4))) * U32PtrK;
 
-// ---- dynamic LDS layout: [flags][tile slots: headers, then pixel sums][geom][matc][cell entries][cell items]
+// ---- dynamic LDS layout: [flags][tile slots: headers, then pixel sums][coop exchange][geom][matc][cell entries][cell items]
 // one resident set of workgroups per CU must fit 160 KB of LDS
 constexpr uint32_t LDS_TABLES_MAX_BYTES = BLOCK >= 1024 ? 156u * 1024u : (BLOCK >= 512 ? 78u * 1024u : 52u * 1024u);
 // Tile slots are shared by the workgroup.  A slot holds one open tile: header + the exact
@@ -95,12 +95,13 @@ __host__ __device__ inline uint32_t tile_slots(uint32_t tile_log2) {
   return t > T_SLOTS_MAX ? T_SLOTS_MAX : t;
 }
 struct LdsLayout {
-  uint32_t hdr_off, geom_off, matc_off, cell_off, item_off, total;
+  uint32_t hdr_off, coop_off, geom_off, matc_off, cell_off, item_off, total;
 };
 __host__ __device__ inline LdsLayout lds_layout(uint32_t n_spheres, uint32_t n_cells, uint32_t n_items, bool tables) {
   LdsLayout l;
   uint32_t o = LDS_FLAGS_BYTES;
   l.hdr_off = o; o += LDS_SLOT_BUDGET;  // [t_slots headers][t_slots x npx x 3 u64 sums], sized by tile_slots()
+  l.coop_off = o; o += WAVES * 64u * 16u;  // per wave: 64 x 16 B exchange slots of coop_random_in_unit_sphere
   l.geom_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(SphereGeom);
   l.matc_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(MatCore);
   l.cell_off = o; if (tables) o += n_cells * 8u;
@@ -118,6 +119,71 @@ __device__ __forceinline__ const KArgs& fresh_args() {
   KArgsK p = (KArgsK)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(p));
   return *(const KArgs*)p;
+}
+
+// random_in_unit_sphere (point3d.rs:31-38) for a whole wave.  Per lane the rejection loop takes
+// 1.9 attempts on average, but a wave runs max-over-lanes (~6) rounds of it: measured 18 % of the
+// frame.  Here every lane makes attempt 0 for itself; after that ALL 64 lanes (also those that
+// need no point) work for the lanes still failing: failing lane #r posts its RNG address in LDS
+// slot r, helper lane h makes attempt base + h / nf of failing lane #(h % nf), accepted helpers
+// post their three words, and each failing lane takes those of its lowest-numbered accepted
+// attempt.  Attempt a is Philox slot 1+a whoever computes it, so the result is bit-identical to
+// the sequential loop.  `xch`: this wave's 64 x uint4 exchange slots.
+#ifndef RT_COOP_RANDOM
+#define RT_COOP_RANDOM 1
+#endif
+__device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, const RngAddr& ra, uint32_t node, uint32_t lane, uint4* xch) {
+  auto point = [](uint32_t x, uint32_t y, uint32_t z) { return v3(range_m1_1(x), range_m1_1(y), range_m1_1(z)); };
+  uint32_t wx = 0, wy = 0, wz = 0;
+  bool pending = false;
+  if (need) {
+    const U4 w = rng(ra, node, 1u);
+    wx = w.x; wy = w.y; wz = w.z;
+    pending = !(length_squared(point(wx, wy, wz)) < 1.0);
+  }
+  uint32_t base = 1;  // next attempt of every lane still pending (wave-uniform)
+  for (;;) {
+    const unsigned long long F = __ballot(pending);
+    if (!F) break;
+    const uint32_t nf = (uint32_t)__builtin_popcountll(F);
+    uint32_t layers = 64u / nf;
+    if (layers > 4u) layers = 4u;
+    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(F >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)F, 0u));
+    if (pending) xch[r] = make_uint4(ra.pixel, ra.sample, node, 0u);
+    const uint32_t m = (65536u + nf - 1u) / nf;  // j = lane / nf for lane < 64 by multiplication
+    const uint32_t j = (lane * m) >> 16, q = lane - j * nf;
+    const bool helping = j < layers;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    bool acc = false;
+    uint32_t hx = 0, hy = 0, hz = 0;
+    if (helping) {
+      const uint4 a = xch[q];
+      RngAddr ha; ha.pixel = a.x; ha.sample = a.y; ha.k0 = ra.k0; ha.k1 = ra.k1;
+      const U4 hw = rng(ha, a.z, 1u + base + j);
+      hx = hw.x; hy = hw.y; hz = hw.z;
+      acc = length_squared(point(hx, hy, hz)) < 1.0;
+    }
+    const unsigned long long A = __ballot(acc);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every helper has read its slot: reuse them for the answers
+    if (acc) xch[lane] = make_uint4(hx, hy, hz, 0u);
+    // failing lane #r: its helpers are lanes r, r + nf, r + 2 nf, ...: the lowest layer that accepted
+    uint32_t from = 0;
+    bool found = false;
+    if (pending) {
+      const unsigned long long mine = A >> r;
+      for (uint32_t l = 0; l < 4u; ++l)
+        if (!found && l < layers && ((mine >> (l * nf)) & 1ull)) { found = true; from = r + l * nf; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (found) {
+      const uint4 g = xch[from];
+      wx = g.x; wy = g.y; wz = g.z;
+      pending = false;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    base += layers;
+  }
+  return point(wx, wy, wz);
 }
 
 struct LdsTables {  // per-lane gathers from the workgroup's LDS copies
@@ -142,6 +208,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   SlotHdr* const hdr = reinterpret_cast<SlotHdr*>(lds_raw + lay.hdr_off);
   const uint32_t T = ka.t_slots, acc_stride = 3u << (2u * ka.tile_log2);  // u64 words of pixel sums per slot
   unsigned long long* const tile_acc = reinterpret_cast<unsigned long long*>(lds_raw + lay.hdr_off + T * 32u);
+  uint4* const coop_xch = reinterpret_cast<uint4*>(lds_raw + lay.coop_off) + wave * 64u;
   for (uint32_t i = threadIdx.x; i < T; i += BLOCK) {
     SlotHdr h; h.tile_xy = 0; h.next = 0x80000000u; h.finished = 0; h.expected = 0; h.state = SLOT_FREE; h.pad[0] = h.pad[1] = h.pad[2] = 0;
     hdr[i] = h;
@@ -393,12 +460,20 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       double closest = T_MAX;
       int best = -1;
       if (has_ray) n_segments++;
-      // (1) spheres outside the grid: every lane tests them; the record is wave-uniform -> SGPRs
-      for (uint32_t i = 0; i < n_large; ++i) {
-        const uint32_t idx = large_k[i];
-        const F64PtrK gp = geom_k + (size_t)idx * 4u;
-        SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
-        if (has_ray && rk.fast) exact_hit_any_order_t<true>(L.o, L.d, rk, g, idx, closest, best);
+      // (1) spheres outside the grid: every lane tests them.  The records are wave-uniform, so they
+      // arrive by scalar loads as SGPR operands; the next record is fetched while this one is tested.
+      if (n_large != 0u) {
+        const F64PtrK lg = (F64PtrK)(uintptr_t)sc.large_geom;
+        SphereGeom g; g.cx = lg[0]; g.cy = lg[1]; g.cz = lg[2]; g.r = lg[3];
+        uint32_t idx = large_k[0];
+        for (uint32_t i = 0; i < n_large; ++i) {
+          const uint32_t nx = i + 1u < n_large ? i + 1u : i;  // (the last round re-reads its own record)
+          const F64PtrK np = lg + (size_t)nx * 4u;
+          SphereGeom gn; gn.cx = np[0]; gn.cy = np[1]; gn.cz = np[2]; gn.r = np[3];
+          const uint32_t idxn = large_k[nx];
+          if (has_ray && rk.fast) exact_hit_any_order_t<true>(L.o, L.d, rk, g, idx, closest, best);
+          g = gn; idx = idxn;
+        }
       }
       if (has_ray && rk.fast) n_exact += n_large;
       RT_PROF(1);
@@ -491,8 +566,16 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 
       // ---------------------------------------------------------- ray_color body
       bool finished = false;
+#if RT_COOP_RANDOM
+      // the unit-sphere point most hits need is drawn by the whole wave together
+      const bool need_rnd = has_ray && best >= 0 && material_draws_unit_sphere(tb.mat((uint32_t)(best >= 0 ? best : 0)).kind);
+      const V3 rnd = coop_random_in_unit_sphere(need_rnd, L.ra, L.node, lane, coop_xch);
+      if (has_ray) finished = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd);
+#else
+      if (has_ray) finished = lane_shade(fresh_args().sc, tb, L, best, closest);
+#endif
+      RT_PROF(2);
       if (has_ray) {
-        finished = lane_shade(fresh_args().sc, tb, L, best, closest);
         if (finished) {  // sample finished: add it to its pixel (raytracer.rs:203-205)
           unsigned long long* acc = tile_acc + my_k * acc_stride + cur_p * 3u;
           atomicAdd(&acc[0], sample_to_fixed(L.val[0]));

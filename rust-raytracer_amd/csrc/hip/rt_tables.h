@@ -27,12 +27,13 @@ struct HostTables {
   std::vector<uint32_t> cell_word;
   std::vector<uint16_t> cell_items;
   std::vector<uint32_t> large;
+  std::vector<SphereGeom> large_geom;
 };
 
 // Grid construction knobs (development tunables; the defaults are what ships).
 // Bytes the per-segment tables (geometry, material cores, cell entries, item lists) may take so
 // that the megakernel can keep them in LDS next to its tile slots (rt_kernel.hip: 160 KB per CU).
-constexpr size_t GRID_LDS_TABLE_BUDGET = 104u * 1024u;
+constexpr size_t GRID_LDS_TABLE_BUDGET = 88u * 1024u;
 struct GridParams {
   double cells_per_sphere = 0.0;   // target cell count = this * gridded spheres; 0 = automatic (below)
   double large_radius_ratio = 4;   // |r| > ratio * median |r|  ->  `large` list (the biggest `max_large_by_radius` of them)
@@ -261,8 +262,12 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
     cp.cx[1] = cp.cx[0]; cp.cy[1] = cp.cy[0]; cp.cz[1] = cp.cz[0]; cp.R[1] = -INFINITY;
   }
   if (!t.lights.empty()) t.simple_colour = false;
+  auto pack_large = [&]() {
+    t.large_geom.resize(t.large.size());
+    for (size_t i = 0; i < t.large.size(); ++i) t.large_geom[i] = t.geom[t.large[i]];
+  };
   GridParams gp = grid_params_from_env();
-  if (gp.cells_per_sphere > 0.0) build_grid(sc, t, gp);
+  if (gp.cells_per_sphere > 0.0) { build_grid(sc, t, gp); pack_large(); }
   else {
     // Finer cells mean fewer exact tests per ray but more steps; measured on the headline scene
     // (profiles/) 8 cells per sphere is best as long as the tables stay LDS-resident; scenes whose
@@ -274,6 +279,7 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
       const size_t bytes = (size_t)n * (sizeof(SphereGeom) + sizeof(MatCore)) + (size_t)t.grid.n_cells * 8u + (size_t)t.grid.n_items * 2u;
       if (bytes <= GRID_LDS_TABLE_BUDGET || t.grid.n[0] == 0u) break;
     }
+    pack_large();
   }
   return "";
 }

@@ -119,7 +119,7 @@ extern "C" int hostsim_render(const RtScene* scene, const RtRowTiles* tiles, uin
     if (scene->textures[i].nbytes) std::memcpy(&blob[t.tex_off[i]], scene->textures[i].rgb8, scene->textures[i].nbytes);
   ds.geom = t.geom.data(); ds.mat = t.mat.data(); ds.cull = t.cull.data(); ds.lights = t.lights.data();
   ds.tex = blob.data(); ds.sky = scene->sky_rgb8;
-  ds.matc = t.matc.data(); ds.cell_word = t.cell_word.data(); ds.cell_items = t.cell_items.data(); ds.large = t.large.data();
+  ds.matc = t.matc.data(); ds.cell_word = t.cell_word.data(); ds.cell_items = t.cell_items.data(); ds.large = t.large.data(); ds.large_geom = t.large_geom.data();
   if (t.lights.empty()) render_rows<false>(*scene, t, ds, tiles, rgb8, linear, stats, use_cull);
   else render_rows<true>(*scene, t, ds, tiles, rgb8, linear, stats, use_cull);
   return RT_OK;
@@ -156,7 +156,7 @@ extern "C" int hostsim_hit_world(const RtScene* scene, const double o[3], const 
   DevScene ds;
   fill_dev_scene(*scene, t, ds);
   ds.geom = t.geom.data(); ds.matc = t.matc.data(); ds.cell_word = t.cell_word.data(); ds.cell_items = t.cell_items.data();
-  ds.large = t.large.data();
+  ds.large = t.large.data(); ds.large_geom = t.large_geom.data();
   const GlobalTables tb{ds.geom, ds.matc};
   V3 oo = v3(o[0], o[1], o[2]), dd = v3(d[0], d[1], d[2]);
   const double a = length_squared(dd);

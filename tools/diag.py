@@ -73,7 +73,7 @@ def main():
                items=wi[3])
     pc = st["prof_cycles"]
     if pc[6]:
-        names = ["refill", "large", "grid_begin", "walk", "shade", "item", "total"]
+        names = ["refill", "large", "lane_shade", "walk", "accumulate", "item", "total"]
         out["prof_share"] = {n: round(pc[i] / pc[6], 4) for i, n in enumerate(names[:6])}
         out["wave_busy_frac_at_2.4GHz"] = round(pc[6] / (4096 * st["kernel_ms"] * 2.4e6), 3)
         out["prof_cycles_per_wave_iter"] = {n: round(pc[i] / max(1, wi[0]), 1) for i, n in enumerate(names)}
