@@ -163,7 +163,8 @@ def main():
             "kernel_ms": round(kernel_ms, 4), "segments_per_sample": round(segments / samples, 4),
             "exact_tests_per_segment": round(exact / max(1.0, segments), 3),
             "grid_steps_per_segment": round(steps / max(1.0, segments), 3),
-            "roofline": {"bound": "valu", "note": "vector-ALU bound: neither hbm nor mfma binds this path (DESIGN.md §6)",
+            "roofline": {"bound": "valu", "note": "vector-ALU bound: neither hbm nor mfma binds this path (DESIGN.md §6); `achieved` counts the "
+                         "reference's brute-force tests (SURVEY §8d), of which the grid walk executes ~1 % (`executed`), so frac may exceed 1",
                          "achieved": round(tflops, 3),
                          "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / PEAK_FP32_VALU_TFLOPS, 4),
                          "traffic": traffic, "kernel": "rt_megakernel", "flop_per_test": FLOP_PER_TEST,

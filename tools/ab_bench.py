@@ -27,11 +27,13 @@ VARIANTS = {
     "b512": (W4 + ["-DRT_BLOCK=512"], {}, {}),
     "b256": (W4 + ["-DRT_BLOCK=256"], {}, {}),
     "waves3": (["-DRT_WAVES_PER_EU=3"], {}, {}),
+    "no_coop_random": (W4 + ["-DRT_COOP_RANDOM=0"], {}, {}),
+    "tall_spheres_in_grid": (W4, {}, {"RT_GRID_LARGE_RATIO": "16"}),
     "tile8x8_chunk8": (W4, {"tile_log2": 3, "chunk_spp": 8}, {}),
     "tile8x8_unchunked": (W4, {"tile_log2": 3, "chunk_spp": 128}, {}),
     "tile2x2_chunk32": (W4, {"tile_log2": 1, "chunk_spp": 32}, {}),
     "cells_per_sphere2": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "2"}),
-    "cells_per_sphere4": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "4"}),
+    "cells_per_sphere8": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "8"}),
     "brute_force_on_gpu": (W4, {"variant": 1}, {}),
     "round1_scan_kernel": (W4, {"variant": 2}, {}),
 }
