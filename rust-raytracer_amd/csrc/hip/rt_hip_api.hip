@@ -42,6 +42,7 @@ struct RtHipScene {
   rtc::GridDesc grid{};    // the product grid (variant 0)
   unsigned long long* d_counters = nullptr;  // 4 counters + the work-queue cursor
   int num_cus = 0;
+  int cfg_key = -1; size_t cfg_lds = 0; int cfg_per_cu = 0;  // cached launch configuration
   int chunk_spp = 0;       // 0 = automatic
   int tile_log2 = -1;      // -1 = automatic; else tiles of 2^k x 2^k pixels, k = 0..3
 
@@ -201,10 +202,16 @@ int launch_scan(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb8, void* d_li
 template <bool HL, bool SIMPLE, bool LDS>
 int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka, size_t lds_bytes, uint32_t n_items, hipStream_t stream) {
   auto kern = rtk::rt_megakernel<HL, SIMPLE, LDS>;
-  if (lds_bytes > 48 * 1024) RT_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  int per_cu = 0;
-  RT_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, rtk::BLOCK, lds_bytes));
-  if (per_cu < 1) return fail(RT_ERR_HIP, "megakernel does not fit on a CU");
+  // the launch configuration of this scene's kernel is worked out once (it costs two runtime calls a frame otherwise)
+  const int key = (HL ? 4 : 0) | (SIMPLE ? 2 : 0) | (LDS ? 1 : 0);
+  if (s->cfg_key != key || s->cfg_lds != lds_bytes) {
+    if (lds_bytes > 48 * 1024) RT_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int per_cu_q = 0;
+    RT_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_q, kern, rtk::BLOCK, lds_bytes));
+    if (per_cu_q < 1) return fail(RT_ERR_HIP, "megakernel does not fit on a CU");
+    s->cfg_key = key; s->cfg_lds = lds_bytes; s->cfg_per_cu = per_cu_q;
+  }
+  const int per_cu = s->cfg_per_cu;
   // persistent: exactly the resident set, never more workgroups than there are wave-sized items
   uint32_t wgs = (uint32_t)per_cu * (uint32_t)s->num_cus;
   const uint32_t need = (n_items + rtk::WAVES - 1) / rtk::WAVES;

@@ -298,3 +298,18 @@ def test_div_by_recip_is_exact(hostsim):
     want = x / b
     bad = out != want
     assert not bad.any(), (int(bad.sum()), x[bad][:3], b[bad][:3])
+
+
+def test_grid_policy_on_the_reference_scenes(hostsim, load_scene):
+    """build_grid's choices on the scenes that matter: the cover scene keeps its ground and its
+    three r = 1 spheres out of the grid (a flat one-cell-high grid around the 480 small spheres),
+    the 7-sphere test scene is not gridded at all, every sphere is either gridded or `large`."""
+    info = (C.c_uint32 * 6)()
+    sc = load_scene("cover", 64, 48, 1, 50)
+    assert hostsim.hostsim_grid_info(sc.ptr, info) == 0
+    nx, ny, nz, n_large, n_cells, n_items = info[:]
+    assert n_large == 4 and ny == 1 and 24 <= nx <= 96 and 24 <= nz <= 96
+    assert n_cells == (nx + 2) * (ny + 2) * (nz + 2) and n_items >= 480
+    sc = load_scene("test", 64, 48, 1, 8)
+    assert hostsim.hostsim_grid_info(sc.ptr, info) == 0
+    assert info[0] == 0 and info[3] == sc.c.n_spheres == 7
