@@ -167,6 +167,8 @@ const char* rt_host_last_error(void);
 /* camera.rs:45-77 Camera::new: out = origin[3], lower_left[3], horizontal[3], vertical[3], focal_length */
 void rt_camera_derive(const double look_from[3], const double look_at[3], const double vup[3],
                       double vfov_deg, double aspect, double out[13]);
+/* camera description of a loaded scene file (camera.rs:29-36): look_from[3], look_at[3], vup[3], vfov, aspect */
+void rt_scene_camera(const RtSceneFile*, double out[11]);
 /* raytracer.rs:220-229 find_lights: writes indices of Light spheres in object order */
 uint32_t rt_find_lights(const RtSphere* spheres, uint32_t n, uint32_t* out_idx, uint32_t cap);
 /* materials.rs:213-219 load_texture_image: baseline JPEG -> RGB8 (malloc'd, free with rt_free) */
@@ -202,6 +204,12 @@ int rt_hip_wait(RtHipScene*, RtStats* stats);
  * 2^k x 2^k (k = 0..3, -1 = automatic); "samples_per_pixel",
  * "max_depth", "seed" override the scene's values. */
 int rt_hip_set_option(RtHipScene*, const char* key, int64_t value);
+/* Animation (the reference's `anim/frame_%03d.png` workflow, README.md:43-57, main.rs:17): move the
+ * camera of a resident scene — the four vectors of camera.rs:52-63 — without touching its tables,
+ * and render whole frames of it into a host buffer (internal device framebuffer, blocking). */
+int rt_hip_set_camera(RtHipScene*, const double origin[3], const double lower_left[3], const double horizontal[3],
+                      const double vertical[3]);
+int rt_hip_render_to_host(RtHipScene*, uint8_t* out_rgb8, RtStats* stats);
 /* Convenience = the drop-in for render()'s parallel loop: host buffers in, host RGB8 out.
  * Blocking; uploads, renders the whole frame on device 0, downloads. */
 int rt_render_rgb8(const RtScene* scene, uint8_t* out_rgb8, RtStats* stats);

@@ -50,7 +50,7 @@ def build_cli(force=False):
     src = _srcs("csrc/host/main.cpp")
     deps = src + [os.path.join(HERE, "librt_host.so"), os.path.join(HERE, "librt_hip.so")]
     if os.path.exists(src[0]) and (force or _newer(out, deps)):
-        _run(["g++", *CXXFLAGS, *src, "-o", out, "-L" + HERE, "-lrt_host", "-lrt_hip", "-Wl,-rpath,$ORIGIN"])
+        _run(["g++", *CXXFLAGS, *src, "-o", out, "-L" + HERE, "-lrt_host", "-lrt_hip", "-lpthread", "-Wl,-rpath,$ORIGIN"])
     return out
 
 

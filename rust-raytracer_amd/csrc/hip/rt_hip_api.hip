@@ -43,6 +43,7 @@ struct RtHipScene {
   unsigned long long* d_counters = nullptr;  // 4 counters + the work-queue cursor
   int num_cus = 0;
   int cfg_key = -1; size_t cfg_lds = 0; int cfg_per_cu = 0;  // cached launch configuration
+  void* d_frame = nullptr; size_t frame_bytes = 0;           // framebuffer of rt_hip_render_to_host
   int chunk_spp = 0;       // 0 = automatic
   int tile_log2 = -1;      // -1 = automatic; else tiles of 2^k x 2^k pixels, k = 0..3
 
@@ -82,7 +83,7 @@ extern "C" void rt_hip_scene_destroy(RtHipScene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (void* p : {s->d_geom, s->d_mat, s->d_cull, s->d_lights, s->d_tex, s->d_sky, (void*)s->d_counters, s->d_matc,
-                  s->d_cell_word, s->d_cell_items, s->d_large, s->d_all, s->d_large_geom})
+                  s->d_cell_word, s->d_cell_items, s->d_large, s->d_all, s->d_large_geom, s->d_frame})
     if (p) (void)hipFree(p);
   if (s->ev_start) (void)hipEventDestroy(s->ev_start);
   if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
@@ -321,6 +322,40 @@ extern "C" int rt_hip_wait(RtHipScene* s, RtStats* stats) {
     for (int k = 0; k < 8; ++k) stats->prof_cycles[k] = c[8 + k];
     stats->kernel_ms = ms;
     stats->frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s->t_launch).count();
+  }
+  return RT_OK;
+}
+
+extern "C" int rt_hip_set_camera(RtHipScene* s, const double origin[3], const double lower_left[3], const double horizontal[3],
+                                 const double vertical[3]) {
+  if (!s || !origin || !lower_left || !horizontal || !vertical) return fail(RT_ERR_INVALID, "null argument");
+  for (int i = 0; i < 3; ++i) {
+    s->host.cam_origin[i] = s->dev.cam_origin[i] = origin[i];
+    s->host.cam_lower_left[i] = s->dev.cam_ll[i] = lower_left[i];
+    s->host.cam_horizontal[i] = s->dev.cam_h[i] = horizontal[i];
+    s->host.cam_vertical[i] = s->dev.cam_v[i] = vertical[i];
+  }
+  return RT_OK;
+}
+
+extern "C" int rt_hip_render_to_host(RtHipScene* s, uint8_t* out_rgb8, RtStats* stats) {
+  if (!s || !out_rgb8) return fail(RT_ERR_INVALID, "null argument");
+  auto t0 = std::chrono::steady_clock::now();
+  RT_HIP_TRY(hipSetDevice(s->device));
+  const size_t bytes = (size_t)s->host.width * s->host.height * 3;
+  if (bytes > s->frame_bytes) {
+    if (s->d_frame) { (void)hipFree(s->d_frame); s->d_frame = nullptr; s->frame_bytes = 0; }
+    RT_HIP_TRY(hipMalloc(&s->d_frame, bytes));
+    s->frame_bytes = bytes;
+  }
+  int rc = rt_hip_render(s, nullptr, s->d_frame, nullptr, nullptr);
+  RtStats st;
+  if (rc == RT_OK) rc = rt_hip_wait(s, &st);
+  if (rc != RT_OK) return rc;
+  RT_HIP_TRY(hipMemcpy(out_rgb8, s->d_frame, bytes, hipMemcpyDeviceToHost));
+  if (stats) {
+    *stats = st;
+    stats->frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
   return RT_OK;
 }

@@ -329,6 +329,11 @@ extern "C" int rt_scene_load_file(const char* json_path, RtSceneFile** out) {
 extern "C" const RtScene* rt_scene_get(const RtSceneFile* sf) { return sf ? &sf->scene : nullptr; }
 extern "C" RtScene* rt_scene_get_mut(RtSceneFile* sf) { return sf ? &sf->scene : nullptr; }
 extern "C" void rt_scene_free(RtSceneFile* sf) { delete sf; }
+extern "C" void rt_scene_camera(const RtSceneFile* sf, double out[11]) {
+  if (!sf || !out) return;
+  for (int i = 0; i < 3; ++i) { out[i] = sf->look_from[i]; out[3 + i] = sf->look_at[i]; out[6 + i] = sf->vup[i]; }
+  out[9] = sf->vfov; out[10] = sf->aspect;
+}
 extern "C" void rt_free(void* p) { std::free(p); }
 
 extern "C" int rt_scene_to_json(const RtSceneFile* sf, char* buf, size_t cap, size_t* needed) {

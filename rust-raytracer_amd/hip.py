@@ -34,6 +34,8 @@ def lib():
         L.rt_hip_wait.argtypes = [C.c_void_p, C.POINTER(abi.RtStats)]
         L.rt_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.rt_render_rgb8.argtypes = [C.POINTER(abi.RtScene), C.c_void_p, C.POINTER(abi.RtStats)]
+        L.rt_hip_set_camera.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 4
+        L.rt_hip_render_to_host.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.RtStats)]
         L.rt_hip_math_probe.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_void_p]
         _LIB = L
     return _LIB
@@ -66,6 +68,19 @@ class HipScene:
         """enqueue the megakernel; d_* are raw device pointers (ints), stream a hipStream_t"""
         _check(lib().rt_hip_render(self._h, C.byref(tiles) if tiles is not None else None,
                                    C.c_void_p(d_rgb8), C.c_void_p(d_linear or None), C.c_void_p(stream or None)))
+
+    def set_camera(self, origin, lower_left, horizontal, vertical):
+        """move the camera of the resident scene (the four vectors of camera.rs:52-63)"""
+        v = [(C.c_double * 3)(*x) for x in (origin, lower_left, horizontal, vertical)]
+        _check(lib().rt_hip_set_camera(self._h, *v))
+
+    def render_to_host(self):
+        """whole frame into a numpy [h,w,3] array (blocking) + stats"""
+        import numpy as np
+        out = np.zeros((self.height, self.width, 3), np.uint8)
+        st = abi.RtStats()
+        _check(lib().rt_hip_render_to_host(self._h, out.ctypes.data, C.byref(st)))
+        return out, st.as_dict()
 
     def wait(self):
         st = abi.RtStats()

@@ -15,6 +15,7 @@
 using namespace rtc;
 
 namespace {
+unsigned long long* g_hist = nullptr;  // [0..63] steps per segment, [64..127] exact tests per segment (diagnostics)
 template <bool HL>
 void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, const RtRowTiles* tiles, uint8_t* rgb8,
                  float* linear, RtStats* stats, int use_cull_flags) {
@@ -49,6 +50,13 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
           hit_world_grid(ds, tb, L.o, L.d, closest, best, L.n_exact, n_steps);
           steps += n_steps;
           if (L.k == 0 && !L.in_light) { cam_steps += n_steps; cam_segs++; cam_exact += L.n_exact - e0; }
+          if (g_hist) {
+            uint32_t a = n_steps > 63u ? 63u : n_steps, b = (L.n_exact - e0) > 63u ? 63u : (L.n_exact - e0);
+#pragma omp atomic
+            g_hist[a]++;
+#pragma omp atomic
+            g_hist[64 + b]++;
+          }
           if (use_cull == 4) {  // audit: the reference's brute force must agree on (t, sphere), bit for bit
             double c2 = T_MAX; int b2 = -1;
             for (uint32_t i = 0; i < sc.n_spheres; ++i) {
@@ -176,3 +184,5 @@ extern "C" void hostsim_div_by_recip(const double* x, const double* b, double* o
 #pragma omp parallel for
   for (int64_t i = 0; i < (int64_t)n; ++i) out[i] = div_by_recip(x[i], b[i], 1.0 / b[i]);
 }
+
+extern "C" void hostsim_set_histogram(unsigned long long* h) { g_hist = h; }
