@@ -219,9 +219,6 @@ RT_HD V3 random_in_unit_sphere(const RngAddr& a, uint32_t node) {
     U4 w = rng(a, node, 1u + attempt);
     V3 p = v3(range_m1_1(w.x), range_m1_1(w.y), range_m1_1(w.z));
     if (length_squared(p) < 1.0) return p;
-#ifdef RT_EXPERIMENT_ONE_ATTEMPT  // timing experiment only (changes the image): how much does the rejection loop cost?
-    return muls(p, 0.5);
-#endif
   }
 }
 
