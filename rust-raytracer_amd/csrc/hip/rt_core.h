@@ -66,6 +66,22 @@ struct MatCore {
   double fuzz_or_ior;
   double inv_r;  // RN(1/radius) for div_by_recip (sphere.rs:60), or 0: divide the slow way
 };
+// Glass ignores its albedo (attenuation is white, materials.rs:178): those bytes carry 1/ior, the
+// quotient materials.rs:181 computes at every front-face hit, divided once on the host instead.
+RT_HD void matcore_set_inv_ior(MatCore& m, double inv_ior) {
+  unsigned long long b;
+  __builtin_memcpy(&b, &inv_ior, 8);
+  uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
+  __builtin_memcpy(&m.albedo[0], &lo, 4); __builtin_memcpy(&m.albedo[1], &hi, 4);
+}
+RT_HD double matcore_inv_ior(const MatCore& m) {
+  uint32_t lo, hi;
+  __builtin_memcpy(&lo, &m.albedo[0], 4); __builtin_memcpy(&hi, &m.albedo[1], 4);
+  const unsigned long long b = ((unsigned long long)hi << 32) | lo;
+  double d;
+  __builtin_memcpy(&d, &b, 8);
+  return d;
+}
 
 // Uniform grid over the scene's ordinary spheres (rt_tables.h builds it).  Oversized spheres
 // (the r = 1000 ground of cover_scene.json) are kept out of it in the `large` list, which
@@ -639,10 +655,11 @@ RT_HD V3 unit_vector_fast(V3 a) {
 RT_HD bool material_draws_unit_sphere(uint32_t kind) {
   return kind == RT_MAT_LAMBERTIAN || kind == RT_MAT_TEXTURE || kind == RT_MAT_METAL;
 }
-// rnd_pre: the random_in_unit_sphere(ra, node) point if the caller already drew it, or null
+// rnd_pre / glass_u_pre: the random_in_unit_sphere(ra, node) point and the Glass reflectance draw
+// (slot 0, .x.y) if the caller already drew them, or null
 RT_HD int scatter(const DevScene& sc, const RngAddr& ra, uint32_t node, V3 in_dir, const Surface& h,
                   const SphereGeom& g, const MatCore& m, uint32_t idx, V3& out_dir, float att[3], uint32_t& tex_oob,
-                  const V3* rnd_pre = nullptr) {
+                  const V3* rnd_pre = nullptr, const double* glass_u_pre = nullptr) {
   // Lambertian, Texture and Metal all draw random_in_unit_sphere (Metal even with fuzz = 0,
   // materials.rs:120); one shared rejection loop instead of one per material branch.
   V3 rnd = v3(0.0, 0.0, 0.0);
@@ -672,14 +689,16 @@ RT_HD int scatter(const DevScene& sc, const RngAddr& ra, uint32_t node, V3 in_di
     }
     case RT_MAT_GLASS: {  // :176-199
       att[0] = att[1] = att[2] = 1.0f;
-      double refraction_ratio = h.front_face ? 1.0 / m.fuzz_or_ior : m.fuzz_or_ior;
+      double refraction_ratio = h.front_face ? matcore_inv_ior(m) : m.fuzz_or_ior;  // :180-184 (1/ior precomputed)
       V3 unit_direction = unit_vector_fast(in_dir);
       double cos_theta = fmin(dot(neg(unit_direction), h.normal), 1.0);
       double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
       bool do_reflect = refraction_ratio * sin_theta > 1.0;
-      if (!do_reflect) {
-        U4 w = rng(ra, node, 0);
-        do_reflect = reflectance(cos_theta, refraction_ratio) > u01_53(w.x, w.y);
+      if (!do_reflect) {  // (the draw is addressed by counter: taking it early or not at all changes nothing else)
+        double u;
+        if (glass_u_pre) u = *glass_u_pre;
+        else { U4 w = rng(ra, node, 0); u = u01_53(w.x, w.y); }
+        do_reflect = reflectance(cos_theta, refraction_ratio) > u;
       }
       out_dir = do_reflect ? reflect(unit_direction, h.normal) : refract(unit_direction, h.normal, refraction_ratio);
       return SCATTER_RAY;
@@ -814,7 +833,8 @@ RT_HD bool lane_light_return(const DevScene& sc, const Tables& tb, Lane<true>& L
 // Consume the closest hit (idx < 0: miss) of the lane's current ray.  Returns true when the
 // lane's current sample finished (its radiance is in L.val; the caller starts the next one).
 template <class LaneT, class Tables>
-RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, double t, const V3* rnd_pre = nullptr) {
+RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, double t, const V3* rnd_pre = nullptr,
+                      const double* glass_u_pre = nullptr) {
   constexpr bool HL = LaneT::kLights;
   if (idx < 0) {  // raytracer.rs:133-163
     Rgb sky = sky_color(sc, L.d, L.n_tex_oob);
@@ -829,7 +849,7 @@ RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, d
   Surface h = surface_at(L.o, L.d, t, g, m.inv_r);
   V3 out_dir = v3(0, 0, 0);
   float att[3];
-  int st = scatter(sc, L.ra, L.node, L.d, h, g, m, (uint32_t)idx, out_dir, att, L.n_tex_oob, rnd_pre);
+  int st = scatter(sc, L.ra, L.node, L.d, h, g, m, (uint32_t)idx, out_dir, att, L.n_tex_oob, rnd_pre, glass_u_pre);
   const float zero3[3] = {0.0f, 0.0f, 0.0f};
 
   if constexpr (HL) {

@@ -132,15 +132,20 @@ __device__ __forceinline__ const KArgs& fresh_args() {
 #ifndef RT_COOP_RANDOM
 #define RT_COOP_RANDOM 1
 #endif
-__device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, const RngAddr& ra, uint32_t node, uint32_t lane, uint4* xch) {
+// Lanes whose hit is Glass need no point but one Philox call of their own (slot 0, the reflectance
+// draw of materials.rs:189): they make it in round 0, in the instruction stream the others use for
+// attempt 0, and get its first two words back in `glass_u`.
+__device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, bool glass, const RngAddr& ra, uint32_t node, uint32_t lane, uint4* xch,
+                                                         double& glass_u) {
   auto point = [](uint32_t x, uint32_t y, uint32_t z) { return v3(range_m1_1(x), range_m1_1(y), range_m1_1(z)); };
   uint32_t wx = 0, wy = 0, wz = 0;
   bool pending = false;
-  if (need) {
-    const U4 w = rng(ra, node, 1u);
+  if (need || glass) {
+    const U4 w = rng(ra, node, glass ? 0u : 1u);
     wx = w.x; wy = w.y; wz = w.z;
-    pending = !(length_squared(point(wx, wy, wz)) < 1.0);
+    pending = need && !(length_squared(point(wx, wy, wz)) < 1.0);
   }
+  glass_u = u01_53(wx, wy);
   uint32_t base = 1;  // next attempt of every lane still pending (wave-uniform)
   for (;;) {
     const unsigned long long F = __ballot(pending);
@@ -568,9 +573,11 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       bool finished = false;
 #if RT_COOP_RANDOM
       // the unit-sphere point most hits need is drawn by the whole wave together
-      const bool need_rnd = has_ray && best >= 0 && material_draws_unit_sphere(tb.mat((uint32_t)(best >= 0 ? best : 0)).kind);
-      const V3 rnd = coop_random_in_unit_sphere(need_rnd, L.ra, L.node, lane, coop_xch);
-      if (has_ray) finished = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd);
+      const uint32_t hit_kind = has_ray && best >= 0 ? tb.mat((uint32_t)best).kind : 0xFFFFFFFFu;
+      double glass_u;
+      const V3 rnd = coop_random_in_unit_sphere(hit_kind != 0xFFFFFFFFu && material_draws_unit_sphere(hit_kind), hit_kind == RT_MAT_GLASS,
+                                                L.ra, L.node, lane, coop_xch, glass_u);
+      if (has_ray) finished = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u);
 #else
       if (has_ray) finished = lane_shade(fresh_args().sc, tb, L, best, closest);
 #endif

@@ -249,6 +249,7 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
     mc.albedo[0] = m.albedo[0]; mc.albedo[1] = m.albedo[1]; mc.albedo[2] = m.albedo[2];
     mc.kind = m.kind; mc.fuzz_or_ior = m.fuzz_or_ior;
     mc.inv_r = recip_safe(s.radius) ? 1.0 / s.radius : 0.0;
+    if (s.kind == RT_MAT_GLASS) matcore_set_inv_ior(mc, 1.0 / s.fuzz_or_ior);  // materials.rs:181: 1.0 / ir, divided once here
     t.matc[i] = mc;
     if (s.kind == RT_MAT_LIGHT) t.lights.push_back(i);
     if (s.kind == RT_MAT_LAMBERTIAN || s.kind == RT_MAT_METAL)
@@ -272,13 +273,17 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
     // Finer cells mean fewer exact tests per ray but more steps; measured on the headline scene
     // (profiles/) 8 cells per sphere is best as long as the tables stay LDS-resident; scenes whose
     // tables cannot fit anyway (thousands of spheres) walk a 4-cells-per-sphere grid out of L2.
-    const double tries[] = {8.0, 6.0, 4.0};
-    for (double c : tries) {
-      gp.cells_per_sphere = c;
-      build_grid(sc, t, gp);
-      const size_t bytes = (size_t)n * (sizeof(SphereGeom) + sizeof(MatCore)) + (size_t)t.grid.n_cells * 8u + (size_t)t.grid.n_items * 2u;
-      if (bytes <= GRID_LDS_TABLE_BUDGET || t.grid.n[0] == 0u) break;
-    }
+    const size_t fixed = (size_t)n * (sizeof(SphereGeom) + sizeof(MatCore));
+    auto table_bytes = [&]() { return fixed + (size_t)t.grid.n_cells * 8u + (size_t)t.grid.n_items * 2u; };
+    const double tries[] = {8.0, 6.0, 4.0, 3.0, 2.0};
+    bool fits = false;
+    if (fixed < GRID_LDS_TABLE_BUDGET)
+      for (double c : tries) {
+        gp.cells_per_sphere = c;
+        build_grid(sc, t, gp);
+        if (table_bytes() <= GRID_LDS_TABLE_BUDGET || t.grid.n[0] == 0u) { fits = true; break; }
+      }
+    if (!fits) { gp.cells_per_sphere = 4.0; build_grid(sc, t, gp); }
     pack_large();
   }
   return "";
