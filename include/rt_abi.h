@@ -127,7 +127,7 @@ typedef struct RtStats {
   /* shader-clock cycles summed over waves per kernel section; only filled by builds with
    * -DRT_PROFILE (tools/ab_bench.py "prof" arm): [0] sample refill, [1] `large` list,
    * [2] lane_shade, [3] grid entry + walk, [4] pixel sums + tile bookkeeping, [5] item fetch, [6] whole wave */
-  uint64_t prof_cycles[8];
+  uint64_t prof_cycles[12]; /* ... [7] longest wave, [8] shortest wave, [10] waves launched */
 } RtStats;
 
 /* rows this call renders (its packed RGB8 output is rows*width*3 bytes) */
@@ -198,6 +198,12 @@ int rt_hip_render(RtHipScene*, const RtRowTiles* tiles, void* d_rgb8, void* d_li
 /* Block until the last rt_hip_render on this scene finished; fill counters and the HIP-event
  * duration of its kernel (events are recorded on the stream the kernel was launched on). */
 int rt_hip_wait(RtHipScene*, RtStats* stats);
+/* Diagnostics (builds with -DRT_PROFILE only; other builds return stale memory): the 32 raw
+ * launch counters, then {start, end, time the
+ * wave found the tile queue empty, iterations after that | lanes x iterations << 32} of every
+ * wave of the last launch, on the chip-wide 100 MHz clock.  Returns the number of waves copied
+ * (out holds 32 + 4 x max_waves uint64) or a negative RtStatus. */
+int rt_hip_debug_timeline(RtHipScene*, uint64_t* out, uint32_t max_waves);
 /* Tunables / A-B arms.  Keys: "variant" 0 = grid walk (default), 1 = the
  * reference's brute force (exact test on every sphere), 2 = round-1 f32 cull-scan kernel;
  * "chunk_spp" samples of a pixel per work item (0 = automatic); "tile_log2" pixel tiles of

@@ -38,7 +38,7 @@ class RtRowTiles(C.Structure):
 class RtStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("exact_tests", C.c_uint64), ("tex_oob", C.c_uint64),
-                ("kernel_ms", C.c_double), ("frame_ms", C.c_double), ("grid_steps", C.c_uint64), ("wave_iters", C.c_uint64 * 4), ("prof_cycles", C.c_uint64 * 8)]
+                ("kernel_ms", C.c_double), ("frame_ms", C.c_double), ("grid_steps", C.c_uint64), ("wave_iters", C.c_uint64 * 4), ("prof_cycles", C.c_uint64 * 12)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if k in ("wave_iters", "prof_cycles") else getattr(self, k)) for k, _ in self._fields_}

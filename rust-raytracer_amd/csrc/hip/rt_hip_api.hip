@@ -29,6 +29,8 @@ int fail(int code, const std::string& m) { g_err = m; return code; }
 
 }  // namespace
 
+constexpr uint32_t RT_TIMELINE_WAVES = 8192;  // profile builds: {start, end} wall clock per wave behind the counters
+
 struct RtHipScene {
   int device = 0;
   RtScene host{};          // scalar fields only (pointers are not kept)
@@ -51,6 +53,7 @@ struct RtHipScene {
   hipStream_t last_stream = nullptr;
   bool launched = false;
   uint32_t last_rows = 0;
+  uint64_t last_waves = 0;
   int variant = 0;
   int pool = 1;            // 1: pooled samples + exact fixed-point pixel sums; 0: reference f32 order
   std::chrono::steady_clock::time_point t_launch;
@@ -151,7 +154,7 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
     if (scene->sky_mode == RT_SKY_TEXTURE) sky.assign(scene->sky_rgb8, scene->sky_rgb8 + scene->sky_w * scene->sky_h * 3);
     if ((rc = upload(&s->d_sky, sky)) != RT_OK) return bail(rc);
   }
-  if (hipMalloc((void**)&s->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess ||
+  if (hipMalloc((void**)&s->d_counters, (32 + 4 * RT_TIMELINE_WAVES) * sizeof(unsigned long long)) != hipSuccess ||
       hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess)
     return bail(fail(RT_ERR_HIP, "hipMalloc/hipEventCreate failed"));
   s->dev.geom = (const rtc::SphereGeom*)s->d_geom; s->dev.mat = (const rtc::SphereMat*)s->d_mat;
@@ -217,6 +220,7 @@ int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka, size_t lds_bytes, uint32_
   uint32_t wgs = (uint32_t)per_cu * (uint32_t)s->num_cus;
   const uint32_t need = (n_items + rtk::WAVES - 1) / rtk::WAVES;
   if (wgs > need) wgs = need;
+  s->last_waves = (uint64_t)wgs * rtk::WAVES;
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(rtk::BLOCK), lds_bytes, stream, ka);
   return RT_OK;
 }
@@ -302,13 +306,22 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   return RT_OK;
 }
 
+extern "C" int rt_hip_debug_timeline(RtHipScene* s, uint64_t* out, uint32_t max_waves) {
+  if (!s || !out) return fail(RT_ERR_INVALID, "null argument");
+  RT_HIP_TRY(hipSetDevice(s->device));
+  RT_HIP_TRY(hipStreamSynchronize(s->last_stream));
+  const uint32_t n = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(s->last_waves, max_waves), RT_TIMELINE_WAVES);
+  RT_HIP_TRY(hipMemcpy(out, s->d_counters, (32 + (size_t)n * 4) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return (int)n;
+}
+
 extern "C" int rt_hip_wait(RtHipScene* s, RtStats* stats) {
   if (!s) return fail(RT_ERR_INVALID, "null argument");
   RT_HIP_TRY(hipSetDevice(s->device));
   RT_HIP_TRY(hipStreamSynchronize(s->last_stream));
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
-    unsigned long long c[16] = {0};  // segments, exact tests, tex_oob, grid steps, 4 x wave trip counts, 8 x section cycles
+    unsigned long long c[20] = {0};  // segments, exact tests, tex_oob, grid steps, 4 x wave trip counts, 8 x section cycles, profile clocks
     RT_HIP_TRY(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
     float ms = 0.f;
     if (s->launched) RT_HIP_TRY(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
@@ -320,6 +333,11 @@ extern "C" int rt_hip_wait(RtHipScene* s, RtStats* stats) {
     stats->grid_steps = c[3];
     for (int k = 0; k < 4; ++k) stats->wave_iters[k] = c[4 + k];
     for (int k = 0; k < 8; ++k) stats->prof_cycles[k] = c[8 + k];
+    if (c[14] && s->last_waves) {  // profile builds: longest / shortest wave, waves launched
+      stats->prof_cycles[7] = c[15];
+      stats->prof_cycles[8] = ~c[17];
+      stats->prof_cycles[10] = s->last_waves;
+    }
     stats->kernel_ms = ms;
     stats->frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s->t_launch).count();
   }

@@ -52,8 +52,8 @@ struct KArgs {
 #endif
 
 #ifdef RT_PROFILE
-#define RT_PROF_DECL unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_last = __builtin_readcyclecounter(); const unsigned long long prof_begin = prof_last;
-#define RT_PROF(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof_t[k] += now_ - prof_last; prof_last = now_; } while (0)
+#define RT_PROF_DECL unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_last = __builtin_readcyclecounter(); const unsigned long long prof_begin = prof_last; const unsigned long long prof_wall0 = wall_clock64(); unsigned long long prof_wall_qdone = 0; uint32_t prof_tail_iters = 0, prof_tail_lanes = 0; bool prof_in_tail = false; unsigned long long prof_tail_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RT_PROF(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof_t[k] += now_ - prof_last; if (prof_in_tail) prof_tail_t[k] += now_ - prof_last; prof_last = now_; } while (0)
 #define RT_PROF_COUNT(c) do { (c)++; } while (0)
 #else
 #define RT_PROF_COUNT(c) do { } while (0)
@@ -71,7 +71,11 @@ typedef const uint32_t __attribute__((address_space(4))) * U32PtrK;
 
 // ---- dynamic LDS layout: [flags][tile slots: headers, then pixel sums][coop exchange][geom][matc][cell entries][cell items]
 // one resident set of workgroups per CU must fit 160 KB of LDS
+#ifdef RT_LDS_TABLES_MAX
+constexpr uint32_t LDS_TABLES_MAX_BYTES = RT_LDS_TABLES_MAX;  // (occupancy experiments)
+#else
 constexpr uint32_t LDS_TABLES_MAX_BYTES = BLOCK >= 1024 ? 156u * 1024u : (BLOCK >= 512 ? 78u * 1024u : 52u * 1024u);
+#endif
 // Tile slots are shared by the workgroup.  A slot holds one open tile: header + the exact
 // fixed-point sums of its pixels.  It is freed when ALL samples of the tile have been added —
 // counted per tile, whichever waves traced them — so a long path only keeps its own tile's
@@ -86,7 +90,7 @@ struct SlotHdr {
 };
 static_assert(sizeof(SlotHdr) == 32, "slot header is 32 B");
 enum { SLOT_FREE = 0, SLOT_OPEN = 1, SLOT_OPENING = 2 };
-constexpr uint32_t LDS_FLAGS_BYTES = 32u;                    // {queue_empty, hint} + pad
+constexpr uint32_t LDS_FLAGS_BYTES = 32u + 32u * 8u;          // {queue_empty, hint, waves retired} + pad, then the workgroup's 32 launch counters
 constexpr uint32_t LDS_SLOT_BUDGET = WAVES * 3u * 1024u;     // 48 KB at 16 waves (3 KB per wave)
 constexpr uint32_t T_SLOTS_MAX = 512u;
 __host__ __device__ inline uint32_t tile_slots(uint32_t tile_log2) {
@@ -207,6 +211,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   const DevScene& sc = ka.sc;
   const GridDesc& G = sc.grid;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  RT_PROF_DECL
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const LdsLayout lay = lds_layout(sc.n_spheres, G.n_cells, G.n_items, LDS_TABLES);
   uint32_t* const wg_flags = reinterpret_cast<uint32_t*>(lds_raw);  // [0] the frame's tile queue is empty, [1] slot opened last
@@ -218,7 +223,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     SlotHdr h; h.tile_xy = 0; h.next = 0x80000000u; h.finished = 0; h.expected = 0; h.state = SLOT_FREE; h.pad[0] = h.pad[1] = h.pad[2] = 0;
     hdr[i] = h;
   }
-  if (threadIdx.x == 0) { wg_flags[0] = 0u; wg_flags[1] = 0u; }
+  if (threadIdx.x == 0) { wg_flags[0] = 0u; wg_flags[1] = 0u; wg_flags[2] = 0u; }
+  unsigned long long* const wg_counters = reinterpret_cast<unsigned long long*>(lds_raw + 32);
+  if (threadIdx.x < 32u) wg_counters[threadIdx.x] = 0ull;
   if constexpr (!LDS_TABLES) __syncthreads();
 
   if constexpr (LDS_TABLES) {  // stage the tables once per (persistent) workgroup
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   uint32_t n_segments = 0, n_exact = 0, n_steps = 0;  // per-lane counters (one exec-masked add each)
   uint32_t cnt_w_iter = 0, cnt_w_step = 0, cnt_w_test = 0, cnt_items = 0;  // wave trip counts (RT_PROFILE builds)
 
-  RT_PROF_DECL
+  RT_PROF(5);  // staging of the tables into LDS (+ item bookkeeping later)
   // ---- work distribution, two levels.
   // Global: a queue of pixel TILES (2^k x 2^k pixels, all their samples).  Workgroup: an open tile
   // lives in one of T shared LDS slots (header + exact fixed-point pixel sums); its samples are
@@ -436,7 +443,14 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         if (q_done) break;
         uint32_t k = 0, chunk = 0;
         const int got = acquire(k, chunk);
-        if (got < 0) { q_done = true; break; }
+        if (got < 0) {
+          q_done = true;
+#ifdef RT_PROFILE
+          prof_wall_qdone = wall_clock64();
+          prof_in_tail = true;
+#endif
+          break;
+        }
         if (got == 0) break;  // every tile slot is busy: these lanes wait
         open_item(k, chunk);
       }
@@ -451,6 +465,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     }
 
     idle_spins = 0;
+#ifdef RT_PROFILE
+    if (q_done) { prof_tail_iters++; prof_tail_lanes += (uint32_t)__builtin_popcountll(__ballot(has_ray)); }
+#endif
     RT_PROF_COUNT(cnt_w_iter);
     RT_PROF(0);
     {
@@ -615,20 +632,38 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     c0 += __shfl_down(c0, off); c1 += __shfl_down(c1, off); c2 += __shfl_down(c2, off); c3 += __shfl_down(c3, off);
   }
   if (lane == 0) {
-    const KArgs& ka = fresh_args();
-    atomicAdd(&ka.counters[0], c0);
-    atomicAdd(&ka.counters[1], c1);
-    if (c2) atomicAdd(&ka.counters[2], c2);
-    atomicAdd(&ka.counters[3], c3);
-    atomicAdd(&ka.counters[4], (unsigned long long)cnt_w_iter);
-    atomicAdd(&ka.counters[5], (unsigned long long)cnt_w_step);
-    atomicAdd(&ka.counters[6], (unsigned long long)cnt_w_test);
-    atomicAdd(&ka.counters[7], (unsigned long long)cnt_items);
+    // workgroup totals in LDS; the wave that retires last sends them on (one global atomic per
+    // counter and workgroup, not per wave: 4096 waves hitting the same few words at the end of
+    // the frame queue up at the memory side)
+    auto wg_add = [&](int k, unsigned long long v) { __hip_atomic_fetch_add(&wg_counters[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto wg_max = [&](int k, unsigned long long v) { __hip_atomic_fetch_max(&wg_counters[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    wg_add(0, c0); wg_add(1, c1); wg_add(2, c2); wg_add(3, c3);
+    wg_add(4, cnt_w_iter); wg_add(5, cnt_w_step); wg_add(6, cnt_w_test); wg_add(7, cnt_items);
 #ifdef RT_PROFILE
     RT_PROF(5);
     prof_t[6] = prof_last - prof_begin;
-    for (int k = 0; k < 7; ++k) atomicAdd(&ka.counters[8 + k], prof_t[k]);
+    for (int k = 0; k < 7; ++k) wg_add(8 + k, prof_t[k]);
+    for (int k = 0; k < 5; ++k) wg_add(19 + k, prof_tail_t[k]);   // sections of the iterations after the queue ran dry
+    wg_max(15, prof_last - prof_begin);     // longest / shortest wave (clock bases differ between XCDs)
+    wg_max(17, ~(prof_last - prof_begin));  // (max of the complement = min; the counters start at 0)
+    {  // timeline on the chip-wide 100 MHz clock, behind the 32 counters
+      const KArgs& ka = fresh_args();
+      const uint32_t wid = blockIdx.x * WAVES + wave;
+      ka.counters[32 + 4 * wid] = prof_wall0;
+      ka.counters[32 + 4 * wid + 1] = wall_clock64();
+      ka.counters[32 + 4 * wid + 2] = prof_wall_qdone;
+      ka.counters[32 + 4 * wid + 3] = (unsigned long long)prof_tail_iters | ((unsigned long long)prof_tail_lanes << 32);
+    }
 #endif
+    const uint32_t retired = __hip_atomic_fetch_add(&wg_flags[2], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (retired == WAVES - 1u) {
+      const KArgs& ka = fresh_args();
+      for (int k = 0; k < 24; ++k) {
+        const unsigned long long v = __hip_atomic_load(&wg_counters[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k == 15 || k == 17) { if (v) atomicMax(&ka.counters[k], v); }
+        else if (v) atomicAdd(&ka.counters[k], v);
+      }
+    }
   }
 }
 

@@ -32,6 +32,7 @@ def lib():
         L.rt_hip_scene_destroy.restype = None
         L.rt_hip_render.argtypes = [C.c_void_p, C.POINTER(abi.RtRowTiles), C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_hip_wait.argtypes = [C.c_void_p, C.POINTER(abi.RtStats)]
+        L.rt_hip_debug_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.rt_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.rt_render_rgb8.argtypes = [C.POINTER(abi.RtScene), C.c_void_p, C.POINTER(abi.RtStats)]
         L.rt_hip_set_camera.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 4
@@ -86,6 +87,15 @@ class HipScene:
         st = abi.RtStats()
         _check(lib().rt_hip_wait(self._h, C.byref(st)))
         return st.as_dict()
+
+    def debug_timeline(self, max_waves=8192):
+        """{start, end, queue-empty time, tail iterations | lane-iterations << 32} of every wave of the last launch, 100 MHz ticks (RT_PROFILE builds of the library only)."""
+        import numpy as np
+        buf = np.zeros(32 + 4 * max_waves, np.uint64)
+        n = lib().rt_hip_debug_timeline(self._h, buf.ctypes.data, max_waves)
+        if n < 0:
+            _check(n)
+        return buf[32:32 + 4 * n].reshape(n, 4), buf[:32]
 
     def close(self):
         if self._h:

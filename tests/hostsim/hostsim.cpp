@@ -15,7 +15,7 @@
 using namespace rtc;
 
 namespace {
-unsigned long long* g_hist = nullptr;  // [0..63] steps per segment, [64..127] exact tests per segment (diagnostics)
+unsigned long long* g_hist = nullptr;  // [0..63] steps per segment, [64..127] exact tests per segment, [128..] path lengths (diagnostics; 512 entries)
 template <bool HL>
 void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, const RtRowTiles* tiles, uint8_t* rgb8,
                  float* linear, RtStats* stats, int use_cull_flags) {
@@ -33,11 +33,13 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
       unsigned long long facc[3] = {0ull, 0ull, 0ull};  // accum 1: exact fixed point (pooled-sample kernels)
       L.ra.pixel = y * sc.width + x; L.ra.k0 = ds.seed_lo; L.ra.k1 = ds.seed_hi;
       bool need_new = true;
+      uint32_t cur_depth = 0; int first_kind = -1;
       for (;;) {
         if (need_new) {
           if (L.s >= sc.samples_per_pixel || sc.max_depth == 0) break;
           lane_begin_sample(ds, L, x, y);
           need_new = false;
+          cur_depth = 0; first_kind = -1;
         }
         // ---- trace: f32 cull + exact confirm, object order
         const double a = length_squared(L.d);
@@ -85,7 +87,18 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
           double r = exact_root(L.o, L.d, a, t.geom[i], T_MIN, closest);
           if (r >= 0.0) { closest = r; best = (int)i; }
         }
+        if (cur_depth == 0 && best >= 0) first_kind = (int)tb.mat((uint32_t)best).kind;
+        cur_depth++;
         need_new = lane_shade(ds, tb, L, best, closest);
+        if (need_new && g_hist) {  // [128..191] path length, [192 + 64 * kind ..] path length by the first hit's material
+          uint32_t dd = cur_depth > 63u ? 63u : cur_depth;
+#pragma omp atomic
+          g_hist[128 + dd]++;
+          if (first_kind >= 0 && first_kind < 5) {
+#pragma omp atomic
+            g_hist[192 + 64 * first_kind + dd]++;
+          }
+        }
         if (need_new) {
           for (int k = 0; k < 3; ++k) { acc[k] += L.val[k]; facc[k] += sample_to_fixed(L.val[k]); }
           L.s += 1;

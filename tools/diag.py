@@ -11,6 +11,22 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 
+def tail_stats(tl, t0):
+    """What the waves do after the tile queue ran dry (RT_PROFILE timeline)."""
+    import numpy as np
+    qd = (tl[:, 2] - t0).astype(np.float64) / 100.0
+    e = (tl[:, 1] - t0).astype(np.float64) / 100.0
+    it = (tl[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.float64)
+    ln = (tl[:, 3] >> np.uint64(32)).astype(np.float64)
+    ok = it > 0
+    q = [0, 10, 50, 90, 100]
+    return {"queue_empty_seen_pct": dict(zip(q, np.percentile(qd, q).round(1).tolist())),
+            "tail_iters_pct": dict(zip(q, np.percentile(it, q).round(1).tolist())),
+            "us_per_tail_iter": round(float(((e - qd)[ok]).sum() / it[ok].sum()), 2),
+            "us_per_tail_iter_longest10": round(float(np.sort((e - qd))[-10:].sum() / it[np.argsort(e - qd)[-10:]].sum()), 2),
+            "mean_lanes_in_tail_iter": round(float(ln.sum() / max(1.0, it.sum())), 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scene", default="scenes/cfg2_cover_1200x800_spp128.json")
@@ -51,12 +67,14 @@ def main():
         parts = [int(v) for v in a.shard.split(",")]
         r, w = parts[0], parts[1]
         tiles = pkg.abi.RtRowTiles(parts[2] if len(parts) > 2 else 8, r, w)
-    best = None
+    best, timeline = None, None
     for _ in range(a.reps):
         gs.render(rgb.data_ptr(), 0, tiles, torch.cuda.current_stream().cuda_stream)
         st = gs.wait()
         if best is None or st["kernel_ms"] < best["kernel_ms"]:
             best = st
+            if st["prof_cycles"][6]:
+                timeline, raw_counters = gs.debug_timeline()
     st = best
     wi = st["wave_iters"]
     out = dict(scene=os.path.basename(a.scene), opts=a.opt, kernel_ms=round(st["kernel_ms"], 3),
@@ -75,7 +93,24 @@ def main():
     if pc[6]:
         names = ["refill", "large", "lane_shade", "walk", "accumulate", "item", "total"]
         out["prof_share"] = {n: round(pc[i] / pc[6], 4) for i, n in enumerate(names[:6])}
-        out["wave_busy_frac_at_2.4GHz"] = round(pc[6] / (4096 * st["kernel_ms"] * 2.4e6), 3)
+        if pc[7]:
+            out["wave_us_at_2.4GHz"] = {"longest": round(pc[7] / 2400.0, 1), "shortest": round(pc[8] / 2400.0, 1),
+                                        "mean": round(pc[6] / max(1, pc[10]) / 2400.0, 1), "waves": pc[10]}
+        if timeline is not None and len(timeline):
+            import numpy as np
+            t0 = timeline[:, 0].min()
+            b = (timeline[:, 0] - t0).astype(np.float64) / 100.0   # us
+            e = (timeline[:, 1] - t0).astype(np.float64) / 100.0
+            q = [0, 1, 10, 50, 90, 99, 100]
+            out["timeline_us"] = {"start_pct": dict(zip(q, np.percentile(b, q).round(1).tolist())),
+                                  "end_pct": dict(zip(q, np.percentile(e, q).round(1).tolist())),
+                                  "idle_frac_after_end": round(float((e.max() - e).sum() / (len(e) * e.max())), 4),
+                                  "tail": tail_stats(timeline, t0),
+                                  "tail_section_share": dict(zip(["refill", "large", "lane_shade", "walk", "accumulate"],
+                                                                 (raw_counters[19:24] / max(1.0, float(raw_counters[19:24].sum()))).round(3).tolist())),
+                                  "tail_cycles_per_iter": round(float(raw_counters[19:24].sum()) / max(1.0, float((timeline[:, 3] & np.uint64(0xFFFFFFFF)).sum())), 1),
+                                  "end_by_xcd_mean": [round(float(e.reshape(-1, 16)[x::8].mean()), 1) for x in range(8)]}
+        out["wave_busy_frac_at_2.4GHz"] = round(pc[6] / (max(1, pc[10]) * st["kernel_ms"] * 2.4e6), 3)
         out["prof_cycles_per_wave_iter"] = {n: round(pc[i] / max(1, wi[0]), 1) for i, n in enumerate(names)}
     print(json.dumps(out))
 
