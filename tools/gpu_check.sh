@@ -1,6 +1,7 @@
 #!/bin/bash
-# One GPU-box session: smoke, GPU parity tests, bench line, rocprofv3 kernel stats, PMC passes (+ optional A/B).
-# Usage (from the build container):  gpurun --timeout 900 -- 'bash tools/gpu_check.sh [ab] [pmc]'
+# One GPU-box session: smoke, GPU parity tests, bench line, rocprofv3 kernel stats, PMC passes (+ optional A/B,
+# + optional full-size runs of every BASELINE config and the one-rank-at-a-time shard emulation).
+# Usage (from the build container):  gpurun --timeout 900 -- 'bash tools/gpu_check.sh [ab] [pmc] [configs]'
 # Every step runs under `timeout` and nothing reads stdin: a stuck step must not eat GPU budget.
 set -u
 exec </dev/null
@@ -27,6 +28,25 @@ if [[ " $* " == *" pmc "* ]]; then
   ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$REPO/$OUT/pmc_sq2" -o bench -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ) > $OUT/pmc_sq2.log 2>&1; stamp pmc_sq2 $?
   python tools/pmc_summary.py $OUT > $OUT/pmc_summary.json 2>$OUT/pmc_summary.err; stamp pmc_summary $?
   cat $OUT/pmc_summary.json
+fi
+if [[ " $* " == *" configs "* ]]; then
+  {
+    echo "# full-size runs of every BASELINE config, current kernel"
+    for S in scenes/cfg1_test_800x600_spp16.json scenes/cfg3_cover_4k_textured.json scenes/cfg4_cover_4k_textured_spp512.json; do
+      timeout 120 python tools/diag.py --scene $S --reps 2 2>/dev/null | tail -1
+    done
+    timeout 200 python tools/diag.py --procedural 50 --spp 2048 --reps 1 2>/dev/null | tail -1
+    echo "# one rank's shard of the headline frame at a time (2-scanline interleave): G = 2, 4, 8"
+    for SH in 0,2,2 1,2,2 0,4,2 3,4,2 0,8,2 3,8,2 7,8,2; do
+      echo -n "shard $SH "; timeout 60 python tools/diag.py --shard $SH --reps 10 2>/dev/null | tail -1 | cut -c 50-140
+    done
+    if [ -f build/ab/librt_hip_prof.so ]; then
+      echo "# RT_PROFILE build: section shares, wave timeline (full frame, then rank 3 of 8)"
+      timeout 60 python tools/diag.py --lib build/ab/librt_hip_prof.so --reps 5 2>/dev/null | tail -1
+      timeout 60 python tools/diag.py --lib build/ab/librt_hip_prof.so --shard 3,8,2 --reps 5 2>/dev/null | tail -1
+    fi
+  } > $OUT/all_configs.log 2>&1; stamp configs $?
+  cut -c1-160 $OUT/all_configs.log
 fi
 # the bench line last: if profiles/hbm_traffic.json was just refreshed by the caller it is picked up next time
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT/prof" -o bench -- python "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline ) > $OUT/rocprof.log 2>&1
