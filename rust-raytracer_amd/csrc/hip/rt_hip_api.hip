@@ -157,6 +157,8 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   if (hipMalloc((void**)&s->d_counters, (32 + 4 * RT_TIMELINE_WAVES) * sizeof(unsigned long long)) != hipSuccess ||
       hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess)
     return bail(fail(RT_ERR_HIP, "hipMalloc/hipEventCreate failed"));
+  if (hipMemset(s->d_counters, 0, (32 + 4 * RT_TIMELINE_WAVES) * sizeof(unsigned long long)) != hipSuccess)
+    return bail(fail(RT_ERR_HIP, "hipMemset failed"));
   s->dev.geom = (const rtc::SphereGeom*)s->d_geom; s->dev.mat = (const rtc::SphereMat*)s->d_mat;
   s->dev.cull = (const rtc::CullPair*)s->d_cull; s->dev.lights = (const uint32_t*)s->d_lights;
   s->dev.tex = (const uint8_t*)s->d_tex; s->dev.sky = (const uint8_t*)s->d_sky;
