@@ -10,7 +10,9 @@ A "step" is one frame of BASELINE configs[1] — cover_scene at 1200x800, spp 12
 scene tables already resident in HBM.  With N > 1 the frame is sharded by interleaved
 2-scanline tiles (rank r renders tiles r, r+N, ...) and assembled on rank 0 by ONE gather
 over RCCL; total work is fixed, so scaling is "strong" (the north-star target is a >=6x
-speed-up of this frame at 8 GPUs).  Rank 0 prints ONE JSON line.
+speed-up of this frame at 8 GPUs).  The tile buffers are double-buffered: frame i's gather
+runs (asynchronously, on the collective's stream) while frame i+1 is being rendered, and all K
+frames are assembled on rank 0 before the closing barrier.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
   roofline      the megakernel against the roof that actually binds it (vector ALU; rocprof
@@ -95,31 +97,32 @@ def main():
     if args.variant:
         gs.set_option("variant", args.variant)
     tiles = rdist.shard(rank, world)
-    pad_rows = rdist.max_local_rows(H, world) if world > 1 else H
-    local = torch.zeros((pad_rows, W, 3), dtype=torch.uint8, device=dev)
+    pipe = rdist.FramePipeline(H, W, rank, world, dev)   # double-buffered tiles; frame i's gather runs under frame i+1
     stream = torch.cuda.current_stream()
-
-    def step():
-        gs.render(local.data_ptr(), 0, tiles, stream.cuda_stream)   # the megakernel, on torch's current stream
-        return rdist.gather_frame(local, H, W, rank, world) if world > 1 else local
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    n_frames = 0
+    for i in range(args.warmup):
+        buf, _ = pipe.begin(i)
+        gs.render(buf.data_ptr(), 0, tiles, stream.cuda_stream)   # the megakernel, on torch's current stream
+        pipe.submit(i)
+    pipe.drain()
     fence()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    frame = None
     for i in range(args.steps):
+        buf, done = pipe.begin(i)            # (hands back frame i-2, assembled on rank 0)
+        n_frames += done is not None
         ev0[i].record(stream)
-        gs.render(local.data_ptr(), 0, tiles, stream.cuda_stream)
+        gs.render(buf.data_ptr(), 0, tiles, stream.cuda_stream)
         ev1[i].record(stream)
-        frame = rdist.gather_frame(local, H, W, rank, world) if world > 1 else local
+        pipe.submit(i)                       # N > 1: ONE gather over RCCL, asynchronous
+    n_frames += sum(f is not None for f in pipe.drain())
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / max(1, args.steps)
@@ -138,6 +141,7 @@ def main():
         segments, exact, steps = float(st["segments"]), float(st["exact_tests"]), float(st["grid_steps"])
 
     if rank == 0:
+        assert n_frames == args.steps, (n_frames, args.steps)   # every timed frame was assembled inside the timed region
         samples = W * H * SPP
         ms_per_step = elapsed * 1e3 / args.steps
         value = samples * args.steps / elapsed / 1e6
@@ -158,7 +162,7 @@ def main():
             "dtype": "f64", "data": "scene derived from the reference's data/cover_scene.json (committed under scenes/); Philox seed 0",
             "config": {"workload": f"{os.path.basename(args.scene)}: {W}x{H} spp {SPP} depth {sc.c.max_depth}, {N_SPH} spheres"
                                    + (" (BASELINE configs[1])" if headline else " (NON-HEADLINE run)"),
-                       "parallelism": f"{world} x interleaved {rdist.TILE_ROWS}-scanline tiles, one RCCL gather" if world > 1 else "single GPU",
+                       "parallelism": f"{world} x interleaved {rdist.TILE_ROWS}-scanline tiles, one RCCL gather per frame (overlapping the next frame's render)" if world > 1 else "single GPU",
                        "inputs": "scene tables resident in HBM before the timed region"},
             "kernel_ms": round(kernel_ms, 4), "segments_per_sample": round(segments / samples, 4),
             "exact_tests_per_segment": round(exact / max(1.0, segments), 3),

@@ -60,3 +60,55 @@ def gather_frame(local_rgb8, height, width, rank, world, tile_rows=TILE_ROWS, ds
         return stacked.view(world * pad_rows, width, 3).index_select(0, perm)  # de-interleave: packed rows -> scanlines
     dist.gather(local_rgb8, None, dst=dst)
     return None
+
+
+class FramePipeline:
+    """Double-buffered frames for a stream of renders (bench.py, animation): frame i's gather runs
+    asynchronously (on the collective's own stream with RCCL) while frame i+1 is being rendered
+    into the other buffer.  Per frame still ONE collective + one row permutation on `dst`.
+
+        buf, done = pipe.begin(i)     # tile buffer to render frame i into; `done` = frame i-depth
+        ... render into buf on the current stream ...
+        pipe.submit(i)                # gather of frame i starts once the render has finished
+        frames = pipe.drain()         # after the last frame: the frames still in flight, in order
+    """
+
+    def __init__(self, height, width, rank, world, device, tile_rows=TILE_ROWS, dst=0, depth=2):
+        self.h, self.w, self.rank, self.world, self.dst, self.depth, self.tile_rows = height, width, rank, world, dst, depth, tile_rows
+        self.pad_rows = max_local_rows(height, world, tile_rows) if world > 1 else height
+        self.local = [torch.zeros((self.pad_rows, width, 3), dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.stacked = [torch.empty((world, self.pad_rows, width, 3), dtype=torch.uint8, device=device)
+                        if (world > 1 and rank == dst) else None for _ in range(depth)]
+        self.work = [None] * depth
+        self.order = []  # buffer slots with a gather in flight, oldest first
+
+    def _collect(self, slot):
+        work, self.work[slot] = self.work[slot], None
+        if self.world <= 1:
+            return self.local[slot][: self.h]
+        if work is not None:
+            work.wait()  # the current stream (or the host, with gloo) waits for the collective
+        if self.rank != self.dst:
+            return None
+        perm = _assembly_perm(self.h, self.world, self.tile_rows, self.pad_rows, self.local[slot].device)
+        return self.stacked[slot].view(self.world * self.pad_rows, self.w, 3).index_select(0, perm)
+
+    def begin(self, i):
+        slot = i % self.depth
+        done = None
+        if slot in self.order:  # the buffer is still owned by frame i - depth: finish that one first
+            self.order.remove(slot)
+            done = self._collect(slot)
+        return self.local[slot], done
+
+    def submit(self, i):
+        slot = i % self.depth
+        if self.world > 1:
+            outs = [self.stacked[slot][r] for r in range(self.world)] if self.rank == self.dst else None
+            self.work[slot] = dist.gather(self.local[slot], outs, dst=self.dst, async_op=True)
+        self.order.append(slot)
+
+    def drain(self):
+        frames = [self._collect(slot) for slot in self.order]
+        self.order = []
+        return frames

@@ -54,3 +54,51 @@ def test_two_rank_gather_matches_single(tmp_path, oracle, abi, load_scene, w, h)
     sc = load_scene("cover", w, h, 2)
     full, _, _ = oracle.render(abi, sc.ptr, want_linear=False)
     assert np.array_equal(np.load(out), full)
+
+
+def _pipeline_worker(rank, world, port, w, h, n_frames, out_path):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    os.chdir(ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = graft.load_package()
+        oracle = graft.load_oracle()
+        from rust_raytracer_amd import dist as rdist
+        sc = pkg.host.Scene.load("scenes/cfg2_cover_1200x800_spp128.json")
+        sc.c.width, sc.c.height, sc.c.samples_per_pixel = w, h, 1
+        tiles = rdist.shard(rank, world)
+        pipe = rdist.FramePipeline(h, w, rank, world, torch.device("cpu"))
+        frames = []
+        for i in range(n_frames):  # frame i = seed i: every frame differs, so a mixed-up buffer shows
+            buf, done = pipe.begin(i)
+            if i >= pipe.depth:
+                frames.append(done)
+            else:
+                assert done is None
+            sc.c.seed = i
+            rgb, _, _ = oracle.render(pkg.abi, sc.ptr, tiles, n_threads=2, want_linear=False)
+            buf.zero_()
+            buf[: rgb.shape[0]] = torch.from_numpy(rgb)
+            pipe.submit(i)
+        frames += pipe.drain()
+        assert len(frames) == n_frames
+        if rank == 0:
+            np.save(out_path, np.stack([f.numpy() for f in frames]))
+        else:
+            assert all(f is None for f in frames)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_frame_pipeline_keeps_frames_apart(tmp_path, oracle, abi, load_scene):
+    """bench.py's N>1 loop: double-buffered tiles, asynchronous gather of frame i under frame i+1."""
+    w, h, n = 24, 10, 5
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), w, h, n, out), nprocs=2, join=True)
+    got = np.load(out)
+    for i in range(n):
+        sc = load_scene("cover", w, h, 1, seed=i)
+        full, _, _ = oracle.render(abi, sc.ptr, want_linear=False)
+        assert np.array_equal(got[i], full), i
