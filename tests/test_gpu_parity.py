@@ -318,3 +318,26 @@ def test_full_size_headline_config_properties(gpu_render, oracle, abi, load_scen
         assert_parity(rgb[y:y + 1], lin[y:y + 1], o_rgb, o_lin, f"row {y} pooled", atol=pooled_atol(128), flip_frac=2e-3)
     # image statistics sanity: top rows are sky gradient, bottom rows ground
     assert lin[:40].mean() > lin[-40:].mean()
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the driver's keys (+ roofline / cpu_baseline objects)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-row-stride", "200"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "Msamples/s" and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "BASELINE configs[1]" in d["config"]["workload"]
+    samples = 1200 * 800 * 128
+    assert abs(d["value"] - samples / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * d["value"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
