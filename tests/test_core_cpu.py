@@ -313,3 +313,17 @@ def test_grid_policy_on_the_reference_scenes(hostsim, load_scene):
     sc = load_scene("test", 64, 48, 1, 8)
     assert hostsim.hostsim_grid_info(sc.ptr, info) == 0
     assert info[0] == 0 and info[3] == sc.c.n_spheres == 7
+
+
+@pytest.mark.parametrize("kind", range(6))
+def test_fuzz_worlds_grid_audit(hostsim, host, kind):
+    """tests/fuzz_worlds.py through the per-segment audit (mode 4: every segment's grid-walk hit
+    against the reference's scan over all spheres) — the same worlds the GPU test renders."""
+    from fuzz_worlds import fuzz_world_json
+    sc = host.Scene.loads(fuzz_world_json(np.random.default_rng(1000 + kind), kind))
+    _, _, st = hostsim.render(sc.ptr, mode=4)
+    assert st["kernel_ms"] == 0.0, f"{int(st['kernel_ms'])} segments where the grid walk and the brute-force scan disagree"
+    assert st["segments"] > sc.c.width * sc.c.height * sc.c.samples_per_pixel
+    a = hostsim.render(sc.ptr, mode=3 + 16)
+    b = hostsim.render(sc.ptr, mode=0 + 16)
+    assert np.array_equal(a[1], b[1]) and a[2]["segments"] == b[2]["segments"]

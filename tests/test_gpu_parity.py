@@ -10,6 +10,7 @@ import sys
 import numpy as np
 import pytest
 
+from fuzz_worlds import fuzz_world_json
 from parity import assert_parity, pooled_atol
 
 pytestmark = pytest.mark.gpu
@@ -341,3 +342,20 @@ def test_bench_line_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.parametrize("kind", range(6))
+def test_fuzz_worlds_grid_equals_bruteforce_on_the_gpu(gpu_render, hostsim, host, kind):
+    """The product kernel (grid walk) against the same kernel running the reference's scan over
+    every sphere (variant 1): same bits, same path count — and the same bits as the CPU build of
+    the lane logic."""
+    rng = np.random.default_rng(1000 + kind)
+    sc = host.Scene.loads(fuzz_world_json(rng, kind))
+    a_rgb, a_lin, a_st = gpu_render(sc, variant=0)
+    b_rgb, b_lin, b_st = gpu_render(sc, variant=1)
+    assert a_st["segments"] == b_st["segments"], kind
+    assert np.array_equal(a_lin, b_lin) and np.array_equal(a_rgb, b_rgb), kind
+    h_rgb, h_lin, h_st = hostsim.render(sc.ptr, mode=3 + 16)
+    assert int(h_st["segments"]) == a_st["segments"] and np.array_equal(h_lin, a_lin) and np.array_equal(h_rgb, a_rgb), kind
+    if kind != 2:
+        assert a_st["grid_steps"] > 0, "the world is expected to be gridded"
