@@ -114,6 +114,12 @@ __host__ __device__ inline LdsLayout lds_layout(uint32_t n_spheres, uint32_t n_c
   return l;
 }
 
+// Wave votes on a bool: the i1 form of the ballot is a plain lane-mask AND (HIP's __ballot / __any
+// take an int and go through a VGPR 0/1 and a compare again — two VALU instructions and a
+// VALU->SALU dependency per vote, three votes per walk round).
+__device__ __forceinline__ unsigned long long wave_ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+__device__ __forceinline__ bool wave_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+
 // The kernel arguments live in the kernarg segment (constant memory).  Reading them through a
 // pointer the compiler cannot see through makes every section of the path loop RE-LOAD the few
 // fields it needs (s_load, scalar cache) instead of keeping all ~80 argument SGPRs live across
@@ -152,7 +158,7 @@ __device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, bool glass, 
   glass_u = u01_53(wx, wy);
   uint32_t base = 1;  // next attempt of every lane still pending (wave-uniform)
   for (;;) {
-    const unsigned long long F = __ballot(pending);
+    const unsigned long long F = wave_ballot(pending);
     if (!F) break;
     const uint32_t nf = (uint32_t)__builtin_popcountll(F);
     uint32_t layers = 64u / nf;
@@ -172,7 +178,7 @@ __device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, bool glass, 
       hx = hw.x; hy = hw.y; hz = hw.z;
       acc = length_squared(point(hx, hy, hz)) < 1.0;
     }
-    const unsigned long long A = __ballot(acc);
+    const unsigned long long A = wave_ballot(acc);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every helper has read its slot: reuse them for the answers
     if (acc) xch[lane] = make_uint4(hx, hy, hz, 0u);
     // failing lane #r: its helpers are lanes r, r + nf, r + 2 nf, ...: the lowest layer that accepted
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         const bool mine = k < T;
         const uint32_t st = mine ? lds_load(&hdr[mine ? k : 0].state) : (uint32_t)SLOT_OPEN;
         const uint32_t nx = mine ? lds_load(&hdr[mine ? k : 0].next) : 0xFFFFFFFFu;
-        unsigned long long mo = __ballot(mine && st == SLOT_OPEN && nx < n_chunks);
+        unsigned long long mo = wave_ballot(mine && st == SLOT_OPEN && nx < n_chunks);
         while (mo) {
           const uint32_t kk = base + (uint32_t)__builtin_ctzll(mo);
           mo &= mo - 1ull;
@@ -352,8 +358,8 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
           c = bcast(c);
           if (c < n_chunks) { k_out = kk; chunk_out = c; return 1; }
         }
-        any_opening = any_opening || __any(mine && st == SLOT_OPENING);
-        const unsigned long long mf = __ballot(mine && st == SLOT_FREE);
+        any_opening = any_opening || wave_any(mine && st == SLOT_OPENING);
+        const unsigned long long mf = wave_ballot(mine && st == SLOT_FREE);
         if (mf && !free_mask) { free_mask = mf; free_base = base; }
       }
       if (bcast(lds_load(&wg_flags[0])) != 0u) return any_opening ? 0 : -1;  // (a tile being opened right now will still offer chunks)
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       const uint32_t tl = ka.tile_log2, tw = 1u << tl, npx = 1u << (2u * tl);
       const uint32_t by = tile / ka.tiles_x, bx = tile - by * ka.tiles_x;
       const uint32_t px = (bx << tl) + (lane & (tw - 1u)), lr = (by << tl) + (lane >> tl);
-      const uint32_t n_valid = (uint32_t)__builtin_popcountll(__ballot(lane < npx && px < sc.width && lr < ka.local_rows));
+      const uint32_t n_valid = (uint32_t)__builtin_popcountll(wave_ballot(lane < npx && px < sc.width && lr < ka.local_rows));
       // max_depth == 0: ray_color returns black before tracing anything (raytracer.rs:80-82)
       const uint32_t expected = sc.max_depth != 0u ? n_valid * sc.spp : 0u;
       unsigned long long* acc = tile_acc + k * acc_stride;
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       const uint32_t tl = kr.tile_log2, tw = 1u << tl, pl = 2u * tl, pmask = (1u << pl) - 1u;
       bool want = !has_ray;
       for (;;) {
-        const unsigned long long m = __ballot(want);
+        const unsigned long long m = wave_ballot(want);
         if (!m) break;
         if (it_next < it_total) {  // hand out samples of the current item
           const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         open_item(k, chunk);
       }
     }
-    if (!__any(has_ray)) {
+    if (!wave_any(has_ray)) {
       // nothing in flight.  Done when the frame has nothing left; otherwise (all tile slots are
       // busy with other waves' long paths) wait a little and ask again — bounded, a wave may
       // always retire: the samples it traced are already counted in their tiles.
@@ -466,7 +472,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 
     idle_spins = 0;
 #ifdef RT_PROFILE
-    if (q_done) { prof_tail_iters++; prof_tail_lanes += (uint32_t)__builtin_popcountll(__ballot(has_ray)); }
+    if (q_done) { prof_tail_iters++; prof_tail_lanes += (uint32_t)__builtin_popcountll(wave_ballot(has_ray)); }
 #endif
     RT_PROF_COUNT(cnt_w_iter);
     RT_PROF(0);
@@ -502,7 +508,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       // (2) enter the grid
       GridWalk w;
       const int mode = !has_ray ? GRID_MISS : (!rk.fast ? GRID_FALLBACK : (has_grid ? grid_begin(G, L.o, L.d, w) : GRID_MISS));
-      if (__any(mode == GRID_FALLBACK)) {  // numerically unsafe ray: the reference's full scan, real divisions
+      if (wave_any(mode == GRID_FALLBACK)) {  // numerically unsafe ray: the reference's full scan, real divisions
         for (uint32_t idx = 0; idx < sc.n_spheres; ++idx) {
           const F64PtrK gp = geom_k + (size_t)idx * 4u;
           SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
@@ -527,13 +533,15 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
           it = e.x & CELL_START_MASK; end = it + (e.x >> CELL_COUNT_SHIFT); pend = e.y;
         }
         for (;;) {
-          if (!__any(walking)) break;
+          if (!wave_any(walking)) break;
           // (a) lanes whose cell is exhausted: finished, or on to the next non-empty cell.  The next
           // TWO cells along the ray are computed and fetched together (one LDS round trip), the
           // second one is used only if the first is empty.
           const bool moving = walking && it == end;
-          if (__any(moving)) {
-            RT_PROF_COUNT(cnt_w_step);
+          {  // (no wave vote around the block: the lane mask of `if (moving)` already skips it when empty)
+#ifdef RT_PROFILE
+            if (wave_any(moving)) cnt_w_step++;
+#endif
             if (moving) {
               float tc = (float)(closest - t0);
               tc = tc + fabsf(tc) * 2.384185791015625e-07f;  // grid_done
@@ -569,8 +577,10 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
             }
           }
           const bool testing = walking && it != end;
-          if (__any(testing)) {  // (b) one exact Sphere::hit per lane standing in a cell with spheres left
-            RT_PROF_COUNT(cnt_w_test);
+          {  // (b) one exact Sphere::hit per lane standing in a cell with spheres left
+#ifdef RT_PROFILE
+            if (wave_any(testing)) cnt_w_test++;
+#endif
             if (testing) {
               uint32_t idx = pend & 0xFFFFu;
               if (idx == 0xFFFFu) idx = cell_items[it];  // third and later items of a cell: from the list
@@ -608,12 +618,12 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
           has_ray = false;
         }
       }
-      unsigned long long mf = __ballot(finished);
+      unsigned long long mf = wave_ballot(finished);
       if (mf) {  // count the finished samples per tile; whoever adds a tile's last sample writes its pixels
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         while (mf) {
           const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)my_k, (int)__builtin_ctzll(mf));
-          const unsigned long long same = __ballot(finished && my_k == k);
+          const unsigned long long same = wave_ballot(finished && my_k == k);
           mf &= ~same;
           const uint32_t cnt = (uint32_t)__builtin_popcountll(same);
           uint32_t total = 0, expected = 1;
