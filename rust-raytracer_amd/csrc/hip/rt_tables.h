@@ -270,20 +270,12 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
   GridParams gp = grid_params_from_env();
   if (gp.cells_per_sphere > 0.0) { build_grid(sc, t, gp); pack_large(); }
   else {
-    // Finer cells mean fewer exact tests per ray but more steps; measured on the headline scene
-    // (profiles/) 8 cells per sphere is best as long as the tables stay LDS-resident; scenes whose
-    // tables cannot fit anyway (thousands of spheres) walk a 4-cells-per-sphere grid out of L2.
-    const size_t fixed = (size_t)n * (sizeof(SphereGeom) + sizeof(MatCore));
-    auto table_bytes = [&]() { return fixed + (size_t)t.grid.n_cells * 8u + (size_t)t.grid.n_items * 2u; };
-    const double tries[] = {8.0, 6.0, 4.0, 3.0, 2.0};
-    bool fits = false;
-    if (fixed < GRID_LDS_TABLE_BUDGET)
-      for (double c : tries) {
-        gp.cells_per_sphere = c;
-        build_grid(sc, t, gp);
-        if (table_bytes() <= GRID_LDS_TABLE_BUDGET || t.grid.n[0] == 0u) { fits = true; break; }
-      }
-    if (!fits) { gp.cells_per_sphere = 4.0; build_grid(sc, t, gp); }
+    // Finer cells mean fewer exact tests per ray but more steps (and more lock-step walk rounds per
+    // wave).  Measured once the tall spheres had left the grid (profiles/r01_run9_ab_cells.log: 484
+    // spheres in LDS, 10 001 spheres out of L2, 4K textured): 2 cells per gridded sphere is best or
+    // tied everywhere (2: 15.15 ms, 3: 15.25, 4: 15.9, 8: 16.6), so that is the automatic choice.
+    gp.cells_per_sphere = 2.0;
+    build_grid(sc, t, gp);
     pack_large();
   }
   return "";
