@@ -520,24 +520,27 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         // (3) walk rounds: every walking lane moves on by up to two cells and/or tests one sphere.
         // Per-lane walk state: tm = GridWalk.tmax, dt = GridWalk.delta, dl = GridWalk.dl, lin;
         // the current cell's untested spheres are items [it, end), the next two of them also in `pend`.
-        bool walking = mode == GRID_WALK;
+        const bool walk0 = mode == GRID_WALK;
         float tm0 = w.tmax[0], tm1 = w.tmax[1], tm2 = w.tmax[2];
         const float dt0 = w.delta[0], dt1 = w.delta[1], dt2 = w.delta[2];
         const int dl0 = w.dl[0], dl1 = w.dl[1], dl2 = w.dl[2];
-        int lin = walking ? w.lin : 0;
+        int lin = walk0 ? w.lin : 0;
         const double t0 = w.t0;
         const int lin_max = (int)G.n_cells - 1;
-        uint32_t it = 0, end = 0, pend = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
-        if (walking) {
+        // A lane is walking while it <= end (it == end: cell exhausted, move on; it < end: spheres left to
+        // test); a lane that stopped has (it, end) = (1, 0).  Each predicate is ONE compare: a separate
+        // `walking` flag costs a lane-mask AND per use and a VGPR round trip in the loop's exit vote.
+        uint32_t it = 1, end = 0, pend = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
+        if (walk0) {
           const uint2 e = cell_word[lin];
           it = e.x & CELL_START_MASK; end = it + (e.x >> CELL_COUNT_SHIFT); pend = e.y;
         }
         for (;;) {
-          if (!wave_any(walking)) break;
+          if (!wave_any(it <= end)) break;
           // (a) lanes whose cell is exhausted: finished, or on to the next non-empty cell.  The next
           // TWO cells along the ray are computed and fetched together (one LDS round trip), the
           // second one is used only if the first is empty.
-          const bool moving = walking && it == end;
+          const bool moving = it == end;
           {  // (no wave vote around the block: the lane mask of `if (moving)` already skips it when empty)
 #ifdef RT_PROFILE
             if (wave_any(moving)) cnt_w_step++;
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
               tc = tc + fabsf(tc) * 2.384185791015625e-07f;  // grid_done
               const bool hit = best >= 0;
               const float tminA = rt_min3f(tm0, tm1, tm2);
-              if (hit && tc < tminA) walking = false;
+              if (hit && tc < tminA) { it = 1; end = 0; }
               else {
                 // grid_step x 2
                 const bool ax = tm0 == tminA, ay = !ax && tm1 == tminA, az = !ax && !ay;
@@ -566,17 +569,17 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
                 if (exitA || !emptyA || doneA) {  // stay in A (or stop there)
                   tm0 = a0; tm1 = a1; tm2 = a2; lin = linA;
                   it = eA.x & CELL_START_MASK; end = it + (eA.x >> CELL_COUNT_SHIFT); pend = eA.y;
-                  if (exitA || emptyA) { walking = false; end = it; }
+                  if (exitA || emptyA) { it = 1; end = 0; }
                 } else {                           // A is empty: on to B
                   n_steps++;
                   tm0 = b0; tm1 = b1; tm2 = b2; lin = linB;
                   it = eB.x & CELL_START_MASK; end = it + (eB.x >> CELL_COUNT_SHIFT); pend = eB.y;
-                  if (eB.x == CELL_EXIT) { walking = false; end = it; }
+                  if (eB.x == CELL_EXIT) { it = 1; end = 0; }
                 }
               }
             }
           }
-          const bool testing = walking && it != end;
+          const bool testing = it < end;
           {  // (b) one exact Sphere::hit per lane standing in a cell with spheres left
 #ifdef RT_PROFILE
             if (wave_any(testing)) cnt_w_test++;
