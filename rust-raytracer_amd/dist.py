@@ -73,18 +73,19 @@ class FramePipeline:
         frames = pipe.drain()         # after the last frame: the frames still in flight, in order
     """
 
-    def __init__(self, height, width, rank, world, device, tile_rows=TILE_ROWS, dst=0, depth=2):
+    def __init__(self, height, width, rank, world, device, tile_rows=TILE_ROWS, dst=0, depth=2, force_collective=False):
         self.h, self.w, self.rank, self.world, self.dst, self.depth, self.tile_rows = height, width, rank, world, dst, depth, tile_rows
+        self.collective = world > 1 or force_collective   # (force_collective: a 1-rank group still goes through the gather; tests)
         self.pad_rows = max_local_rows(height, world, tile_rows) if world > 1 else height
         self.local = [torch.zeros((self.pad_rows, width, 3), dtype=torch.uint8, device=device) for _ in range(depth)]
         self.stacked = [torch.empty((world, self.pad_rows, width, 3), dtype=torch.uint8, device=device)
-                        if (world > 1 and rank == dst) else None for _ in range(depth)]
+                        if (self.collective and rank == dst) else None for _ in range(depth)]
         self.work = [None] * depth
         self.order = []  # buffer slots with a gather in flight, oldest first
 
     def _collect(self, slot):
         work, self.work[slot] = self.work[slot], None
-        if self.world <= 1:
+        if not self.collective:
             return self.local[slot][: self.h]
         if work is not None:
             work.wait()  # the current stream (or the host, with gloo) waits for the collective
@@ -103,7 +104,7 @@ class FramePipeline:
 
     def submit(self, i):
         slot = i % self.depth
-        if self.world > 1:
+        if self.collective:
             outs = [self.stacked[slot][r] for r in range(self.world)] if self.rank == self.dst else None
             self.work[slot] = dist.gather(self.local[slot], outs, dst=self.dst, async_op=True)
         self.order.append(slot)

@@ -359,3 +359,58 @@ def test_fuzz_worlds_grid_equals_bruteforce_on_the_gpu(gpu_render, hostsim, host
     assert int(h_st["segments"]) == a_st["segments"] and np.array_equal(h_lin, a_lin) and np.array_equal(h_rgb, a_rgb), kind
     if kind != 2:
         assert a_st["grid_steps"] > 0, "the world is expected to be gridded"
+
+
+_RCCL_ONE_RANK = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+import __graft_entry__ as graft
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[1], RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)   # nccl == RCCL on ROCm
+pkg = graft.load_package()
+from rust_raytracer_amd import dist as rdist
+sc = pkg.host.Scene.load("scenes/cfg2_cover_1200x800_spp128.json")
+sc.c.width, sc.c.height, sc.c.samples_per_pixel = 96, 40, 2
+W, H = 96, 40
+stream = torch.cuda.current_stream()
+pipe = rdist.FramePipeline(H, W, 0, 1, dev, force_collective=True)
+frames, want = [], []
+for i in range(5):
+    gs = pkg.hip.HipScene(sc.ptr, 0)
+    gs.set_option("seed", i)                       # every frame differs
+    ref = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+    gs.render(ref.data_ptr(), 0, None, stream.cuda_stream); gs.wait()
+    want.append(ref.cpu().numpy())
+    buf, done = pipe.begin(i)
+    if done is not None:
+        frames.append(done.cpu().numpy())
+    gs.render(buf.data_ptr(), 0, None, stream.cuda_stream)
+    pipe.submit(i)                                 # asynchronous gather over RCCL
+    gs.wait(); gs.close()
+frames += [f.cpu().numpy() for f in pipe.drain()]
+dist.barrier(); torch.cuda.synchronize()
+assert len(frames) == 5
+for i in range(5):
+    assert np.array_equal(frames[i], want[i]), i
+assert not np.array_equal(want[0], want[1])
+dist.destroy_process_group()
+print("RCCL_PIPELINE_OK")
+'''
+
+
+def test_frame_pipeline_through_rccl_one_rank(tmp_path):
+    """bench.py's N > 1 machinery (double-buffered tiles, asynchronous `gather` on RCCL's stream,
+    row permutation on the destination) with the only process group a 1-GPU box allows: one rank."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(_RCCL_ONE_RANK)
+    r = subprocess.run([sys.executable, str(script), str(port)], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0 and "RCCL_PIPELINE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
