@@ -784,7 +784,13 @@ RT_HD unsigned long long sample_to_fixed(float v) {
   double x = (double)v;
   if (!(x > 0.0)) return 0ull;
   if (x > 1.0) x = 1.0;  // every sample is clamp01'ed at the root level already
-  return (unsigned long long)(x * FIX_SCALE + 0.5);
+  // (unsigned long long)(x * 2^40 + 0.5), written so that the GPU needs no 64-bit float->int
+  // conversion (it has none: 10 instructions per channel): the truncated value is an integer
+  // below 2^41, so adding 2^52 is exact and leaves it in the low mantissa bits.
+  const double y = __builtin_trunc(x * FIX_SCALE + 0.5) + 4503599627370496.0;
+  unsigned long long bits;
+  __builtin_memcpy(&bits, &y, sizeof bits);
+  return bits & 0x000FFFFFFFFFFFFFull;
 }
 RT_HD float fixed_to_mean(unsigned long long sum, uint32_t spp) {
   return (float)(((double)sum * (1.0 / FIX_SCALE)) / (double)spp);
