@@ -204,6 +204,13 @@ int rt_hip_wait(RtHipScene*, RtStats* stats);
  * wave of the last launch, on the chip-wide 100 MHz clock.  Returns the number of waves copied
  * (out holds 32 + 4 x max_waves uint64) or a negative RtStatus. */
 int rt_hip_debug_timeline(RtHipScene*, uint64_t* out, uint32_t max_waves);
+/* Device self-tests (device pointers; tests/test_gpu_parity.py): correctly rounded f64 sqrt / divide,
+ * f32 sqrt and atan2 of n operands; Sphere::hit (sphere.rs:46-58) of n (ray, sphere) pairs through
+ * the kernel's own hit test — rays = n x {origin[3], direction[3]}, spheres = n x {center[3], radius},
+ * out_t = the accepted root with t_max = f64::MAX, or -1. */
+int rt_hip_math_probe(const double* x, const double* y, double* out_sqrt, double* out_div, float* out_sqrtf, double* out_atan2,
+                      uint32_t n, void* stream);
+int rt_hip_hit_probe(const double* rays, const double* spheres, double* out_t, uint32_t n, void* stream);
 /* Tunables / A-B arms.  Keys: "variant" 0 = grid walk (default), 1 = the
  * reference's brute force (exact test on every sphere), 2 = round-1 f32 cull-scan kernel;
  * "chunk_spp" samples of a pixel per work item (0 = automatic); "tile_log2" pixel tiles of

@@ -404,6 +404,12 @@ extern "C" int rt_render_rgb8(const RtScene* scene, uint8_t* out_rgb8, RtStats* 
 }
 
 // math self-test hook (see rtk::rt_math_probe); all pointers are DEVICE pointers
+extern "C" int rt_hip_hit_probe(const double* rays, const double* spheres, double* out_t, uint32_t n, void* stream) {
+  hipLaunchKernelGGL(rtk::rt_hit_probe, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rays, spheres, out_t, n);
+  RT_HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
 extern "C" int rt_hip_math_probe(const double* x, const double* y, double* out_sqrt, double* out_div, float* out_sqrtf,
                                  double* out_atan2, uint32_t n, void* stream) {
   hipLaunchKernelGGL(rtk::rt_math_probe, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, out_sqrt, out_div,

@@ -693,4 +693,20 @@ __global__ void rt_math_probe(const double* x, const double* y, double* out_sqrt
   out_atan2[i] = atan2(x[i] - 0.5, y[i] - 0.5);
 }
 
+// Sphere::hit on the device, one (ray, sphere) pair per thread, through the kernel's own hit test
+// (closest-so-far = f64::MAX): out_t = accepted root or -1.  tests/test_gpu_parity.py compares it
+// with the CPU build of the same function on random, tangent (discriminant 0 / denormal-range) and
+// degenerate pairs — the cold paths a rendered frame practically never takes.
+__global__ void rt_hit_probe(const double* rays, const double* spheres, double* out_t, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 o = v3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), d = v3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+  SphereGeom g; g.cx = spheres[4 * i]; g.cy = spheres[4 * i + 1]; g.cz = spheres[4 * i + 2]; g.r = spheres[4 * i + 3];
+  const RayK rk = ray_consts(d);
+  double closest = T_MAX;
+  int best = -1;
+  const bool hit = exact_hit_any_order(o, d, rk, g, 0u, closest, best);
+  out_t[i] = hit ? closest : -1.0;
+}
+
 }  // namespace rtk

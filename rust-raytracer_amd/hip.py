@@ -38,6 +38,7 @@ def lib():
         L.rt_hip_set_camera.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 4
         L.rt_hip_render_to_host.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.RtStats)]
         L.rt_hip_math_probe.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_void_p]
+        L.rt_hip_hit_probe.argtypes = [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p]
         _LIB = L
     return _LIB
 

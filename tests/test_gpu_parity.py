@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from fuzz_worlds import fuzz_world_json
+from conftest import dvec
 from parity import assert_parity, pooled_atol
 
 pytestmark = pytest.mark.gpu
@@ -72,6 +73,14 @@ def test_gpu_math_is_ieee_exact(pkg, torch_cuda):
     n = 1 << 20
     rng = np.random.default_rng(0)
     x = np.concatenate([rng.random(n // 2), 10.0 ** rng.uniform(-30, 30, n // 2)])
+    # the library's square root rescales arguments below 2^-767: both sides of that threshold, denormals, the
+    # largest finite values, perfect squares and their neighbours, 0 and inf
+    k = 4096
+    sq = rng.integers(1, 1 << 26, k).astype(np.float64) ** 2
+    x[:12 * k] = np.concatenate([2.0 ** rng.uniform(-780, -755, k), 2.0 ** rng.uniform(-1074, -1000, k), 2.0 ** rng.uniform(1000, 1023.99, k),
+                                 2.0 ** rng.uniform(-1022, 1023, 4 * k), sq, np.nextafter(sq, 0), np.nextafter(sq, np.inf),
+                                 np.array([0.0, 2.0 ** -767, np.nextafter(2.0 ** -767, 0), np.finfo(np.float64).max, np.inf, 5e-324] * (k // 6) + [0.0] * (k % 6)),
+                                 rng.random(k) * 1e-300])
     y = np.concatenate([rng.random(n // 2) + 1e-3, 10.0 ** rng.uniform(-30, 30, n // 2)])
     dx, dy = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
     o_sqrt, o_div, o_at = torch.empty_like(dx), torch.empty_like(dx), torch.empty_like(dx)
@@ -81,9 +90,12 @@ def test_gpu_math_is_ieee_exact(pkg, torch_cuda):
     assert rc == 0
     torch.cuda.synchronize()
     assert np.array_equal(o_sqrt.cpu().numpy(), np.sqrt(x))
-    assert np.array_equal(o_div.cpu().numpy(), x / y)
-    assert np.array_equal(o_sqrtf.cpu().numpy(), np.sqrt(x.astype(np.float32)))
-    at, want = o_at.cpu().numpy(), np.arctan2(x - 0.5, y - 0.5)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(o_div.cpu().numpy(), x / y, equal_nan=True)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(o_sqrtf.cpu().numpy(), np.sqrt(x.astype(np.float32)))
+    fin = np.isfinite(x)
+    at, want = o_at.cpu().numpy()[fin], np.arctan2(x - 0.5, y - 0.5)[fin]
     assert np.allclose(at, want, rtol=4e-16, atol=0)
     print("atan2 last-ulp mismatches:", float((at != want).mean()))
 
@@ -414,3 +426,46 @@ def test_frame_pipeline_through_rccl_one_rank(tmp_path):
     script.write_text(_RCCL_ONE_RANK)
     r = subprocess.run([sys.executable, str(script), str(port)], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0 and "RCCL_PIPELINE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_device_sphere_hit_matches_the_host_build(pkg, hostsim, abi, torch_cuda):
+    """Sphere::hit pair by pair on the device (the kernel's own exact_hit_any_order) against the CPU
+    build of the same source: random pairs, rays tangent to the sphere (discriminant exactly 0 or in
+    the denormal range — the cold library-sqrt path), origins on / inside the sphere, negative
+    radii, degenerate directions."""
+    torch = torch_cuda
+    rng = np.random.default_rng(99)
+    n = 200_000
+    c = rng.uniform(-5, 5, (n, 3))
+    r = rng.uniform(0.05, 3.0, n) * rng.choice([1.0, 1.0, 1.0, -1.0], n)
+    o = c + rng.standard_normal((n, 3)) * rng.uniform(0.0, 6.0, (n, 1))
+    d = (c + rng.standard_normal((n, 3)) * np.abs(r)[:, None] * rng.uniform(0.0, 1.5, (n, 1))) - o
+    k = n // 8
+    # exactly tangent, representable: axis-aligned rays past integer-ish spheres  (oc.d)^2 - |d|^2 (|oc|^2 - r^2) = 0
+    ci = rng.integers(-4, 5, (k, 3)).astype(np.float64); ri = rng.integers(1, 4, k).astype(np.float64)
+    ax = rng.integers(0, 3, k); bx = (ax + 1) % 3
+    ot = ci.copy(); ot[np.arange(k), bx] += ri; ot[np.arange(k), ax] -= rng.integers(2, 9, k)
+    dt = np.zeros((k, 3)); dt[np.arange(k), ax] = rng.choice([0.5, 1.0, 2.0, 4.0], k)
+    c[:k], r[:k], o[:k], d[:k] = ci, ri, ot, dt
+    # almost tangent: the same rays nudged by a few ulps / tiny offsets either way (tiny positive and negative discriminants)
+    c[k:2 * k], r[k:2 * k], d[k:2 * k] = ci, ri, dt
+    o[k:2 * k] = ot
+    o[np.arange(k, 2 * k), bx] += ri * rng.choice([-1.0, 1.0], k) * 10.0 ** rng.uniform(-150, -17, k)
+    # origin exactly on the surface / inside; zero and denormal direction components
+    o[2 * k:3 * k] = c[2 * k:3 * k] + np.eye(3)[rng.integers(0, 3, k)] * np.abs(r[2 * k:3 * k, None])
+    d[3 * k:3 * k + k // 2, rng.integers(0, 3)] = rng.choice([0.0, -0.0, 1e-310, -1e-305], k // 2)
+    rays = np.ascontiguousarray(np.concatenate([o, d], axis=1))
+    sph = np.ascontiguousarray(np.concatenate([c, r[:, None]], axis=1))
+    d_rays, d_sph = torch.from_numpy(rays).cuda(), torch.from_numpy(sph).cuda()
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    assert pkg.hip.lib().rt_hip_hit_probe(d_rays.data_ptr(), d_sph.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    want = np.empty(n)
+    s = abi.RtSphere()
+    tmax = float(np.finfo(np.float64).max)
+    for i in range(n):
+        s.center[:] = c[i].tolist(); s.radius = float(r[i])
+        want[i] = hostsim.hostsim_exact_root(dvec(*o[i]), dvec(*d[i]), s, 0.001, tmax)
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+    assert (want[:k] > 0).mean() > 0.9 and (want >= 0).mean() > 0.3   # the tangent rays do hit (discriminant 0 -> one root)
