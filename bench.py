@@ -180,6 +180,14 @@ def main():
                              "note": "achieved = algorithmic sphere-geometry bytes (32 B/test) per second; the tables are "
                                      "LDS-resident, real HBM traffic is `traffic` bytes per launch"},
         }
+        if world == 1:
+            # the frame as a host caller sees it with the scene resident — kernel + the 2.88 MB
+            # device-to-host copy of the RGB8 frame (pageable numpy buffer) — reported beside `value`, never as it
+            gs.render_to_host()
+            h0 = time.perf_counter()
+            for _ in range(3):
+                gs.render_to_host()
+            out["frame_ms_to_host_buffer"] = round((time.perf_counter() - h0) * 1e3 / 3, 3)
         if world == 1 and not args.no_cpu_baseline:
             oracle = graft.load_oracle()
             cores = oracle.lib(abi).rt_oracle_threads()
