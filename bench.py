@@ -45,6 +45,14 @@ PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 
 
+def _flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,9 +83,25 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # RT_BENCH_FORCE_COLLECTIVE=1: a one-rank RCCL group still goes through init / gather / barrier — the N > 1
+    # code path exercised on a 1-GPU box (self-check; the line then says so in config.parallelism)
+    force_coll = world == 1 and os.environ.get("RT_BENCH_FORCE_COLLECTIVE") == "1"
+    if world > 1 or force_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # RCCL prints a version banner through C stdio when the communicator comes up (device_id = eager init); on
+        # a pipe it would sit in the buffer until exit and land AFTER the JSON line.  stdout carries that ONE line
+        # only: while the group comes up, file descriptor 1 points at stderr, and the buffer is pushed out there.
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+            dist.barrier()
+        finally:
+            _flush_c_stdio()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     pkg = graft.load_package()
     abi, host, hip = pkg.abi, pkg.host, pkg.hip
@@ -97,11 +121,11 @@ def main():
     if args.variant:
         gs.set_option("variant", args.variant)
     tiles = rdist.shard(rank, world)
-    pipe = rdist.FramePipeline(H, W, rank, world, dev)   # double-buffered tiles; frame i's gather runs under frame i+1
+    pipe = rdist.FramePipeline(H, W, rank, world, dev, force_collective=force_coll)   # double-buffered tiles; frame i's gather runs under frame i+1
     stream = torch.cuda.current_stream()
 
     def fence():
-        if world > 1:
+        if world > 1 or force_coll:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -162,7 +186,7 @@ def main():
             "dtype": "f64", "data": "scene derived from the reference's data/cover_scene.json (committed under scenes/); Philox seed 0",
             "config": {"workload": f"{os.path.basename(args.scene)}: {W}x{H} spp {SPP} depth {sc.c.max_depth}, {N_SPH} spheres"
                                    + (" (BASELINE configs[1])" if headline else " (NON-HEADLINE run)"),
-                       "parallelism": f"{world} x interleaved {rdist.TILE_ROWS}-scanline tiles, one RCCL gather per frame (overlapping the next frame's render)" if world > 1 else "single GPU",
+                       "parallelism": f"{world} x interleaved {rdist.TILE_ROWS}-scanline tiles, one RCCL gather per frame (overlapping the next frame's render)" if world > 1 else ("single GPU (one-rank RCCL group forced: self-check)" if force_coll else "single GPU"),
                        "inputs": "scene tables resident in HBM before the timed region"},
             "kernel_ms": round(kernel_ms, 4), "segments_per_sample": round(segments / samples, 4),
             "exact_tests_per_segment": round(exact / max(1.0, segments), 3),
@@ -208,10 +232,14 @@ def main():
                                    "sample": f"every {stride}th scanline of the same frame ({rows} rows, {ost['samples'] / 1e6:.2f} Msamples, "
                                              f"{csec:.1f} s); C oracle, OpenMP one scanline per task, -O3 -march=native -ffp-contract=off",
                                    "gpu_over_cpu": round(value / (ost["samples"] / csec / 1e6), 1)}
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     gs.close()
-    if world > 1:
+    if world > 1 or force_coll:
+        dist.barrier()
         dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank == 0:
+        print(line, flush=True)   # the ONE JSON line, and the last thing this process writes to stdout
 
 
 if __name__ == "__main__":

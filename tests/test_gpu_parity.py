@@ -333,13 +333,19 @@ def test_full_size_headline_config_properties(gpu_render, oracle, abi, load_scen
     assert lin[:40].mean() > lin[-40:].mean()
 
 
-def test_bench_line_contract():
-    """bench.py prints ONE JSON line with the driver's keys (+ roofline / cpu_baseline objects)."""
+@pytest.mark.parametrize("force_rccl", [False, True])
+def test_bench_line_contract(force_rccl):
+    """bench.py prints ONE JSON line with the driver's keys (+ roofline / cpu_baseline objects) and nothing
+    else on stdout — also when an RCCL group is up (RT_BENCH_FORCE_COLLECTIVE: the N > 1 code path with one
+    rank; RCCL's version banner must not reach stdout)."""
+    env = dict(os.environ, MASTER_PORT="29561")
+    if force_rccl:
+        env["RT_BENCH_FORCE_COLLECTIVE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-row-stride", "200"],
-                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+                       capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
