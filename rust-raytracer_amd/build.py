@@ -31,7 +31,7 @@ def build_host(force=False):
     src = _srcs("csrc/host/scene.cpp", "csrc/host/jpeg.cpp")
     deps = src + _srcs("csrc/host/json.hpp") + [os.path.join(ROOT, "include/rt_abi.h")]
     if force or _newer(out, deps):
-        _run(["g++", *CXXFLAGS, "-shared", *src, "-o", out, "-lz"])
+        _run(["g++", *CXXFLAGS, "-shared", *src, "-o", out, "-lz", "-lpthread"])
     return out
 
 
