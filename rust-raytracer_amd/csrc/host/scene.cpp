@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <map>
 #include <memory>
 #include <string>
@@ -117,13 +118,65 @@ struct RtSceneFile {
 
 namespace {
 
+// A decoded JPEG (or why it could not be decoded).  The scene's textures (2-3 MP each, ~40 ms of Huffman +
+// IDCT) are decoded concurrently, one host thread per distinct file, while the rest of the scene is parsed.
+struct Decoded {
+  uint8_t* px = nullptr;
+  uint32_t w = 0, h = 0;
+  int rc = RT_OK;
+  std::string err;
+};
+typedef std::map<std::string, std::shared_future<Decoded>> DecodeJobs;
+void start_decode(DecodeJobs& jobs, const std::string& path) {
+  if (path.empty() || jobs.count(path)) return;
+  jobs[path] = std::async(std::launch::async, [path]() {
+    Decoded d;
+    d.rc = rt_jpeg_decode_file(path.c_str(), &d.px, &d.w, &d.h);
+    if (d.rc != RT_OK) d.err = rt_jpeg_last_error();  // (thread-local in the decoder: read it on this thread)
+    return d;
+  }).share();
+}
+// every texture file the config names: Sky.texture and Texture.pixels of each object
+void start_all_decodes(const Value& root, DecodeJobs& jobs) {
+  if (root.kind != Value::Object) return;
+  if (const Value* sky = root.find("sky"))
+    if (sky->kind == Value::Object)
+      if (const Value* t = sky->find("texture"))
+        if (t->kind == Value::String) start_decode(jobs, t->text);
+  const Value* objs = root.find("objects");
+  if (!objs || objs->kind != Value::Array) return;
+  for (auto& o : objs->items) {
+    if (o->kind != Value::Object) continue;
+    const Value* m = o->find("material");
+    if (!m || m->kind != Value::Object || m->members.size() != 1 || m->members[0].first != "Texture") continue;
+    const Value& body = *m->members[0].second;
+    if (body.kind != Value::Object) continue;
+    if (const Value* px = body.find("pixels"))
+      if (px->kind == Value::String) start_decode(jobs, px->text);
+  }
+}
+Decoded take_decoded(DecodeJobs& jobs, const std::string& path) {
+  start_decode(jobs, path);
+  return jobs[path].get();
+}
+// (a decode that nobody claimed — the config was rejected before its texture was reached — is freed here)
+struct DecodeJobsGuard {
+  DecodeJobs jobs;
+  std::map<std::string, bool> taken;
+  ~DecodeJobsGuard() {
+    for (auto& j : jobs)
+      if (!taken[j.first]) { Decoded d = j.second.get(); std::free(d.px); }
+  }
+};
+
 // materials.rs:213-219 / config.rs:36-47; `File::open(path).expect(path)` -> RT_ERR_TEXTURE
-uint32_t load_texture(RtSceneFile& sf, std::map<std::string, uint32_t>& cache, const std::string& path) {
+uint32_t load_texture(RtSceneFile& sf, std::map<std::string, uint32_t>& cache, DecodeJobsGuard& dj, const std::string& path) {
   auto it = cache.find(path);
   if (it != cache.end()) return it->second;
-  uint8_t* px = nullptr; uint32_t w = 0, h = 0;
-  int rc = rt_jpeg_decode_file(path.c_str(), &px, &w, &h);
-  if (rc != RT_OK) bad("texture " + path + ": " + rt_jpeg_last_error());
+  const Decoded d = take_decoded(dj.jobs, path);
+  dj.taken[path] = true;
+  if (d.rc != RT_OK) bad("texture " + path + ": " + d.err);
+  uint8_t* px = d.px; const uint32_t w = d.w, h = d.h;
   sf.pixel_store.emplace_back(px, std::free);
   RtTexture t{};
   t.rgb8 = px; t.nbytes = uint64_t(w) * h * 3; t.width = w; t.height = h;
@@ -149,6 +202,8 @@ void build_scene(const Value& root, RtSceneFile& sf) {
   sc.max_depth = uint32_t(as_u64(field(root, "max_depth", "Config"), "max_depth", 0x7FFFFFFFull));
 
   std::map<std::string, uint32_t> cache;
+  DecodeJobsGuard dj;
+  start_all_decodes(root, dj.jobs);
   // config.rs:22-28, 49-64: Option<Sky>; texture "" -> None
   const Value* sky = root.find("sky");
   sc.sky_mode = RT_SKY_NONE;
@@ -157,9 +212,13 @@ void build_scene(const Value& root, RtSceneFile& sf) {
     if (tex.kind != Value::String) bad("Sky.texture: expected a string");
     if (tex.text.empty()) sc.sky_mode = RT_SKY_GRADIENT;
     else {
-      uint8_t* px = nullptr; uint32_t w = 0, h = 0;
-      if (rt_jpeg_decode_file(tex.text.c_str(), &px, &w, &h) != RT_OK)
-        bad("sky texture " + tex.text + ": " + rt_jpeg_last_error());
+      // (the sky gets its own copy of the pixels even when a sphere uses the same file: separate owners)
+      Decoded d = take_decoded(dj.jobs, tex.text);
+      if (d.rc != RT_OK) bad("sky texture " + tex.text + ": " + d.err);
+      const uint32_t w = d.w, h = d.h;
+      uint8_t* px = static_cast<uint8_t*>(std::malloc(size_t(w) * h * 3));
+      if (!px) bad("sky texture " + tex.text + ": out of memory");
+      std::memcpy(px, d.px, size_t(w) * h * 3);
       sf.sky_pixels.reset(px);
       sf.sky_path = tex.text;
       sc.sky_mode = RT_SKY_TEXTURE; sc.sky_rgb8 = px; sc.sky_w = w; sc.sky_h = h;
@@ -205,7 +264,7 @@ void build_scene(const Value& root, RtSceneFile& sf) {
       s.tex_w = as_u64(field(body, "width", "Texture"), "Texture.width", ~0ull);
       s.tex_h = as_u64(field(body, "height", "Texture"), "Texture.height", ~0ull);
       s.h_offset = as_f64(field(body, "h_offset", "Texture"), "Texture.h_offset");
-      s.tex_id = load_texture(sf, cache, px.text);
+      s.tex_id = load_texture(sf, cache, dj, px.text);
     } else if (tag == "Light") {
       if (body.kind != Value::Object) bad("Light: expected {}");
       s.kind = RT_MAT_LIGHT;
