@@ -4,9 +4,10 @@
 // Shape (CDNA4-first):
 //   * persistent workgroups (one per CU, 16 waves) pull pixel TILES (8x8 ... 1x1, by frame size)
 //     from a global queue; a tile's samples are handed out to the workgroup's waves in small
-//     chunks through shared LDS slots and counted per tile, so the frame has no tail even though
-//     paths differ 50x in length, and a pixel's samples meet in LDS: the only HBM traffic of a
-//     frame is the framebuffer write;
+//     chunks through shared LDS slots and counted per tile, so tiles leave no tail of their own
+//     although paths differ 50x in length (what a frame ends on is the latency of its deepest
+//     paths), and a pixel's samples meet in LDS: the only HBM traffic of a frame is
+//     the framebuffer write; launch counters are summed per workgroup in LDS before they go out;
 //   * the scene tables a ray touches per segment — f64 sphere geometry, material cores, the
 //     uniform grid's cell words and item lists — are staged ONCE per workgroup into LDS and
 //     gathered from there by lane (ds_read_b64), never from HBM;
