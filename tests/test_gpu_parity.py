@@ -196,6 +196,25 @@ def test_degenerate_scenes(gpu_render, oracle, abi, host):
                     assert_parity(rgb, lin, o_rgb, o_lin, f"depth {depth} sky {sky} objs {len(objs)} variant {variant}")
 
 
+@pytest.mark.parametrize("w,h", [(1, 1), (1, 4), (5, 1)])
+def test_one_pixel_wide_or_high_frames(gpu_render, oracle, abi, host, w, h):
+    """width - 1 = 0 or height - 1 = 0: the reference divides by zero (raytracer.rs:199-200), every ray is
+    NaN/inf, every sample NaN, and palette turns the NaN pixel into 0.  The product's RGB8 is the same; its
+    diagnostic linear image holds 0 where the oracle's holds NaN (a NaN sample adds 0 to the fixed-point sum)."""
+    text = ('{"width":%d,"height":%d,"samples_per_pixel":3,"max_depth":5,"sky":{"texture":""},"camera":{"look_from":{"x":0.0,"y":0.0,"z":0.0},'
+            '"look_at":{"x":0.0,"y":0.0,"z":-1.0},"vup":{"x":0.0,"y":1.0,"z":0.0},"vfov":90.0,"aspect":1.8},"objects":['
+            '{"center":{"x":0.0,"y":0.0,"z":-1.0},"radius":0.5,"material":{"Lambertian":{"albedo":[0.8,0.3,0.3]}}}]}' % (w, h))
+    sc = host.Scene.loads(text)
+    o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+    assert np.isnan(o_lin).all() and not o_rgb.any()
+    for variant, pool in ((0, None), (1, None), (2, 0)):
+        rgb, lin, st = gpu_render(sc, variant=variant, pool=pool)
+        assert np.array_equal(rgb, o_rgb), (variant, rgb.ravel())
+        assert st["segments"] == o_st["segments"] == w * h * 3
+        if variant != 2:
+            assert not lin.any()
+
+
 def test_many_lights_nested_sampling(gpu_render, oracle, abi, host):
     """several lights + occluders: exercises the nested light-ray stack (raytracer.rs:103-110)"""
     objs = ['{"center":{"x":0.0,"y":-100.5,"z":-1.0},"radius":100.0,"material":{"Lambertian":{"albedo":[0.7,0.7,0.7]}}}']
