@@ -280,12 +280,19 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   // A tile's samples are handed out to the waves of its workgroup in chunks: an item's latency
   // is what the last wave of a frame waits for, but below ~128 samples per item the acquire /
   // finish overhead shows (measured, profiles/r01_run4_tiles.log): 8x8 -> 8 samples per pixel,
-  // 4x4 -> 16, 2x2 -> 32, 1x1 -> 128.
+  // 4x4 -> 16, 2x2 -> 32, 1x1 -> 128 — give or take a factor of two so that a frame has about 60
+  // items per wave (measured on the whole frame and its 1/2, 1/4, 1/8 shards, profiles/r01_run11_tiles.log:
+  // both fewer, larger items and more, smaller ones lose up to 5 %).
   const uint32_t spp = s->host.samples_per_pixel;
   uint32_t chunk_spp = (uint32_t)s->chunk_spp;
   if (chunk_spp == 0) {
     static const uint32_t by_tile[4] = {128u, 32u, 16u, 8u};
-    chunk_spp = by_tile[tl];
+    const uint64_t target_items = (uint64_t)s->num_cus * rtk::WAVES * 60u;
+    const uint64_t ideal = ((uint64_t)ka.n_tiles * spp + target_items / 2) / target_items;  // samples per pixel and item
+    uint32_t c = 1;
+    while ((uint64_t)c * 3u < ideal * 2u) c <<= 1;  // nearest power of two (geometric)
+    const uint32_t lo = by_tile[tl] / 2u, hi = by_tile[tl] * 2u;
+    chunk_spp = c < lo ? lo : (c > hi ? hi : c);
   }
   if (chunk_spp > spp || spp == 0) chunk_spp = spp ? spp : 1;
   ka.chunk_spp = chunk_spp;
