@@ -52,6 +52,8 @@ def lib(abi):
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.rt_oracle_draws.restype = None
         L.rt_oracle_threads.restype = C.c_int
+        L.rt_oracle_atan2.argtypes = [C.c_double, C.c_double]
+        L.rt_oracle_atan2.restype = C.c_double
         _LIB = L
     return _LIB
 

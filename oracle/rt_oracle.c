@@ -9,6 +9,8 @@
  * /root/reference/raytracer/src/).
  */
 #include "rt_oracle.h"
+/* the one atan2 shared with the kernel (see its header for why libm's cannot be used) */
+#include "../rust-raytracer_amd/csrc/common/rt_atan2.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -135,7 +137,7 @@ typedef struct {
 /* sphere.rs:35-43 */
 static void u_v_from_sphere_hit_point(P3 hp, double* u, double* v) {
   P3 n = p3_unit(hp);
-  *u = (atan2(n.x, n.z) / (2.0 * 3.14159265358979323846264338327950288)) + 0.5;
+  *u = (rt_atan2(n.x, n.z) / (2.0 * 3.14159265358979323846264338327950288)) + 0.5;
   *v = n.y * 0.5 + 0.5;
 }
 /* sphere.rs:46-78 */
@@ -175,6 +177,8 @@ int rt_oracle_sphere_hit(const double center[3], double radius, const double ori
   out[8] = h.u; out[9] = h.v;
   return hit;
 }
+
+double rt_oracle_atan2(double y, double x) { return rt_atan2(y, x); }
 
 /* raytracer.rs:44-59 */
 static int hit_world(Ctx* c, Ray r, double t_min, double t_max, HitRecord* best) {

@@ -45,6 +45,8 @@ void rt_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint3
 /* sphere.rs:46-78; returns 1 on hit. out = t, p[3], normal[3], front_face, u, v (10 doubles) */
 int rt_oracle_sphere_hit(const double center[3], double radius, const double origin[3],
                          const double dir[3], double t_min, double t_max, double out[10]);
+/* f64::atan2 of sphere.rs:39 as both sides evaluate it (rust-raytracer_amd/csrc/common/rt_atan2.h) */
+double rt_oracle_atan2(double y, double x);
 /* materials.rs:144-149 */
 void rt_oracle_refract(const double uv[3], const double n[3], double etai_over_etat, double out[3]);
 /* materials.rs:151-155 */

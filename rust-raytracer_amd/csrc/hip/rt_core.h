@@ -21,6 +21,11 @@
 #include "../../../include/rt_abi.h"
 
 #if defined(__HIPCC__)
+#define RT_ATAN2_FN __host__ __device__ inline
+#endif
+#include "../common/rt_atan2.h"  // the one atan2 kernel and CPU checker share (sphere.rs:39)
+
+#if defined(__HIPCC__)
 #define RT_HD __host__ __device__ __forceinline__
 // cold paths (texture lookups): a real call, so that their constants (atan2's polynomial) are
 // not hoisted into registers that stay live across the whole path loop
@@ -641,7 +646,7 @@ struct UV {
 RT_HD_COLD UV sphere_uv(V3 point, SphereGeom g) {  // by value: see exact_hit_slow
   V3 n = unit_vector(sub(point, v3(g.cx, g.cy, g.cz)));
   UV r;
-  r.u = (atan2(n.x, n.z) / (2.0 * 3.14159265358979323846264338327950288)) + 0.5;
+  r.u = (rt_atan2(n.x, n.z) / (2.0 * 3.14159265358979323846264338327950288)) + 0.5;
   r.v = n.y * 0.5 + 0.5;
   return r;
 }

@@ -691,7 +691,7 @@ __global__ void rt_math_probe(const double* x, const double* y, double* out_sqrt
   out_sqrt[i] = sqrt(x[i]);
   out_div[i] = x[i] / y[i];
   out_sqrtf[i] = __builtin_sqrtf((float)x[i]);
-  out_atan2[i] = atan2(x[i] - 0.5, y[i] - 0.5);
+  out_atan2[i] = rt_atan2(x[i] - 0.5, y[i] - 0.5);  // the shared routine (csrc/common/rt_atan2.h): must equal its CPU build bit for bit
 }
 
 // Sphere::hit on the device, one (ray, sphere) pair per thread, through the kernel's own hit test

@@ -23,12 +23,16 @@ struct Huff {
   uint8_t look_nbits[512];  // 9-bit fast lookup
   uint8_t look_sym[512];
   bool present = false;
-  void build() {
+  // false: the code lengths over-subscribe the code space (more than 2^l codes of length <= l) — such a
+  // table would index past the 9-bit lookup below; jpeg-decoder rejects it too
+  bool build() {
     int code = 0, k = 0;
     std::memset(look_nbits, 0, sizeof look_nbits);
+    present = false;
     for (int l = 1; l <= 16; ++l) {
       valptr[l] = k;
       mincode[l] = code;
+      if (code + int(bits[l]) > (1 << l)) return false;
       for (int i = 0; i < bits[l]; ++i, ++k, ++code) {
         if (l <= 9) {
           int base = code << (9 - l);
@@ -40,6 +44,7 @@ struct Huff {
     }
     maxcode[17] = 0x7fffffff;
     present = true;
+    return true;
   }
 };
 
@@ -226,12 +231,14 @@ struct Decoder {
           s += 16;
           if (total > 256 || s + total > se) return fail("bad DHT");
           std::memcpy(h.vals, s, total); s += total;
-          h.build();
+          if (!h.build()) return fail("bad DHT (over-subscribed code lengths)");
         }
       } else if (m == 0xC0 || m == 0xC1) {
+        if (L < 8) return fail("truncated SOF");
         if (s[0] != 8) return fail("only 8-bit JPEG supported");
         height = be16(s + 1); width = be16(s + 3); ncomp = s[5];
         if (!(ncomp == 1 || ncomp == 3) || width <= 0 || height <= 0) return fail("unsupported component count");
+        if (L < 8 + 3 * ncomp) return fail("truncated SOF");
         hmax = vmax = 1;
         for (int c = 0; c < ncomp; ++c) {
           comp[c].id = s[6 + 3 * c]; comp[c].h = s[7 + 3 * c] >> 4; comp[c].v = s[7 + 3 * c] & 15;
@@ -247,15 +254,21 @@ struct Decoder {
         }
         sof_seen = true;
       } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-        return fail("progressive / lossless / arithmetic JPEG not supported");
+        char what[192];
+        std::snprintf(what, sizeof what, "JPEG frame type SOF%d (%s) not supported: baseline / extended-sequential Huffman only",
+                      m - 0xC0, m == 0xC2 ? "progressive" : (m >= 0xC9 ? "arithmetic coding" : "lossless / differential"));
+        return fail(what);
       } else if (m == 0xDD) {
+        if (L < 4) return fail("truncated DRI");
         restart_interval = be16(s);
       } else if (m == 0xEE && L >= 14 && std::memcmp(s, "Adobe", 5) == 0) {
         adobe = true; adobe_transform = s[11];
       } else if (m == 0xDA) {
         if (!sof_seen) return fail("SOS before SOF");
+        if (L < 3) return fail("truncated SOS");
         int ns = s[0];
-        if (ns != ncomp) return fail("non-interleaved scans not supported");
+        if (ns != ncomp) return fail("non-interleaved (multi-scan) baseline JPEG not supported");
+        if (L < 6 + 2 * ns) return fail("truncated SOS");
         for (int i = 0; i < ns; ++i) {
           int cid = s[1 + 2 * i], tbl = s[2 + 2 * i];
           int c = -1;

@@ -125,6 +125,19 @@ def jpeg_decode(path):
         lib().rt_free(px)
 
 
+def jpeg_decode_mem(data):
+    """rt_jpeg_decode_mem: bytes -> numpy [h,w,3]; raises RtError(RT_ERR_TEXTURE) on anything malformed"""
+    import numpy as np
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    px = C.POINTER(C.c_uint8)()
+    w, h = C.c_uint32(), C.c_uint32()
+    _check(lib().rt_jpeg_decode_mem(buf, len(data), C.byref(px), C.byref(w), C.byref(h)))
+    try:
+        return np.ctypeslib.as_array(px, shape=(h.value, w.value, 3)).copy()
+    finally:
+        lib().rt_free(px)
+
+
 def png_write(path, rgb8):
     import numpy as np
     a = np.ascontiguousarray(rgb8, dtype=np.uint8)

@@ -127,3 +127,89 @@ def test_png_write_roundtrip(host, tmp_path):
     host.png_write(p, img)
     back = Image.open(p)
     assert back.mode == "RGB" and back.size == (53, 37) and np.array_equal(np.asarray(back), img)
+
+
+def _baseline_jpeg(w=40, h=24, subsampling=2, restart=0):
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    img = Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+    b = io.BytesIO()
+    kw = dict(restart_marker_blocks=restart) if restart else {}
+    img.save(b, "JPEG", quality=80, subsampling=subsampling, progressive=False, optimize=False, **kw)
+    return b.getvalue()
+
+
+def _segments(data):
+    """[(marker, offset of 0xFF, segment length incl. the 2 length bytes)] up to SOS"""
+    out, p = [], 2
+    while p + 4 <= len(data):
+        assert data[p] == 0xFF
+        m, L = data[p + 1], (data[p + 2] << 8) | data[p + 3]
+        out.append((m, p, L))
+        if m == 0xDA:
+            break
+        p += 2 + L
+    return out
+
+
+def test_malformed_jpeg_is_rejected_not_overrun(host, abi):
+    """a crafted texture must fail with RT_ERR_TEXTURE like jpeg-decoder's Err (materials.rs:214-217
+    then panics on it), never write or read out of bounds: over-subscribed DHT code lengths, SOF / SOS / DRI segments
+    shorter than the fields read from them, truncated files, and random byte flips."""
+    good = _baseline_jpeg()
+    assert host.jpeg_decode_mem(good).shape == (24, 40, 3)
+    segs = _segments(good)
+    kinds = {m for m, _, _ in segs}
+    assert {0xC0, 0xC4, 0xDA, 0xDB} <= kinds
+
+    def expect_fail(data, what):
+        with pytest.raises(host.RtError) as e:
+            host.jpeg_decode_mem(bytes(data))
+        assert e.value.code == abi.RT_ERR_TEXTURE, what
+
+    # (1) over-subscribed Huffman table: 255 codes of length 1 (the r1 decoder wrote ~64 KB past a 512-byte array)
+    m, p, L = next(s for s in segs if s[0] == 0xC4)
+    bad = bytearray(good)
+    bad[p + 5] = 255                       # bits[1] of the first table
+    expect_fail(bad, "over-subscribed DHT")
+    bad = bytearray(good)
+    bad[p + 5 + 1] = 5                     # 5 codes of length 2 (> 4 possible)
+    expect_fail(bad, "over-subscribed DHT, length 2")
+    # (2) segments declared shorter than the fields the parser reads from them
+    for marker, short in ((0xC0, 4), (0xC0, 9), (0xDA, 2), (0xDA, 4)):
+        m, p, L = next(s for s in segs if s[0] == marker)
+        bad = bytearray(good[:p + 2]) + bytes([0, short]) + bytearray(good[p + 4:p + 2 + short]) + bytearray(good[p + 2 + L:])
+        expect_fail(bad, f"short segment {marker:#x} L={short}")
+    # a DRI segment with no payload, placed before SOS
+    m, p, L = next(s for s in segs if s[0] == 0xDA)
+    expect_fail(good[:p] + bytes([0xFF, 0xDD, 0, 2]) + good[p:], "empty DRI")
+    # (3) truncations: any prefix either fails cleanly or (entropy data cut short) decodes with zero-filled bits
+    for cut in list(range(0, 64)) + list(range(64, len(good), 37)):
+        try:
+            host.jpeg_decode_mem(good[:cut])
+        except host.RtError as e:
+            assert e.code == abi.RT_ERR_TEXTURE
+    # (4) random corruption of the headers and the scan, with and without restart markers / subsampling
+    rng = np.random.default_rng(11)
+    for base in (good, _baseline_jpeg(33, 17, 0), _baseline_jpeg(48, 32, 1, restart=2)):
+        for _ in range(400):
+            bad = bytearray(base)
+            for _ in range(int(rng.integers(1, 6))):
+                bad[int(rng.integers(2, len(bad)))] = int(rng.integers(0, 256))
+            try:
+                out = host.jpeg_decode_mem(bytes(bad))
+                assert out.ndim == 3 and out.shape[2] == 3
+            except host.RtError as e:
+                assert e.code == abi.RT_ERR_TEXTURE
+
+
+def test_unsupported_jpeg_kinds_say_so(host, abi):
+    """progressive JPEGs name their frame type in the error (jpeg-decoder would decode them; documented limit)"""
+    import io
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(np.zeros((16, 16, 3), np.uint8)).save(b, "JPEG", progressive=True)
+    with pytest.raises(host.RtError) as e:
+        host.jpeg_decode_mem(b.getvalue())
+    assert e.value.code == abi.RT_ERR_TEXTURE
