@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2u
+#define RT_ABI_VERSION 3u /* v3: RtScene.n_gpus, RtStats.{segments_discarded, n_gpus_used, gather_ms, setup_ms}, rt_abi_sizeof */
 
 /* Nested light-ray recursion (raytracer.rs:103-110 calls ray_color(.., 2, 1), which can
  * itself trigger light sampling again) is unbounded in the reference.  Oracle and kernel
@@ -99,6 +99,10 @@ typedef struct RtScene {
   uint32_t n_textures;
   const RtTexture* textures;
   uint64_t seed; /* Philox key; replaces rand::thread_rng (raytracer.rs:78,192) */
+  uint32_t n_gpus;   /* rt_render_rgb8 only: GPUs to shard the frame over by interleaved scanline tiles;
+                      * 0 = the RT_GPUS environment variable, else 1.  More than rt_hip_device_count()
+                      * is RT_ERR_INVALID.  The frame is bit-identical for every value. */
+  uint32_t reserved0;
 } RtScene;
 
 /* Which scanline tiles to render.  Tile k covers rows [k*tile_rows, (k+1)*tile_rows).
@@ -128,6 +132,16 @@ typedef struct RtStats {
    * -DRT_PROFILE (tools/ab_bench.py "prof" arm): [0] sample refill, [1] `large` list,
    * [2] lane_shade, [3] grid entry + walk, [4] pixel sums + tile bookkeeping, [5] item fetch, [6] whole wave */
   uint64_t prof_cycles[12]; /* ... [7] longest wave, [8] shortest wave, [10] waves launched */
+  /* CPU oracle only (0 from the GPU): segments traced inside the light loop of a hit on a Light sphere,
+   * whose sum raytracer.rs:124 throws away (`None => albedo`).  The kernel does not trace them:
+   * kernel.segments == oracle.segments - oracle.segments_discarded, exactly. */
+  uint64_t segments_discarded;
+  uint32_t n_gpus_used; /* rt_render_rgb8: devices the frame was sharded over (1 elsewhere) */
+  uint32_t reserved0;
+  double gather_ms; /* rt_render_rgb8, n_gpus_used > 1: end of the slowest rank's kernel -> frame assembled on device 0 */
+  double setup_ms;  /* rt_render_rgb8: HIP context + table build + scene upload, NOT part of frame_ms
+                     * (frame_ms is the window the reference times, raytracer.rs:259-263: the parallel loop
+                     * until the pixels are in the caller's buffer) */
 } RtStats;
 
 /* rows this call renders (its packed RGB8 output is rows*width*3 bytes) */
@@ -183,6 +197,12 @@ void rt_free(void*);
  * ---------------------------------------------------------------------------------- */
 typedef struct RtHipScene RtHipScene; /* scene tables + textures resident in HBM on one GPU */
 
+/* Layout check for foreign-language bindings: sizeof of "RtSphere", "RtTexture",
+ * "RtScene", "RtRowTiles", "RtStats" as THIS library was compiled, 0 for an unknown name.  A binding
+ * compares them with its own struct sizes once at start-up; rt_abi_version() returns RT_ABI_VERSION. */
+size_t rt_abi_sizeof(const char* struct_name);
+uint32_t rt_abi_version(void);
+
 int rt_hip_device_count(void);
 const char* rt_hip_last_error(void);
 /* Upload scene tables, textures and sky to HBM of `device`.  The caller may free the
@@ -190,10 +210,20 @@ const char* rt_hip_last_error(void);
 int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene** out);
 void rt_hip_scene_destroy(RtHipScene*);
 /* Launch the megakernel for the given row tiles on `stream` (a hipStream_t, NULL = default).
- *   d_rgb8    device buffer, rt_tiles_local_rows()*width*3 bytes, packed, top row first
+ *   d_rgb8    device buffer, rt_tiles_local_rows()*width*3 bytes, packed, top row first;
+ *             4-byte aligned (any hipMalloc'd buffer is)
  *   d_linear  optional device buffer of 3 floats per pixel: mean radiance before the
  *             sqrt gamma (raytracer.rs:207-212) — what the parity tests compare
- * Asynchronous: returns after enqueueing.  Inputs are already in HBM. */
+ * Asynchronous: returns after enqueueing.  Inputs are already in HBM.
+ * Limits (all return RT_ERR_* instead of misbehaving):
+ *   - NOT re-entrant per scene: an RtHipScene owns ONE tile-queue cursor, counter block and event pair.
+ *     Launches of one scene must be ordered on ONE stream at a time (back-to-back launches on the same
+ *     stream are fine; rt_hip_wait then reports the last one).  Launching on a second stream before
+ *     rt_hip_wait() returned for the first is RT_ERR_INVALID.  Use one RtHipScene per concurrent stream
+ *     (tables are ~100 KB + textures); distinct scenes and distinct devices are fully independent.
+ *   - frames wider than 524 280 pixels or with more than 2^31 pixel tiles are RT_ERR_UNSUPPORTED.
+ *   - any sphere count is accepted; above 65 535 spheres the uniform grid (u16 item lists) is not
+ *     built and every ray tests every sphere, like the reference (raytracer.rs:52-57). */
 int rt_hip_render(RtHipScene*, const RtRowTiles* tiles, void* d_rgb8, void* d_linear, void* stream);
 /* Block until the last rt_hip_render on this scene finished; fill counters and the HIP-event
  * duration of its kernel (events are recorded on the stream the kernel was launched on). */
@@ -212,10 +242,10 @@ int rt_hip_math_probe(const double* x, const double* y, double* out_sqrt, double
                       uint32_t n, void* stream);
 int rt_hip_hit_probe(const double* rays, const double* spheres, double* out_t, uint32_t n, void* stream);
 /* Tunables / A-B arms.  Keys: "variant" 0 = grid walk (default), 1 = the
- * reference's brute force (exact test on every sphere), 2 = round-1 f32 cull-scan kernel;
+ * reference's brute force (exact test on every sphere);
  * "chunk_spp" samples of a pixel per work item (0 = automatic); "tile_log2" pixel tiles of
- * 2^k x 2^k (k = 0..3, -1 = automatic); "samples_per_pixel",
- * "max_depth", "seed" override the scene's values. */
+ * 2^k x 2^k (k = 0..3, -1 = automatic); "samples_per_pixel", "max_depth" (0 .. 2^32-1) and
+ * "seed" override the scene's values.  Out-of-range values are RT_ERR_INVALID. */
 int rt_hip_set_option(RtHipScene*, const char* key, int64_t value);
 /* Animation (the reference's `anim/frame_%03d.png` workflow, README.md:43-57, main.rs:17): move the
  * camera of a resident scene — the four vectors of camera.rs:52-63 — without touching its tables,
@@ -223,8 +253,25 @@ int rt_hip_set_option(RtHipScene*, const char* key, int64_t value);
 int rt_hip_set_camera(RtHipScene*, const double origin[3], const double lower_left[3], const double horizontal[3],
                       const double vertical[3]);
 int rt_hip_render_to_host(RtHipScene*, uint8_t* out_rgb8, RtStats* stats);
-/* Convenience = the drop-in for render()'s parallel loop: host buffers in, host RGB8 out.
- * Blocking; uploads, renders the whole frame on device 0, downloads. */
+/* A frame over the GPUs of one node, scene resident (the parallel loop of raytracer.rs:254-262 spread over devices;
+ * animation: README.md:43-57).  n_gpus = 0 takes scene->n_gpus, then RT_GPUS, then 1.  Each rank renders
+ * interleaved 2-scanline tiles (RtRowTiles{2, r, G}) on its own host thread and stream; ONE gather per frame
+ * (RCCL `ncclGather` over xGMI, or peer copies with RT_GATHER=peer) brings the packed tiles to device 0,
+ * a kernel puts the scanlines in order, ONE device-to-host copy delivers them.  Bit-identical for every G.
+ * stats: counters summed over ranks, kernel_ms = slowest rank, frame_ms = the whole call, gather_ms. */
+typedef struct RtHipGroup RtHipGroup;
+int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipGroup** out);
+void rt_hip_group_destroy(RtHipGroup*);
+uint32_t rt_hip_group_size(const RtHipGroup*);
+int rt_hip_group_set_camera(RtHipGroup*, const double origin[3], const double lower_left[3], const double horizontal[3],
+                            const double vertical[3]);
+int rt_hip_group_set_option(RtHipGroup*, const char* key, int64_t value);
+int rt_hip_group_render_to_host(RtHipGroup*, uint8_t* out_rgb8, RtStats* stats);
+/* Convenience = the drop-in for render()'s parallel loop (raytracer.rs:254-262): host buffers in,
+ * host RGB8 out.  Blocking.  Renders on scene->n_gpus devices (see RtScene.n_gpus / RT_GPUS): the scene
+ * is replicated, device r renders scanline tiles r, r+G, ... (2 rows each) on its own host thread and
+ * stream, the packed tiles meet on device 0 through ONE gather (RCCL send/recv over xGMI, or peer copies
+ * with RT_GATHER=peer), are de-interleaved by a small kernel and leave in ONE device-to-host copy. */
 int rt_render_rgb8(const RtScene* scene, uint8_t* out_rgb8, RtStats* stats);
 const char* rt_strerror(int code);
 

@@ -86,6 +86,10 @@ typedef struct {
   uint32_t n_lights;
   uint32_t pixel, sample;
   uint64_t segments, tex_oob;
+  /* bookkeeping only (no effect on the image): > 0 while tracing light rays whose sum the caller will
+   * throw away (raytracer.rs:124) — the GPU kernel skips exactly those segments */
+  uint32_t discarding;
+  uint64_t segments_discarded;
 } Ctx;
 
 static void rng_words(const Ctx* c, uint32_t node, uint32_t slot, uint32_t w[4]) {
@@ -186,6 +190,7 @@ static int hit_world(Ctx* c, Ray r, double t_min, double t_max, HitRecord* best)
   double closest_so_far = t_max;
   int any = 0;
   c->segments++;
+  if (c->discarding) c->segments_discarded++;
   for (uint32_t i = 0; i < sc->n_spheres; ++i) {
     const RtSphere* s = &sc->spheres[i];
     HitRecord h;
@@ -329,6 +334,7 @@ static Rgb ray_color(Ctx* c, Ray ray, uint32_t max_depth, uint32_t depth, uint32
     if (c->n_lights > 0 && depth_ok && nest < RT_MAX_LIGHT_NEST) {
       uint32_t w[4]; rng_words(c, node, 0, w);
       if (u01_53(w[2], w[3]) > (1.0 - (double)c->n_lights * prob)) {
+        if (st == SCATTER_EMIT) c->discarding++;  /* (counter only: :124 returns `albedo`, not the light sum) */
         for (uint32_t j = 0; j < c->n_lights; ++j) {                                    /* :103-110 */
           const RtSphere* light = &sc->spheres[c->lights[j]];
           Ray light_ray = {rec.point, p3_sub(p3(light->center[0], light->center[1], light->center[2]), rec.point)};
@@ -340,6 +346,7 @@ static Rgb ray_color(Ctx* c, Ray ray, uint32_t max_depth, uint32_t depth, uint32
         light_red /= (float)c->n_lights;                                                /* :111-113 */
         light_green /= (float)c->n_lights;
         light_blue /= (float)c->n_lights;
+        if (st == SCATTER_EMIT) c->discarding--;
       }
     }
     if (st == SCATTER_RAY) {                                                            /* :116-123 */
@@ -478,20 +485,20 @@ int rt_oracle_render(const RtScene* scene, const RtRowTiles* tiles, uint8_t* rgb
   rt_oracle_find_lights(scene->spheres, scene->n_spheres, lights, n_lights);
   const uint32_t rows = rt_tiles_local_rows(scene->height, tiles);
   const size_t row_elems = (size_t)scene->width * 3;
-  uint64_t segments = 0, tex_oob = 0;
+  uint64_t segments = 0, tex_oob = 0, discarded = 0;
 #ifdef _OPENMP
   if (n_threads <= 0) n_threads = omp_get_max_threads();
 #else
   n_threads = 1;
 #endif
   double t0 = now_ms();
-#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : segments, tex_oob)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : segments, tex_oob, discarded)
   for (uint32_t lr = 0; lr < rows; ++lr) {
     Ctx c; memset(&c, 0, sizeof c);
     c.scene = scene; c.lights = lights; c.n_lights = n_lights;
     uint32_t y = rt_tiles_global_row(tiles, lr);
     render_line(&c, y, rgb8 ? rgb8 + lr * row_elems : NULL, linear ? linear + lr * row_elems : NULL);
-    segments += c.segments; tex_oob += c.tex_oob;
+    segments += c.segments; tex_oob += c.tex_oob; discarded += c.segments_discarded;
   }
   double t1 = now_ms();
   free(lights);
@@ -505,6 +512,8 @@ int rt_oracle_render(const RtScene* scene, const RtRowTiles* tiles, uint8_t* rgb
     stats->kernel_ms = t1 - t0;
     stats->frame_ms = t1 - t0;
     stats->grid_steps = 0; /* the reference has no acceleration structure (raytracer.rs:52-57) */
+    stats->segments_discarded = discarded;
+    stats->n_gpus_used = 0;
   }
   return RT_OK;
 }

@@ -12,7 +12,9 @@
 #include <vector>
 
 #include "rt_kernel.hip"
+#ifdef RT_WITH_SCAN_KERNEL  // A/B builds only (tools/ab_bench.py): the round-1 cull-scan kernel as "variant" 2
 #include "rt_kernel_scan.hip"
+#endif
 #include "rt_tables.h"
 
 namespace {
@@ -52,6 +54,7 @@ struct RtHipScene {
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   hipStream_t last_stream = nullptr;
   bool launched = false;
+  bool in_flight = false;  // a launch has been enqueued and rt_hip_wait has not returned for it yet
   uint32_t last_rows = 0;
   uint64_t last_waves = 0;
   int variant = 0;
@@ -60,6 +63,17 @@ struct RtHipScene {
 };
 
 extern "C" const char* rt_hip_last_error(void) { return g_err.c_str(); }
+
+extern "C" uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+extern "C" size_t rt_abi_sizeof(const char* name) {
+  if (!name) return 0;
+  if (!std::strcmp(name, "RtSphere")) return sizeof(RtSphere);
+  if (!std::strcmp(name, "RtTexture")) return sizeof(RtTexture);
+  if (!std::strcmp(name, "RtScene")) return sizeof(RtScene);
+  if (!std::strcmp(name, "RtRowTiles")) return sizeof(RtRowTiles);
+  if (!std::strcmp(name, "RtStats")) return sizeof(RtStats);
+  return 0;
+}
 
 extern "C" const char* rt_strerror(int code) {
   switch (code) {
@@ -112,7 +126,6 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   rtc::HostTables t;
   std::string why = rtc::build_tables(*scene, t);
   if (!why.empty()) return fail(RT_ERR_INVALID, why);
-  if (scene->n_spheres > 65535u) return fail(RT_ERR_UNSUPPORTED, "more than 65535 spheres (u16 candidate lists)");
   RT_HIP_TRY(hipSetDevice(device));
   RtHipScene* s = new RtHipScene;
   s->device = device;
@@ -171,17 +184,27 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
 
 extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) {
   if (!s || !key) return fail(RT_ERR_INVALID, "null argument");
-  if (!std::strcmp(key, "variant")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "variant must be 0, 1 or 2"); s->variant = (int)value; return RT_OK; }
+#ifdef RT_WITH_SCAN_KERNEL
+  constexpr int64_t max_variant = 2;
+#else
+  constexpr int64_t max_variant = 1;
+#endif
+  if (!std::strcmp(key, "variant")) { if (value < 0 || value > max_variant) return fail(RT_ERR_INVALID, "variant must be 0 (grid walk) or 1 (brute force)"); s->variant = (int)value; return RT_OK; }
   if (!std::strcmp(key, "pool")) { s->pool = value != 0; return RT_OK; }
   if (!std::strcmp(key, "tile_log2")) { if (value < -1 || value > 3) return fail(RT_ERR_INVALID, "tile_log2 must be -1..3"); s->tile_log2 = (int)value; return RT_OK; }
   if (!std::strcmp(key, "chunk_spp")) { if (value < 0) return fail(RT_ERR_INVALID, "chunk_spp must be >= 0"); s->chunk_spp = (int)value; return RT_OK; }
-  if (!std::strcmp(key, "samples_per_pixel")) { s->host.samples_per_pixel = s->dev.spp = (uint32_t)value; return RT_OK; }
-  if (!std::strcmp(key, "max_depth")) { s->host.max_depth = s->dev.max_depth = (uint32_t)value; return RT_OK; }
+  if (!std::strcmp(key, "samples_per_pixel") || !std::strcmp(key, "max_depth")) {
+    if (value < 0 || value > (int64_t)0xFFFFFFFFll) return fail(RT_ERR_INVALID, std::string(key) + " must be in 0 .. 2^32-1");
+    if (key[0] == 's') s->host.samples_per_pixel = s->dev.spp = (uint32_t)value;
+    else s->host.max_depth = s->dev.max_depth = (uint32_t)value;
+    return RT_OK;
+  }
   if (!std::strcmp(key, "seed")) { s->host.seed = (uint64_t)value; s->dev.seed_lo = (uint32_t)value; s->dev.seed_hi = (uint32_t)((uint64_t)value >> 32); return RT_OK; }
   return fail(RT_ERR_INVALID, std::string("unknown option ") + key);
 }
 
 namespace {
+#ifdef RT_WITH_SCAN_KERNEL
 // legacy arm (variant 2): the round-1 cull-scan kernel, one workgroup per 16x16 tile
 int launch_scan(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb8, void* d_linear, hipStream_t stream, uint32_t local_rows) {
   rtk_scan::KArgs ka;
@@ -204,6 +227,7 @@ int launch_scan(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb8, void* d_li
 #undef RT_LAUNCH
   return RT_OK;
 }
+#endif  // RT_WITH_SCAN_KERNEL
 
 template <bool HL, bool SIMPLE, bool LDS>
 int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka, size_t lds_bytes, uint32_t n_items, hipStream_t stream) {
@@ -233,21 +257,30 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   const uint32_t local_rows = rt_tiles_local_rows(s->host.height, tiles);
   if (!d_rgb8 && local_rows != 0) return fail(RT_ERR_INVALID, "null framebuffer");
   hipStream_t stream = (hipStream_t)stream_;
+  // one tile-queue cursor / counter block / event pair per scene: launches of a scene are ordered on ONE stream
+  if (s->in_flight && stream != s->last_stream)
+    return fail(RT_ERR_INVALID, "rt_hip_render: this scene has a launch in flight on another stream (call rt_hip_wait first, "
+                                "or use one RtHipScene per concurrent stream)");
+  // the exact pixel sums are 2^-40 fixed point in 64 bits: spp * 2^40 must stay below 2^63
+  if (s->host.samples_per_pixel > (1u << 22)) return fail(RT_ERR_UNSUPPORTED, "more than 2^22 samples per pixel");
+  if (s->host.width > 524280u) return fail(RT_ERR_UNSUPPORTED, "frames wider than 524280 pixels");
   RT_HIP_TRY(hipSetDevice(s->device));
   s->last_rows = local_rows;
   s->last_stream = stream;
   s->t_launch = std::chrono::steady_clock::now();
   RT_HIP_TRY(hipMemsetAsync(s->d_counters, 0, 32 * sizeof(unsigned long long), stream));
   if (local_rows == 0) { s->launched = false; return RT_OK; }
+#ifdef RT_WITH_SCAN_KERNEL
   if (s->variant == 2) {
     RT_HIP_TRY(hipEventRecord(s->ev_start, stream));
     int rc = launch_scan(s, tiles, d_rgb8, d_linear, stream, local_rows);
     if (rc != RT_OK) return rc;
     RT_HIP_TRY(hipGetLastError());
     RT_HIP_TRY(hipEventRecord(s->ev_stop, stream));
-    s->launched = true;
+    s->launched = true; s->in_flight = true;
     return RT_OK;
   }
+#endif
 
   rtk::KArgs ka;
   ka.sc = s->dev;
@@ -273,6 +306,12 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
     tl = 3;
     while (tl > 0 && (uint64_t)((s->host.width + (1u << tl) - 1) >> tl) * ((local_rows + (1u << tl) - 1) >> tl) < want_tiles) tl--;
   }
+  // a slot header packs (tile column | tile row << 16), and the queue cursor is 32 bits
+  while (tl < 3 && (((s->host.width + (1u << tl) - 1) >> tl) > 65535u || ((local_rows + (1u << tl) - 1) >> tl) > 65535u ||
+                    (uint64_t)((s->host.width + (1u << tl) - 1) >> tl) * ((local_rows + (1u << tl) - 1) >> tl) >= (1ull << 31))) tl++;
+  if (((s->host.width + (1u << tl) - 1) >> tl) > 65535u || ((local_rows + (1u << tl) - 1) >> tl) > 65535u ||
+      (uint64_t)((s->host.width + (1u << tl) - 1) >> tl) * ((local_rows + (1u << tl) - 1) >> tl) >= (1ull << 31))
+    return fail(RT_ERR_UNSUPPORTED, "frame too large for the tile queue (more than 65535 tiles on an axis or 2^31 tiles)");
   ka.tile_log2 = tl;
   ka.t_slots = rtk::tile_slots(tl);
   ka.tiles_x = (s->host.width + (1u << tl) - 1) >> tl;
@@ -311,7 +350,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   if (rc != RT_OK) return rc;
   RT_HIP_TRY(hipGetLastError());
   RT_HIP_TRY(hipEventRecord(s->ev_stop, stream));
-  s->launched = true;
+  s->launched = true; s->in_flight = true;
   return RT_OK;
 }
 
@@ -328,8 +367,10 @@ extern "C" int rt_hip_wait(RtHipScene* s, RtStats* stats) {
   if (!s) return fail(RT_ERR_INVALID, "null argument");
   RT_HIP_TRY(hipSetDevice(s->device));
   RT_HIP_TRY(hipStreamSynchronize(s->last_stream));
+  s->in_flight = false;
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
+    stats->n_gpus_used = 1;
     unsigned long long c[20] = {0};  // segments, exact tests, tex_oob, grid steps, 4 x wave trip counts, 8 x section cycles, profile clocks
     RT_HIP_TRY(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
     float ms = 0.f;
@@ -387,28 +428,7 @@ extern "C" int rt_hip_render_to_host(RtHipScene* s, uint8_t* out_rgb8, RtStats* 
   return RT_OK;
 }
 
-// drop-in for the parallel loop of render() (raytracer.rs:254-263): host scene in, host RGB8 out
-extern "C" int rt_render_rgb8(const RtScene* scene, uint8_t* out_rgb8, RtStats* stats) {
-  if (!scene || !out_rgb8) return fail(RT_ERR_INVALID, "null argument");
-  auto t0 = std::chrono::steady_clock::now();
-  RtHipScene* s = nullptr;
-  int rc = rt_hip_scene_create(scene, 0, &s);
-  if (rc != RT_OK) return rc;
-  const size_t bytes = (size_t)scene->width * scene->height * 3;
-  void* d_out = nullptr;
-  if (hipMalloc(&d_out, bytes) != hipSuccess) { rt_hip_scene_destroy(s); return fail(RT_ERR_HIP, "hipMalloc(framebuffer) failed"); }
-  rc = rt_hip_render(s, nullptr, d_out, nullptr, nullptr);
-  RtStats st;
-  if (rc == RT_OK) rc = rt_hip_wait(s, &st);
-  if (rc == RT_OK && hipMemcpy(out_rgb8, d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RT_ERR_HIP, "hipMemcpy(framebuffer) failed");
-  (void)hipFree(d_out);
-  rt_hip_scene_destroy(s);
-  if (rc == RT_OK && stats) {
-    *stats = st;
-    stats->frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  }
-  return rc;
-}
+#include "rt_hip_group.hip"  // rt_hip_group_* and rt_render_rgb8: the frame over 1..G devices
 
 // math self-test hook (see rtk::rt_math_probe); all pointers are DEVICE pointers
 extern "C" int rt_hip_hit_probe(const double* rays, const double* spheres, double* out_t, uint32_t n, void* stream) {

@@ -4,6 +4,10 @@
 // (unreadable / unparsable config, texture or PNG failure) this prints the same message to
 // stderr and exits 101, the exit status of a Rust panic.
 //
+// `Frame time` is the window the reference times (raytracer.rs:259-263: the parallel loop until the pixels are in the
+// host buffer) — HIP start-up, table build and scene upload happen before it and are reported under RT_STATS=1.
+// RT_GPUS=N (or "n_gpus" in RtScene) shards the frame over N GPUs inside librt_hip.so (rt_hip_group_*).
+//
 // Superset (SURVEY §8f "animation driver"): `raytracer <config_file> <output_prefix> --frames N
 // [--orbit DEG]` renders N frames to `<output_prefix>_%03d.png` — the file naming main.rs:17
 // keeps commented out and README.md:43-57 / "Make animation" feed to ffmpeg — turning the camera
@@ -23,8 +27,8 @@
 namespace {
 int animate(RtSceneFile* sf, const char* prefix, int frames, double orbit_deg) {
   RtScene* sc = rt_scene_get_mut(sf);
-  RtHipScene* hs = nullptr;
-  int rc = rt_hip_scene_create(sc, 0, &hs);
+  RtHipGroup* hs = nullptr;  // the scene resident on RT_GPUS devices (default 1)
+  int rc = rt_hip_group_create(sc, 0, &hs);
   if (rc != RT_OK) { std::fprintf(stderr, "render failed: %s: %s\n", rt_strerror(rc), rt_hip_last_error()); return 101; }
   double cam[11];
   rt_scene_camera(sf, cam);
@@ -45,12 +49,12 @@ int animate(RtSceneFile* sf, const char* prefix, int frames, double orbit_deg) {
     double from[3], out[13];
     for (int i = 0; i < 3; ++i) from[i] = la[i] + v[i] * c + kx[i] * s + k[i] * kv * (1.0 - c);
     rt_camera_derive(from, la, up, cam[9], cam[10], out);
-    rt_hip_set_camera(hs, out, out + 3, out + 6, out + 9);
+    rt_hip_group_set_camera(hs, out, out + 3, out + 6, out + 9);
     char name[4096];
     std::snprintf(name, sizeof name, "%s_%03d.png", prefix, f);  // main.rs:17
     std::printf("\nRendering %s\n", name);
     RtStats st{};
-    rc = rt_hip_render_to_host(hs, buf[f & 1].data(), &st);
+    rc = rt_hip_group_render_to_host(hs, buf[f & 1].data(), &st);
     if (rc != RT_OK) { std::fprintf(stderr, "render failed: %s: %s\n", rt_strerror(rc), rt_hip_last_error()); status = 101; break; }
     std::printf("Frame time: %lldms\n", (long long)st.frame_ms);
     if (writer.joinable()) writer.join();
@@ -61,7 +65,7 @@ int animate(RtSceneFile* sf, const char* prefix, int frames, double orbit_deg) {
     writer = std::thread([fname, px, w, h, &write_rc]() { write_rc = rt_png_write_rgb8(fname.c_str(), px, w, h); });
   }
   if (writer.joinable()) writer.join();
-  rt_hip_scene_destroy(hs);
+  rt_hip_group_destroy(hs);
   if (write_rc != RT_OK) { std::fprintf(stderr, "error writing image: %s\n", rt_host_last_error()); status = 101; }
   return status;
 }
@@ -105,9 +109,11 @@ int main(int argc, char** argv) {
   }
   std::printf("Frame time: %lldms\n", (long long)st.frame_ms);  // raytracer.rs:263
   if (std::getenv("RT_STATS"))
-    std::fprintf(stderr, "{\"samples\":%llu,\"segments\":%llu,\"sphere_tests\":%llu,\"exact_tests\":%llu,\"kernel_ms\":%.3f,\"frame_ms\":%.3f,\"msamples_per_s\":%.3f}\n",
+    std::fprintf(stderr, "{\"samples\":%llu,\"segments\":%llu,\"sphere_tests\":%llu,\"exact_tests\":%llu,\"n_gpus\":%u,\"kernel_ms\":%.3f,"
+                         "\"gather_ms\":%.3f,\"frame_ms\":%.3f,\"setup_ms\":%.3f,\"msamples_per_s\":%.3f}\n",
                  (unsigned long long)st.samples, (unsigned long long)st.segments, (unsigned long long)st.sphere_tests,
-                 (unsigned long long)st.exact_tests, st.kernel_ms, st.frame_ms, st.samples / (st.kernel_ms * 1e3));
+                 (unsigned long long)st.exact_tests, st.n_gpus_used, st.kernel_ms, st.gather_ms, st.frame_ms, st.setup_ms,
+                 st.samples / (st.kernel_ms * 1e3));
   rc = rt_png_write_rgb8(filename, pixels.data(), sc->width, sc->height);  // raytracer.rs:265
   rt_scene_free(sf);
   if (rc != RT_OK) {

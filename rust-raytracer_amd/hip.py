@@ -39,6 +39,23 @@ def lib():
         L.rt_hip_render_to_host.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.RtStats)]
         L.rt_hip_math_probe.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_void_p]
         L.rt_hip_hit_probe.argtypes = [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p]
+        L.rt_abi_sizeof.argtypes = [C.c_char_p]
+        L.rt_abi_sizeof.restype = C.c_size_t
+        L.rt_abi_version.restype = C.c_uint32
+        L.rt_hip_group_create.argtypes = [C.POINTER(abi.RtScene), C.c_uint32, C.POINTER(C.c_void_p)]
+        L.rt_hip_group_destroy.argtypes = [C.c_void_p]
+        L.rt_hip_group_destroy.restype = None
+        L.rt_hip_group_size.argtypes = [C.c_void_p]
+        L.rt_hip_group_size.restype = C.c_uint32
+        L.rt_hip_group_set_camera.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 4
+        L.rt_hip_group_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.rt_hip_group_render_to_host.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.RtStats)]
+        for name in ("RtSphere", "RtTexture", "RtScene", "RtRowTiles", "RtStats"):   # the binding's own layout check
+            if L.rt_abi_sizeof(name.encode()) != C.sizeof(getattr(abi, name)):
+                raise ImportError(f"{LIB_PATH}: sizeof({name}) = {L.rt_abi_sizeof(name.encode())} but abi.py has "
+                                  f"{C.sizeof(getattr(abi, name))} — rebuild with __graft_entry__.build()")
+        if L.rt_abi_version() != abi.RT_ABI_VERSION:
+            raise ImportError(f"{LIB_PATH}: ABI version {L.rt_abi_version()} != {abi.RT_ABI_VERSION}")
         _LIB = L
     return _LIB
 
@@ -101,6 +118,44 @@ class HipScene:
     def close(self):
         if self._h:
             lib().rt_hip_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipGroup:
+    """The scene resident on n_gpus devices of this node, frames sharded by interleaved scanline tiles
+    inside librt_hip.so (rt_hip_group_*): host threads + streams + ONE gather per frame, no torch."""
+
+    def __init__(self, scene_ptr, n_gpus=0):
+        self._h = C.c_void_p()
+        _check(lib().rt_hip_group_create(scene_ptr, n_gpus, C.byref(self._h)))
+        sc = scene_ptr.contents
+        self.width, self.height = sc.width, sc.height
+        self.size = lib().rt_hip_group_size(self._h)
+
+    def set_option(self, key, value):
+        _check(lib().rt_hip_group_set_option(self._h, key.encode(), int(value)))
+
+    def set_camera(self, origin, lower_left, horizontal, vertical):
+        v = [(C.c_double * 3)(*x) for x in (origin, lower_left, horizontal, vertical)]
+        _check(lib().rt_hip_group_set_camera(self._h, *v))
+
+    def render_to_host(self, out=None):
+        import numpy as np
+        if out is None:
+            out = np.zeros((self.height, self.width, 3), np.uint8)
+        st = abi.RtStats()
+        _check(lib().rt_hip_group_render_to_host(self._h, out.ctypes.data, C.byref(st)))
+        return out, st.as_dict()
+
+    def close(self):
+        if self._h:
+            lib().rt_hip_group_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -30,16 +30,68 @@ def test_every_declared_symbol_is_exported(pkg):
         assert hasattr(lib, n), f"{n} not exported"
 
 
+def _rust_structs(text):
+    """{name: [(field, rust type)]} of the #[repr(C)] structs in INTEGRATION.md's Rust shim"""
+    out = {}
+    for m in re.finditer(r"#\[repr\(C\)\](?:\s*#\[[^\]]*\])*\s*pub struct (\w+)\s*\{(.*?)\}", text, flags=re.S):
+        fields = []
+        for f in re.split(r",(?![^\[]*\])", m.group(2)):
+            f = f.strip()
+            if f:
+                name, ty = f.split(":", 1)
+                fields.append((name.strip().replace("pub ", ""), ty.strip()))
+        out[m.group(1)] = fields
+    return out
+
+
+def _ctype_of(rust):
+    prim = {"u8": C.c_uint8, "u32": C.c_uint32, "u64": C.c_uint64, "f32": C.c_float, "f64": C.c_double, "i32": C.c_int32}
+    m = re.fullmatch(r"\[(\w+);\s*(\d+)\]", rust)
+    if m:
+        return prim[m.group(1)] * int(m.group(2))
+    if rust.startswith("*const") or rust.startswith("*mut"):
+        return C.c_void_p
+    return prim[rust]
+
+
+def test_rust_shim_in_integration_md_matches_the_header(abi):
+    """The Rust binding cannot be compiled here (no rustc): machine-check its #[repr(C)] struct literals against
+    abi.py (itself checked against the C header below) — field names, order, sizes, total size.  A stale
+    `prof_cycles: [u64; 8]` (round 1) would make rt_hip_wait's memset write past the Rust struct."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    rs = _rust_structs(text)
+    assert set(rs) >= {"RtSphere", "RtTexture", "RtScene", "RtStats", "RtRowTiles"}, sorted(rs)
+    for name, fields in rs.items():
+        ct = getattr(abi, name)
+        want = [(n, C.sizeof(t)) for n, t in ct._fields_]
+        got = [(n, C.sizeof(_ctype_of(t))) for n, t in fields]
+        assert got == want, (name, got, want)
+        mirror = type("M" + name, (C.Structure,), {"_fields_": [(n, _ctype_of(t)) for n, t in fields]})
+        assert C.sizeof(mirror) == C.sizeof(ct), name
+    assert f"abi_version: {abi.RT_ABI_VERSION}" in text           # the version the shim writes into RtScene
+    assert "rt_abi_sizeof" in text and "rt_abi_version" in text   # and it checks the library's layout at start-up
+
+
+def test_abi_sizeof_export(pkg, abi):
+    """rt_abi_sizeof / rt_abi_version: what a foreign binding compares its own struct sizes with"""
+    L = pkg.hip.lib()
+    for name in ("RtSphere", "RtTexture", "RtScene", "RtRowTiles", "RtStats"):
+        assert L.rt_abi_sizeof(name.encode()) == C.sizeof(getattr(abi, name))
+    assert L.rt_abi_sizeof(b"NoSuchStruct") == 0 and L.rt_abi_version() == abi.RT_ABI_VERSION
+
+
 def test_struct_layout_matches_header(abi, tmp_path):
     """ctypes mirrors == C sizeof/offsetof (compiled from the header with gcc)."""
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "rt_abi.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(RtSphere), sizeof(RtTexture),'
-                   ' sizeof(RtScene), sizeof(RtRowTiles), sizeof(RtStats), offsetof(RtScene, spheres), offsetof(RtScene, seed), offsetof(RtSphere, albedo));return 0;}\n')
+                   ' sizeof(RtScene), sizeof(RtRowTiles), sizeof(RtStats), offsetof(RtScene, spheres), offsetof(RtScene, seed), offsetof(RtSphere, albedo));'
+                   'printf("%zu %zu %zu %zu\\n", offsetof(RtScene, n_gpus), offsetof(RtStats, segments_discarded), offsetof(RtStats, gather_ms), offsetof(RtStats, prof_cycles));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     want = [C.sizeof(abi.RtSphere), C.sizeof(abi.RtTexture), C.sizeof(abi.RtScene), C.sizeof(abi.RtRowTiles), C.sizeof(abi.RtStats),
-            abi.RtScene.spheres.offset, abi.RtScene.seed.offset, abi.RtSphere.albedo.offset]
+            abi.RtScene.spheres.offset, abi.RtScene.seed.offset, abi.RtSphere.albedo.offset,
+            abi.RtScene.n_gpus.offset, abi.RtStats.segments_discarded.offset, abi.RtStats.gather_ms.offset, abi.RtStats.prof_cycles.offset]
     assert got == want
 
 
@@ -61,7 +113,7 @@ def test_product_does_not_reference_oracle():
     """oracle/ and tests/hostsim are test infrastructure: no product source may include,
     import, dlopen or link them (comments may mention the oracle as the parity checker)."""
     pat = re.compile(r'#\s*include\s*[<"][^>"]*(oracle|hostsim)|import\s+[\w.]*oracle|from\s+[\w.]*oracle|load_oracle\s*\(|'
-                     r'librt_oracle|libhostsim|rt_oracle_[a-z_0-9]+\s*\(|dlopen')
+                     r'librt_oracle|libhostsim|rt_oracle_[a-z_0-9]+\s*\(')
     bad = []
     for base in ("rust-raytracer_amd", "include"):
         for dp, _, fs in os.walk(os.path.join(ROOT, base)):
@@ -70,6 +122,10 @@ def test_product_does_not_reference_oracle():
                     t = open(os.path.join(dp, f), errors="replace").read()
                     if pat.search(t):
                         bad.append(os.path.join(dp, f))
+                    if "dlopen" in t:  # the only library the product loads at run time is RCCL (multi-GPU gather)
+                        assert f == "rt_hip_group.hip", f
+                        libs = re.findall(r'"([^"]*\.so[^"]*)"', t)
+                        assert libs and all("rccl" in x for x in libs), libs
     assert bad == [], bad
     # and the built product libraries carry no dependency on / symbol of the oracle
     for so in ("librt_hip.so", "librt_host.so"):
