@@ -10,25 +10,31 @@ A "step" is one frame of BASELINE configs[1] — cover_scene at 1200x800, spp 12
 scene tables already resident in HBM.  With N > 1 the frame is sharded by interleaved
 2-scanline tiles (rank r renders tiles r, r+N, ...) and assembled on rank 0 by ONE gather
 over RCCL; total work is fixed, so scaling is "strong" (the north-star target is a >=6x
-speed-up of this frame at 8 GPUs).  The tile buffers are double-buffered: frame i's gather
-runs (asynchronously, on the collective's stream) while frame i+1 is being rendered, and all K
-frames are assembled on rank 0 before the closing barrier.  Rank 0 prints ONE JSON line.
+speed-up of this frame at 8 GPUs).  In the timed region the tile buffers are double-buffered:
+frame i's gather runs (asynchronously, on the collective's stream) while frame i+1 is being
+rendered, and all K frames are assembled on rank 0 before the closing barrier — `value` is that
+pipelined throughput.  The latency of ONE frame with nothing overlapped (render, gather, row
+permutation on rank 0) is measured separately after the timed region: `frame_latency_ms`, next
+to `n1_kernel_ms` (rank 0 rendering the whole frame alone) and their ratio.
+Rank 0 prints ONE JSON line.
 
-Extra objects on that line:
-  roofline      the megakernel against the roof that actually binds it (vector ALU; rocprof
-                shows the VALU pipes >90 % busy and ~6 MB of HBM traffic per frame):
-                ALGORITHMIC ray-sphere tests (segments x n_spheres = the reference's brute
-                force, counted by the kernel) x 17 flop / average kernel time measured with
-                HIP events on the launch stream, vs the 157.3 TFLOP/s FP32 vector peak.
-                The kernel itself executes far fewer tests (grid walk): `executed` restates
-                the same time in tests actually run.
-  roofline_hbm  the HBM view the north star asks for: algorithmic sphere-geometry bytes
-                (32 B per test) per second vs 8 TB/s, plus measured HBM traffic from
-                profiles/hbm_traffic.json (rocprofv3 --pmc passes)
+Extra objects on that line (N = 1):
+  roofline      the megakernel against the roof that binds it: vector-ALU issue (no dense contraction -> no MFMA;
+                ~10 MB of HBM traffic per frame -> not HBM).  `achieved` = executed VALU lane-slots per second =
+                SQ_THREAD_CYCLES_VALU per launch (rocprofv3 --pmc, profiles/<round>_pmc.json, same kernel build) /
+                this run's average kernel time (HIP events on the launch stream); `peak` = 256 CUs x 4 SIMDs x 16
+                lanes x 2.4 GHz = 39.32 T lane-slots/s (x 2 flop per FMA = the 78.6 TFLOP/s FP64 vector peak);
+                `frac` = their ratio = (VALU issue busy) x (lane utilisation), both restated from the counters.
+                `executed_f64`: exact Sphere::hit tests actually run x 17 flop / kernel time vs 78.6 TFLOP/s.
+                `algorithmic`: the reference's brute force (segments x n_spheres tests) over the same
+                time — a speed-up figure (the grid walk runs ~1 % of those tests), NOT a roofline fraction.
+                `traffic`: HBM bytes per launch from the PMC passes, and its ratio to the algorithmic bytes.
   cpu_baseline  the CPU oracle (a literal restatement of the reference's rayon path) timed
                 on this box's host cores on a bounded sample of the same frame
+  other_configs the other BASELINE configs at full size on one GPU (2 frames each): kernel_ms, Msamples/s
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -40,9 +46,10 @@ import __graft_entry__ as graft  # noqa: E402
 
 HEADLINE = "scenes/cfg2_cover_1200x800_spp128.json"
 FLOP_PER_TEST = 17          # sphere.rs:47-53 with |d|^2 and r^2 hoisted
-BYTES_PER_TEST = 32         # f64 centre + radius consumed per test
-PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md chip table
-PEAK_HBM_GBS = 8000.0
+PEAK_FP64_VALU_TFLOPS = 78.6    # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+PEAK_LANE_SLOTS_T = 256 * 4 * 16 * 2.4e9 / 1e12   # 39.32 T VALU lane-slots/s
+ENGINE_HZ = 2.4e9
+N_SIMD = 256 * 4
 
 
 def _flush_c_stdio():
@@ -51,6 +58,22 @@ def _flush_c_stdio():
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
+
+
+def _latest_pmc():
+    """newest profiles/rNN_*pmc.json that carries the VALU counters of the headline kernel"""
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json"))):
+        try:
+            j = json.load(open(p))
+        except Exception:
+            continue
+        m = j.get("mean_per_launch", {})
+        if "SQ_THREAD_CYCLES_VALU" in m and "SQ_ACTIVE_INST_VALU" in m:
+            key = (os.path.basename(p).split("_")[0], os.path.getmtime(p))
+            if best is None or key > best[0]:
+                best = (key, p, j)
+    return (best[1], best[2]) if best else (None, None)
 
 
 def main():
@@ -64,6 +87,7 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-row-stride", type=int, default=16,
                     help="cpu_baseline renders every k-th scanline (default: chosen for ~10 s of CPU wall time)")
     args = ap.parse_args()
@@ -86,7 +110,8 @@ def main():
     # RT_BENCH_FORCE_COLLECTIVE=1: a one-rank RCCL group still goes through init / gather / barrier — the N > 1
     # code path exercised on a 1-GPU box (self-check; the line then says so in config.parallelism)
     force_coll = world == 1 and os.environ.get("RT_BENCH_FORCE_COLLECTIVE") == "1"
-    if world > 1 or force_coll:
+    collective = world > 1 or force_coll
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         # RCCL prints a version banner through C stdio when the communicator comes up (device_id = eager init); on
@@ -124,8 +149,18 @@ def main():
     pipe = rdist.FramePipeline(H, W, rank, world, dev, force_collective=force_coll)   # double-buffered tiles; frame i's gather runs under frame i+1
     stream = torch.cuda.current_stream()
 
+    # every rank renders on its own GPU: collect (host, PCI bus id / uuid) of each rank's device and compare
+    ranks_devices = None
+    if collective:
+        prop = torch.cuda.get_device_properties(local_rank)
+        ident = (os.uname().nodename, str(getattr(prop, "uuid", "")), str(getattr(prop, "pci_bus_id", local_rank)), local_rank)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ident)
+        ranks_devices = gathered
+        assert len({(g[0], g[1], g[2]) for g in gathered}) == world, f"ranks share a device: {gathered}"
+
     def fence():
-        if world > 1 or force_coll:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -152,14 +187,43 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / max(1, args.steps)
     st = gs.wait()                                  # counters of the last launch (this rank's shard)
 
-    t = torch.tensor([elapsed, kernel_ms, float(st["segments"]), float(st["exact_tests"]), float(st["grid_steps"])],
+    # ---- ONE frame, nothing overlapped (the north star's case: render -> one gather at frame end -> frame on rank 0)
+    lat_ms = None
+    if collective:
+        lats = []
+        for i in range(7):
+            fence()
+            l0 = time.perf_counter()
+            buf, _ = pipe.begin(i)
+            gs.render(buf.data_ptr(), 0, tiles, stream.cuda_stream)
+            pipe.submit(i)
+            frames = pipe.drain()              # waits for the gather, permutes the rows on rank 0
+            torch.cuda.synchronize()
+            if collective:
+                dist.barrier()                 # the frame is complete everywhere (rank 0 holds it)
+            lats.append((time.perf_counter() - l0) * 1e3)
+            assert (frames[0] is not None) == (rank == 0)
+        lat_ms = sorted(lats[2:])[len(lats[2:]) // 2]   # median of 5 after 2 warm-ups
+    # the whole frame on ONE GPU (rank 0), for the N = 1 reference inside the same line
+    n1_kernel_ms = None
+    if world > 1:
+        if rank == 0:
+            full = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+            ks = []
+            for _ in range(4):
+                gs.render(full.data_ptr(), 0, None, stream.cuda_stream)
+                ks.append(gs.wait()["kernel_ms"])
+            n1_kernel_ms = sorted(ks[1:])[1]
+        dist.barrier()
+
+    t = torch.tensor([elapsed, kernel_ms, float(st["segments"]), float(st["exact_tests"]), float(st["grid_steps"]), lat_ms or 0.0],
                      dtype=torch.float64, device=dev)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
+        elapsed, kernel_ms, lat_ms = float(tmax[0]), float(tmax[1]), float(tmax[5])
         segments, exact, steps = float(tsum[2]), float(tsum[3]), float(tsum[4])
     else:
         segments, exact, steps = float(st["segments"]), float(st["exact_tests"]), float(st["grid_steps"])
@@ -169,16 +233,39 @@ def main():
         samples = W * H * SPP
         ms_per_step = elapsed * 1e3 / args.steps
         value = samples * args.steps / elapsed / 1e6
-        tests = segments * N_SPH                       # algorithmic tests of the whole frame
-        # dominant kernel: per launch (= per rank) algorithmic work / its average duration
-        tests_per_launch = tests / world
-        tflops = tests_per_launch * FLOP_PER_TEST / (kernel_ms * 1e-3) / 1e12
-        gbs = tests_per_launch * BYTES_PER_TEST / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if headline and world == 1 and os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
+        kernel_s = kernel_ms * 1e-3
+        tests_per_launch = segments * N_SPH / world     # algorithmic tests of one launch (= one rank's shard)
+        exact_per_launch = exact / world
+        # ---- roofline of the dominant kernel (rt_megakernel): executed basis, counters from profiles/
+        pmc_path, pmc = _latest_pmc()
+        roof = {"bound": "valu", "kernel": "rt_megakernel", "unit": "T lane-slots/s", "peak": round(PEAK_LANE_SLOTS_T, 2),
+                "achieved": None, "frac": None, "traffic": None,
+                "note": "vector-ALU issue binds this path (no MFMA: no dense contraction; HBM traffic ~0.01 % of 8 TB/s x frame "
+                        "time): frac = SQ_THREAD_CYCLES_VALU / (16 lanes x 1024 SIMDs x 2.4 GHz x kernel time) = VALU issue busy x "
+                        "lane utilisation; counters per launch from rocprofv3 --pmc of the same build, time from this run's HIP events"}
+        if pmc is not None and headline and world == 1:
+            m = pmc["mean_per_launch"]
+            thr, act = m["SQ_THREAD_CYCLES_VALU"], m["SQ_ACTIVE_INST_VALU"]
+            roof["achieved"] = round(thr / kernel_s / 1e12, 3)
+            roof["frac"] = round(thr / kernel_s / 1e12 / PEAK_LANE_SLOTS_T, 4)
+            roof["valu_issue_busy"] = round(act / (N_SIMD * kernel_s * ENGINE_HZ / 4.0), 4)
+            roof["lane_utilisation"] = round(thr / (64.0 * act), 4)
+            roof["counters"] = {"SQ_THREAD_CYCLES_VALU": thr, "SQ_ACTIVE_INST_VALU": act, "SQ_INSTS_VALU": m.get("SQ_INSTS_VALU"),
+                                "source": os.path.relpath(pmc_path, ROOT), "kernel_ms_of_that_run": pmc.get("kernel_ms")}
+            if pmc.get("hbm_bytes_per_launch") is not None:
+                alg_bytes = 3 * W * H + 32 * N_SPH * 2 + 8 * 4800   # framebuffer + one pass over geometry/material/cell tables
+                roof["traffic"] = pmc["hbm_bytes_per_launch"]
+                roof["traffic_source"] = pmc.get("source")
+                roof["algorithmic_bytes"] = alg_bytes
+                roof["traffic_over_algorithmic"] = round(pmc["hbm_bytes_per_launch"] / alg_bytes, 2)
+        ex_tflops = exact_per_launch * FLOP_PER_TEST / kernel_s / 1e12
+        roof["executed_f64"] = {"exact_tests_per_launch": int(exact_per_launch), "flop_per_test": FLOP_PER_TEST, "tflops": round(ex_tflops, 3),
+                                "peak_fp64_vector_tflops": PEAK_FP64_VALU_TFLOPS, "frac": round(ex_tflops / PEAK_FP64_VALU_TFLOPS, 4)}
+        alg_tflops = tests_per_launch * FLOP_PER_TEST / kernel_s / 1e12
+        roof["algorithmic"] = {"tests_per_launch": int(tests_per_launch), "tflops_equivalent": round(alg_tflops, 2),
+                               "algorithmic_speedup": round(tests_per_launch / max(1.0, exact_per_launch), 1),
+                               "note": "the reference's brute force (segments x n_spheres, SURVEY §8d) over this kernel's time: a speed-up "
+                                       "figure, not a roofline fraction — the grid walk executes ~1 % of these tests"}
         out = {
             "metric": "Msamples/sec (pixels x spp / s) on cover_scene 1200x800",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -191,19 +278,18 @@ def main():
             "kernel_ms": round(kernel_ms, 4), "segments_per_sample": round(segments / samples, 4),
             "exact_tests_per_segment": round(exact / max(1.0, segments), 3),
             "grid_steps_per_segment": round(steps / max(1.0, segments), 3),
-            "roofline": {"bound": "valu", "note": "vector-ALU bound: neither hbm nor mfma binds this path (DESIGN.md §6); `achieved` counts the "
-                         "reference's brute-force tests (SURVEY §8d), of which the grid walk executes ~1 % (`executed`), so frac may exceed 1",
-                         "achieved": round(tflops, 3),
-                         "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / PEAK_FP32_VALU_TFLOPS, 4),
-                         "traffic": traffic, "kernel": "rt_megakernel", "flop_per_test": FLOP_PER_TEST,
-                         "tests_per_launch": int(tests_per_launch),
-                         "executed": {"exact_tests_per_launch": int(exact / world),
-                                      "tflops_f64": round(exact / world * FLOP_PER_TEST / (kernel_ms * 1e-3) / 1e12, 3)}},
-            "roofline_hbm": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                             "note": "achieved = algorithmic sphere-geometry bytes (32 B/test) per second; the tables are "
-                                     "LDS-resident, real HBM traffic is `traffic` bytes per launch"},
+            "roofline": roof,
         }
+        if collective:
+            out["rccl_ranks"] = dist.get_world_size()
+            out["visible_gpus"] = torch.cuda.device_count()
+            out["rank_devices"] = [f"{g[0]}:{g[2]}" for g in ranks_devices]
+            out["frame_latency_ms"] = round(lat_ms, 4)      # ONE frame: render (slowest rank) + gather + row permutation, no overlap
+            out["frame_latency_msamples_per_s"] = round(samples / lat_ms / 1e3, 1)
+            if n1_kernel_ms is not None:
+                out["n1_kernel_ms"] = round(n1_kernel_ms, 4)                      # the whole frame on rank 0's GPU alone, same process
+                out["speedup_vs_n1_latency"] = round(n1_kernel_ms / lat_ms, 3)    # the north star's ">= 6x at 8 GPUs" figure
+                out["speedup_vs_n1_pipelined"] = round(n1_kernel_ms / ms_per_step, 3)
         if world == 1:
             # the frame as a host caller sees it with the scene resident — kernel + the 2.88 MB
             # device-to-host copy of the RGB8 frame (pageable numpy buffer) — reported beside `value`, never as it
@@ -212,6 +298,8 @@ def main():
             for _ in range(3):
                 gs.render_to_host()
             out["frame_ms_to_host_buffer"] = round((time.perf_counter() - h0) * 1e3 / 3, 3)
+        if world == 1 and headline and not args.no_other_configs:
+            out["other_configs"] = other_configs(pkg, torch, dev, stream)
         if world == 1 and not args.no_cpu_baseline:
             oracle = graft.load_oracle()
             cores = oracle.lib(abi).rt_oracle_threads()
@@ -230,16 +318,44 @@ def main():
             out["cpu_baseline"] = {"value": round(ost["samples"] / csec / 1e6, 4), "unit": "Msamples/s",
                                    "cores": cores, "kind": "port",
                                    "sample": f"every {stride}th scanline of the same frame ({rows} rows, {ost['samples'] / 1e6:.2f} Msamples, "
-                                             f"{csec:.1f} s); C oracle, OpenMP one scanline per task, -O3 -march=native -ffp-contract=off",
+                                             f"{csec:.1f} s); C oracle, OpenMP over 32-pixel blocks of a scanline, -O3 -march=native -ffp-contract=off",
                                    "gpu_over_cpu": round(value / (ost["samples"] / csec / 1e6), 1)}
         line = json.dumps(out)
     gs.close()
-    if world > 1 or force_coll:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
     _flush_c_stdio()
     if rank == 0:
         print(line, flush=True)   # the ONE JSON line, and the last thing this process writes to stdout
+
+
+def other_configs(pkg, torch, dev, stream):
+    """the other BASELINE configs at FULL size on this GPU, 1 warm-up + 2 timed frames each (parity of each is
+    tested at full size in tests/test_gpu_parity.py): kernel time from HIP events, Msamples/s"""
+    sys.path.insert(0, os.path.join(ROOT, "scenes"))
+    import procedural
+    res = []
+    cases = [("configs[0] test_scene 800x600 spp16 depth8 (lights, textures, hollow glass)", "scenes/cfg1_test_800x600_spp16.json", None),
+             ("configs[2] cover 3840x2160 spp1024, earth/moon + sky textures", "scenes/cfg3_cover_4k_textured.json", None),
+             ("configs[3] cover 3840x2160 spp512 textured, on ONE GPU (the 8-GPU config)", "scenes/cfg4_cover_4k_textured_spp512.json", None),
+             ("configs[4] procedural 10 001 spheres 3840x2160 spp2048 (tables in L2)", None, dict(width=3840, height=2160, spp=2048, half=50, seed=0))]
+    for name, path, proc in cases:
+        s = pkg.host.Scene.load(path) if path else pkg.host.Scene.loads(procedural.make_json(**proc))
+        g = pkg.hip.HipScene(s.ptr, dev.index or 0)
+        fb = torch.zeros((s.c.height, s.c.width, 3), dtype=torch.uint8, device=dev)
+        ks = []
+        for _ in range(3):
+            g.render(fb.data_ptr(), 0, None, stream.cuda_stream)
+            stt = g.wait()
+            ks.append(stt["kernel_ms"])
+        k = sum(ks[1:]) / 2.0
+        n = s.c.width * s.c.height * s.c.samples_per_pixel
+        res.append({"config": name, "kernel_ms": round(k, 3), "msamples_per_s": round(n / k / 1e3, 1), "n_spheres": s.c.n_spheres,
+                    "segments_per_sample": round(stt["segments"] / n, 3), "exact_tests_per_segment": round(stt["exact_tests"] / max(1, stt["segments"]), 2)})
+        g.close()
+        del fb
+    return res
 
 
 if __name__ == "__main__":

@@ -25,6 +25,8 @@ def lib(abi):
         L = C.CDLL(path)
         L.rt_oracle_render.argtypes = [C.POINTER(abi.RtScene), C.POINTER(abi.RtRowTiles), C.c_void_p, C.c_void_p,
                                        C.POINTER(abi.RtStats), C.c_int]
+        L.rt_oracle_render_window.argtypes = [C.POINTER(abi.RtScene), C.POINTER(abi.RtRowTiles), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                              C.POINTER(abi.RtStats), C.c_int]
         L.rt_oracle_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
         L.rt_oracle_philox4x32_10.restype = None
         L.rt_oracle_sphere_hit.argtypes = [C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double),
@@ -52,21 +54,26 @@ def lib(abi):
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.rt_oracle_draws.restype = None
         L.rt_oracle_threads.restype = C.c_int
+        L.rt_oracle_p3_op.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]
+        L.rt_oracle_ray_at.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]
+        L.rt_oracle_ray_at.restype = None
         L.rt_oracle_atan2.argtypes = [C.c_double, C.c_double]
         L.rt_oracle_atan2.restype = C.c_double
         _LIB = L
     return _LIB
 
 
-def render(abi, scene_ptr, tiles=None, n_threads=0, want_linear=True):
-    """-> (rgb8 [rows,w,3] u8, linear [rows,w,3] f32 | None, stats dict)"""
+def render(abi, scene_ptr, tiles=None, n_threads=0, want_linear=True, x_range=None):
+    """-> (rgb8 [rows,w,3] u8, linear [rows,w,3] f32 | None, stats dict); x_range = (x0, x1): only those pixels
+    of the rows are rendered (the rest of the arrays stays 0)"""
     sc = scene_ptr.contents
     rows = abi.tiles_local_rows(sc.height, tiles)
     rgb = np.zeros((rows, sc.width, 3), np.uint8)
     lin = np.zeros((rows, sc.width, 3), np.float32) if want_linear else None
     st = abi.RtStats()
-    rc = lib(abi).rt_oracle_render(scene_ptr, C.byref(tiles) if tiles is not None else None, rgb.ctypes.data,
-                                   lin.ctypes.data if lin is not None else None, C.byref(st), n_threads)
+    x0, x1 = x_range if x_range is not None else (0, sc.width)
+    rc = lib(abi).rt_oracle_render_window(scene_ptr, C.byref(tiles) if tiles is not None else None, x0, x1, rgb.ctypes.data,
+                                          lin.ctypes.data if lin is not None else None, C.byref(st), n_threads)
     if rc != 0:
         raise RuntimeError(f"rt_oracle_render failed: {rc}")
     return rgb, lin, st.as_dict()

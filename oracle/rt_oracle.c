@@ -184,6 +184,34 @@ int rt_oracle_sphere_hit(const double center[3], double radius, const double ori
 
 double rt_oracle_atan2(double y, double x) { return rt_atan2(y, x); }
 
+/* hooks for the reference's vector / ray unit tests (point3d.rs:197-272, ray.rs:38-63) */
+int rt_oracle_p3_op(int op, const double a[3], const double b[3], double s, double out[3]) {
+  P3 A = p3(a[0], a[1], a[2]), B = b ? p3(b[0], b[1], b[2]) : p3(0, 0, 0), R = p3(0, 0, 0);
+  switch (op) {
+    case 0: R = p3_add(A, B); break;                                             /* :89-99   */
+    case 1: R = p3_sub(A, B); break;                                             /* :101-111 */
+    case 2: R = p3_neg(A); break;                                                /* :113-123 */
+    case 3: R = p3(A.x * B.x, A.y * B.y, A.z * B.z); break;                      /* :125-135 Mul<Point3D> */
+    case 4: R = p3(A.x / B.x, A.y / B.y, A.z / B.z); break;                      /* :149-159 Div<Point3D> */
+    case 5: R = p3_muls(A, s); break;                                            /* :137-147 */
+    case 6: R = p3_divs(A, s); break;                                            /* :161-171 */
+    case 7: R = p3(p3_dot(A, B), 0, 0); break;                                   /* :72-74   */
+    case 8: R = p3(p3_length_squared(A), 0, 0); break;                           /* :59-61   */
+    case 9: R = p3((double)p3_near_zero(A), 0, 0); break;                        /* :84-86   */
+    case 10: R = p3(p3_length(A), 0, 0); break;                                  /* :63-65   */
+    case 11: R = p3_unit(A); break;                                              /* :67-70   */
+    case 12: R = p3_cross(A, B); break;                                          /* :76-82   */
+    default: return -1;
+  }
+  out[0] = R.x; out[1] = R.y; out[2] = R.z;
+  return 0;
+}
+void rt_oracle_ray_at(const double origin[3], const double dir[3], double t, double out[3]) {  /* ray.rs:18-20 */
+  Ray r = {p3(origin[0], origin[1], origin[2]), p3(dir[0], dir[1], dir[2])};
+  P3 q = ray_at(r, t);
+  out[0] = q.x; out[1] = q.y; out[2] = q.z;
+}
+
 /* raytracer.rs:44-59 */
 static int hit_world(Ctx* c, Ray r, double t_min, double t_max, HitRecord* best) {
   const RtScene* sc = c->scene;
@@ -414,12 +442,15 @@ uint32_t rt_oracle_find_lights(const RtSphere* spheres, uint32_t n, uint32_t* ou
   return k;
 }
 
-/* raytracer.rs:213 `color.into_format().into_raw()`: palette 0.6 FromComponent<f32> for u8 =
- * round-to-nearest-even of min(x*255, 255) (the 2^23 magic-number trick); negatives -> 0.
- * Third-party and unpinned by any reference test: the RGB8 comparison allows 1 LSB where
- * it matters (tests/), and oracle and kernel share this definition. */
+/* raytracer.rs:213 `color.into_format().into_raw()`: palette 0.6 FromComponent<f32> for u8, restated from the
+ * crate's source as  scaled = (x * 255.0).min(255.0);  (scaled + 2^23).to_bits().saturating_sub(bits(2^23)) as u8
+ * i.e. round-to-nearest-even of min(x*255, 255); negatives -> 0 (the subtraction saturates); and NaN -> 255,
+ * because Rust's f32::min returns its non-NaN operand.  THIRD-PARTY AND UNPINNED: the crate is not under
+ * /root/reference and no reference test exercises it; oracle and kernel share this definition.  NaN pixels
+ * only arise for frames one pixel wide or high (raytracer.rs:199-200 divides by width-1 / height-1). */
 uint8_t rt_oracle_f32_to_u8(float x) {
   float scaled = x * 255.0f;
+  if (scaled != scaled) return 255;
   if (!(scaled > 0.0f)) return 0;
   if (scaled > 255.0f) scaled = 255.0f;
   return (uint8_t)nearbyintf(scaled);
@@ -437,11 +468,11 @@ void rt_oracle_ray_color(const RtScene* scene, const double o[3], const double d
   out[0] = col.r; out[1] = col.g; out[2] = col.b;
 }
 
-/* raytracer.rs:191-218 for one scanline y; out_row/out_lin are that row's 3*w bytes / floats */
-static void render_line(Ctx* c, uint32_t y, uint8_t* out_row, float* out_lin) {
+/* raytracer.rs:191-218 for pixels [x0, x1) of scanline y; out_row/out_lin are that row's 3*w bytes / floats */
+static void render_line(Ctx* c, uint32_t y, uint32_t x0, uint32_t x1, uint8_t* out_row, float* out_lin) {
   const RtScene* sc = c->scene;
   const uint32_t w = sc->width, h = sc->height;
-  for (uint32_t x = 0; x < w; ++x) {
+  for (uint32_t x = x0; x < x1; ++x) {
     float pixel_colors[3] = {0.0f, 0.0f, 0.0f};
     c->pixel = y * w + x;
     for (uint32_t s = 0; s < sc->samples_per_pixel; ++s) {
@@ -475,16 +506,23 @@ static double now_ms(void) {
   return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
-/* raytracer.rs:250-263 */
-int rt_oracle_render(const RtScene* scene, const RtRowTiles* tiles, uint8_t* rgb8, float* linear,
-                     RtStats* stats, int n_threads) {
+/* raytracer.rs:250-263.  The reference hands whole scanlines to rayon (:255-262); pixels are independent, so the
+ * checker cuts a scanline into blocks of RT_ORACLE_XBLOCK pixels to keep every core busy when only a few rows are
+ * asked for (the full-size parity tests compare single 4K rows at spp 1024).  Same pixels, same bits. */
+#define RT_ORACLE_XBLOCK 32u
+static int render_rows(const RtScene* scene, const RtRowTiles* tiles, uint32_t x0, uint32_t x1, uint8_t* rgb8, float* linear,
+                       RtStats* stats, int n_threads) {
   if (!scene || scene->abi_version != RT_ABI_VERSION) return RT_ERR_INVALID;
   if (scene->width == 0 || scene->height == 0 || (scene->n_spheres && !scene->spheres)) return RT_ERR_INVALID;
+  if (x1 > scene->width) x1 = scene->width;
+  if (x0 > x1) x0 = x1;
   uint32_t n_lights = rt_oracle_find_lights(scene->spheres, scene->n_spheres, NULL, 0);
   uint32_t* lights = (uint32_t*)malloc(sizeof(uint32_t) * (n_lights ? n_lights : 1));
   rt_oracle_find_lights(scene->spheres, scene->n_spheres, lights, n_lights);
   const uint32_t rows = rt_tiles_local_rows(scene->height, tiles);
   const size_t row_elems = (size_t)scene->width * 3;
+  const uint32_t xblocks = (x1 - x0 + RT_ORACLE_XBLOCK - 1) / RT_ORACLE_XBLOCK;
+  const uint64_t n_tasks = (uint64_t)rows * xblocks;
   uint64_t segments = 0, tex_oob = 0, discarded = 0;
 #ifdef _OPENMP
   if (n_threads <= 0) n_threads = omp_get_max_threads();
@@ -493,18 +531,20 @@ int rt_oracle_render(const RtScene* scene, const RtRowTiles* tiles, uint8_t* rgb
 #endif
   double t0 = now_ms();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : segments, tex_oob, discarded)
-  for (uint32_t lr = 0; lr < rows; ++lr) {
+  for (uint64_t task = 0; task < n_tasks; ++task) {
+    const uint32_t lr = (uint32_t)(task / xblocks), xb = (uint32_t)(task % xblocks);
     Ctx c; memset(&c, 0, sizeof c);
     c.scene = scene; c.lights = lights; c.n_lights = n_lights;
     uint32_t y = rt_tiles_global_row(tiles, lr);
-    render_line(&c, y, rgb8 ? rgb8 + lr * row_elems : NULL, linear ? linear + lr * row_elems : NULL);
+    const uint32_t xa = x0 + xb * RT_ORACLE_XBLOCK, xe = xa + RT_ORACLE_XBLOCK < x1 ? xa + RT_ORACLE_XBLOCK : x1;
+    render_line(&c, y, xa, xe, rgb8 ? rgb8 + lr * row_elems : NULL, linear ? linear + lr * row_elems : NULL);
     segments += c.segments; tex_oob += c.tex_oob; discarded += c.segments_discarded;
   }
   double t1 = now_ms();
   free(lights);
   if (stats) {
     memset(stats, 0, sizeof *stats);
-    stats->samples = (uint64_t)rows * scene->width * scene->samples_per_pixel;
+    stats->samples = (uint64_t)rows * (x1 - x0) * scene->samples_per_pixel;
     stats->segments = segments;
     stats->sphere_tests = segments * scene->n_spheres;
     stats->exact_tests = segments * scene->n_spheres;
@@ -516,4 +556,13 @@ int rt_oracle_render(const RtScene* scene, const RtRowTiles* tiles, uint8_t* rgb
     stats->n_gpus_used = 0;
   }
   return RT_OK;
+}
+int rt_oracle_render(const RtScene* scene, const RtRowTiles* tiles, uint8_t* rgb8, float* linear,
+                     RtStats* stats, int n_threads) {
+  return render_rows(scene, tiles, 0, scene ? scene->width : 0, rgb8, linear, stats, n_threads);
+}
+/* pixels [x0, x1) of the selected rows only; the buffers still hold whole rows (other pixels untouched) */
+int rt_oracle_render_window(const RtScene* scene, const RtRowTiles* tiles, uint32_t x0, uint32_t x1, uint8_t* rgb8,
+                            float* linear, RtStats* stats, int n_threads) {
+  return render_rows(scene, tiles, x0, x1, rgb8, linear, stats, n_threads);
 }

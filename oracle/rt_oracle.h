@@ -37,6 +37,9 @@ extern "C" {
  * cores (one scanline per task, dynamic schedule = rayon's work stealing). */
 int rt_oracle_render(const RtScene* scene, const RtRowTiles* tiles, uint8_t* rgb8, float* linear,
                      RtStats* stats, int n_threads);
+/* the same for pixels [x0, x1) of those rows only (buffers still hold whole rows; other pixels are left untouched) */
+int rt_oracle_render_window(const RtScene* scene, const RtRowTiles* tiles, uint32_t x0, uint32_t x1, uint8_t* rgb8,
+                            float* linear, RtStats* stats, int n_threads);
 int rt_oracle_threads(void);
 
 /* ---- hooks for the reference's known-answer tests ---- */
@@ -47,6 +50,12 @@ int rt_oracle_sphere_hit(const double center[3], double radius, const double ori
                          const double dir[3], double t_min, double t_max, double out[10]);
 /* f64::atan2 of sphere.rs:39 as both sides evaluate it (rust-raytracer_amd/csrc/common/rt_atan2.h) */
 double rt_oracle_atan2(double y, double x);
+/* point3d.rs:52-177 one operation at a time: op 0 add, 1 sub, 2 neg, 3 mul (componentwise), 4 div (componentwise),
+ * 5 mul by s, 6 div by s, 7 dot -> out[0], 8 length_squared -> out[0], 9 near_zero -> out[0], 10 length -> out[0],
+ * 11 unit_vector, 12 cross; returns -1 for an unknown op */
+int rt_oracle_p3_op(int op, const double a[3], const double b[3], double s, double out[3]);
+/* ray.rs:18-20 Ray::at */
+void rt_oracle_ray_at(const double origin[3], const double dir[3], double t, double out[3]);
 /* materials.rs:144-149 */
 void rt_oracle_refract(const double uv[3], const double n[3], double etai_over_etat, double out[3]);
 /* materials.rs:151-155 */

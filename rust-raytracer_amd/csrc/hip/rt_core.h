@@ -800,6 +800,15 @@ RT_HD unsigned long long sample_to_fixed(float v) {
 RT_HD float fixed_to_mean(unsigned long long sum, uint32_t spp) {
   return (float)(((double)sum * (1.0 / FIX_SCALE)) / (double)spp);
 }
+// A NaN sample makes the reference's f32 pixel sum NaN (raytracer.rs:203-205).  Fixed point has no NaN: such a
+// sample adds 0 and sets the pixel's bit in a per-tile, per-channel mask instead; the pixel then reads NaN.
+RT_HD bool sample_is_nan(float v) { return v != v; }
+RT_HD float rt_nanf() {
+  const uint32_t b = 0x7FC00000u;
+  float f;
+  __builtin_memcpy(&f, &b, 4);
+  return f;
+}
 
 // Continue the camera path after its hit at level k has been fully evaluated:
 // compose clamp(light + albedo*child) and step to the scattered ray.  Returns true when the
@@ -907,9 +916,11 @@ RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, d
   return lane_continue_main(sc, L, h.point, out_dir, zero3, att);
 }
 
-// raytracer.rs:207-213: mean, sqrt gamma, palette f32 -> u8 (round-half-even of min(x*255,255))
+// raytracer.rs:207-213: mean, sqrt gamma, palette f32 -> u8: round-half-even of min(x*255, 255), negatives -> 0,
+// NaN -> 255 (Rust's f32::min drops a NaN operand; third-party, unpinned — see oracle/rt_oracle.c)
 RT_HD uint8_t f32_to_u8(float x) {
   float scaled = x * 255.0f;
+  if (scaled != scaled) return 255;
   if (!(scaled > 0.0f)) return 0;
   if (scaled > 255.0f) scaled = 255.0f;
 #if defined(__HIP_DEVICE_COMPILE__)

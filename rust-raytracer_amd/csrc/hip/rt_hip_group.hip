@@ -10,9 +10,10 @@
 // ONE device-to-host copy.  No intra-frame communication.  Philox is addressed by GLOBAL pixel index and
 // pixel sums are order-free, so the frame is bit-identical for every G.
 //
-// Test hook: RT_GPUS_EMULATE=1 lets ranks share devices (rank r -> device r mod visible devices; peer
+// Test hooks: RT_GPUS_EMULATE=1 lets ranks share devices (rank r -> device r mod visible devices; peer
 // transport only), so the whole path — threads, sharding, gather buffer layout, de-interleave — runs on a
-// one-GPU box.
+// one-GPU box; RT_GATHER_SELFTEST=1 makes a ONE-rank group go through the gather (RCCL communicator of one
+// rank, in-place ncclGather) and the de-interleave kernel too.
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library is dlopen'ed below, never linked
 
@@ -79,6 +80,7 @@ struct RtHipGroup {
   uint32_t G = 1, width = 0, height = 0, pad_rows = 0;
   size_t row_bytes = 0, pad_bytes = 0;
   bool rccl = false;
+  bool gather = false;               // G > 1 (or the one-rank self-test): gather + de-interleave after the kernels
   std::vector<int> device;
   std::vector<RtHipScene*> scene;
   std::vector<hipStream_t> stream;
@@ -129,7 +131,7 @@ void worker_main(RtHipGroup* g, uint32_t r) {
     int rc = rt_hip_render(g->scene[r], g->G > 1 ? &g->tiles[r] : nullptr, g->d_tiles[r], nullptr, g->stream[r]);
     std::string err;
     if (rc != RT_OK) err = rt_hip_last_error();
-    if (rc == RT_OK && g->G > 1 && !g->rccl && r != 0) {  // peer transport: this rank's slice of the gather
+    if (rc == RT_OK && g->gather && !g->rccl && r != 0) {  // peer transport: this rank's slice of the gather
       const hipError_t e = hipMemcpyPeerAsync(static_cast<uint8_t*>(g->d_stacked) + (size_t)r * g->pad_bytes, g->device[0], g->d_tiles[r],
                                               g->device[r], g->pad_bytes, g->stream[r]);
       if (e != hipSuccess) { rc = RT_ERR_HIP; err = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e); }
@@ -204,7 +206,9 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
   g->pad_bytes = (size_t)g->pad_rows * g->row_bytes;
   const char* tr = std::getenv("RT_GATHER");
   if (tr && std::strcmp(tr, "rccl") && std::strcmp(tr, "peer")) { delete g; return fail(RT_ERR_INVALID, "RT_GATHER must be rccl or peer"); }
-  g->rccl = G > 1 && (tr ? !std::strcmp(tr, "rccl") : !shared_device);
+  const char* st = std::getenv("RT_GATHER_SELFTEST");
+  g->gather = G > 1 || (st && st[0] == '1');
+  g->rccl = g->gather && (tr ? !std::strcmp(tr, "rccl") : !shared_device);
   if (g->rccl && shared_device) { delete g; return fail(RT_ERR_INVALID, "RT_GATHER=rccl needs one device per rank (RT_GPUS_EMULATE shares devices)"); }
   auto bail = [&](int code, const std::string& m) { rt_hip_group_destroy(g); return fail(code, m); };
   // scene replicas: one thread per rank (table upload + texture copy run in parallel)
@@ -228,7 +232,7 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
   if (hipSetDevice(g->device[0]) != hipSuccess) return bail(RT_ERR_HIP, "hipSetDevice failed");
   if (hipMalloc(&g->d_stacked, g->pad_bytes * G ? g->pad_bytes * G : 16) != hipSuccess) return bail(RT_ERR_HIP, "hipMalloc(gather buffer) failed");
   g->d_tiles[0] = g->d_stacked;  // rank 0 renders into its own slice: the gather is in place on the root
-  if (G > 1) {
+  if (g->gather) {
     if (hipMalloc(&g->d_frame, (size_t)g->height * g->row_bytes ? (size_t)g->height * g->row_bytes : 16) != hipSuccess) return bail(RT_ERR_HIP, "hipMalloc(frame) failed");
   } else g->d_frame = g->d_stacked;
   if (hipEventCreate(&g->ev_assembled) != hipSuccess) return bail(RT_ERR_HIP, "hipEventCreate failed");
@@ -238,7 +242,7 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
     g->comm.assign(G, nullptr);
     const ncclResult_t nr = g->api.CommInitAll(g->comm.data(), (int)G, g->device.data());
     if (nr != ncclSuccess) { g->comm.clear(); return bail(RT_ERR_HIP, std::string("ncclCommInitAll: ") + g->api.GetErrorString(nr)); }
-  } else if (G > 1) {
+  } else if (g->gather) {
     for (uint32_t r = 1; r < G; ++r)
       if (g->device[r] != g->device[0]) { (void)hipSetDevice(g->device[r]); (void)hipDeviceEnablePeerAccess(g->device[0], 0); }
     (void)hipGetLastError();  // (already enabled / not supported: the copy is staged instead)
@@ -289,7 +293,7 @@ extern "C" int rt_hip_group_render_to_host(RtHipGroup* g, uint8_t* out_rgb8, RtS
     }
   RT_HIP_TRY(hipSetDevice(g->device[0]));
   hipStream_t s0 = g->stream[0];
-  if (G > 1) {
+  if (g->gather) {
     if (g->rccl) {  // ONE gather over xGMI: every rank's packed tiles -> rank 0's `stacked`, stream-ordered after its kernel
       ncclResult_t nr = g->api.GroupStart();
       for (uint32_t r = 0; r < G && nr == ncclSuccess; ++r)
@@ -323,7 +327,7 @@ extern "C" int rt_hip_group_render_to_host(RtHipGroup* g, uint8_t* out_rgb8, RtS
     *stats = total;
     stats->n_gpus_used = G;
     stats->frame_ms = frame_ms;
-    if (G > 1 && g->scene[0]->launched) {
+    if (g->gather && g->scene[0]->launched) {
       RT_HIP_TRY(hipSetDevice(g->device[0]));
       float ms = 0.f;
       RT_HIP_TRY(hipEventElapsedTime(&ms, g->scene[0]->ev_stop, g->ev_assembled));

@@ -87,15 +87,17 @@ struct SlotHdr {
   uint32_t finished;  // samples of this tile added to the pixel sums so far
   uint32_t expected;  // valid pixels of the tile x samples_per_pixel
   uint32_t state;     // SLOT_*
-  uint32_t pad[3];
+  uint32_t pad;
+  unsigned long long nan_mask[3];  // per channel: pixel slots of this tile that received a NaN sample (sample_is_nan)
 };
-static_assert(sizeof(SlotHdr) == 32, "slot header is 32 B");
+static_assert(sizeof(SlotHdr) == 48, "slot header is 48 B");
+constexpr uint32_t SLOT_HDR_BYTES = (uint32_t)sizeof(SlotHdr);
 enum { SLOT_FREE = 0, SLOT_OPEN = 1, SLOT_OPENING = 2 };
 constexpr uint32_t LDS_FLAGS_BYTES = 32u + 32u * 8u;          // {queue_empty, hint, waves retired} + pad, then the workgroup's 32 launch counters
 constexpr uint32_t LDS_SLOT_BUDGET = WAVES * 3u * 1024u;     // 48 KB at 16 waves (3 KB per wave)
 constexpr uint32_t T_SLOTS_MAX = 512u;
 __host__ __device__ inline uint32_t tile_slots(uint32_t tile_log2) {
-  const uint32_t per_slot = 32u + (1u << (2u * tile_log2)) * 24u;
+  const uint32_t per_slot = SLOT_HDR_BYTES + (1u << (2u * tile_log2)) * 24u;
   const uint32_t t = LDS_SLOT_BUDGET / per_slot;
   return t > T_SLOTS_MAX ? T_SLOTS_MAX : t;
 }
@@ -224,10 +226,11 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   uint32_t* const wg_flags = reinterpret_cast<uint32_t*>(lds_raw);  // [0] the frame's tile queue is empty, [1] slot opened last
   SlotHdr* const hdr = reinterpret_cast<SlotHdr*>(lds_raw + lay.hdr_off);
   const uint32_t T = ka.t_slots, acc_stride = 3u << (2u * ka.tile_log2);  // u64 words of pixel sums per slot
-  unsigned long long* const tile_acc = reinterpret_cast<unsigned long long*>(lds_raw + lay.hdr_off + T * 32u);
+  unsigned long long* const tile_acc = reinterpret_cast<unsigned long long*>(lds_raw + lay.hdr_off + T * SLOT_HDR_BYTES);
   uint4* const coop_xch = reinterpret_cast<uint4*>(lds_raw + lay.coop_off) + wave * 64u;
   for (uint32_t i = threadIdx.x; i < T; i += BLOCK) {
-    SlotHdr h; h.tile_xy = 0; h.next = 0x80000000u; h.finished = 0; h.expected = 0; h.state = SLOT_FREE; h.pad[0] = h.pad[1] = h.pad[2] = 0;
+    SlotHdr h; h.tile_xy = 0; h.next = 0x80000000u; h.finished = 0; h.expected = 0; h.state = SLOT_FREE; h.pad = 0;
+    h.nan_mask[0] = h.nan_mask[1] = h.nan_mask[2] = 0ull;
     hdr[i] = h;
   }
   if (threadIdx.x == 0) { wg_flags[0] = 0u; wg_flags[1] = 0u; wg_flags[2] = 0u; }
@@ -312,14 +315,29 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     const uint32_t tl = ka.tile_log2, tw = 1u << tl;
     const uint32_t px = ((xy & 0xFFFFu) << tl) + (lane & (tw - 1u)), lr = ((xy >> 16) << tl) + (lane >> tl);
     const unsigned long long* acc = tile_acc + k * (3u << (2u * tl));
-    if (lane < (1u << (2u * tl)) && px < sc.width && lr < ka.local_rows) {
-      const size_t o = ((size_t)lr * sc.width + px) * 3;
+    const bool valid = lane < (1u << (2u * tl)) && px < sc.width && lr < ka.local_rows;
+    const size_t o = ((size_t)lr * sc.width + px) * 3;
+    uint32_t rgb = 0u;  // R | G << 8 | B << 16
+    if (valid) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float lin = fixed_to_mean(__hip_atomic_load(&acc[lane * 3u + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), sc.spp);
+        float lin = fixed_to_mean(__hip_atomic_load(&acc[lane * 3u + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), sc.spp);
+        if ((__hip_atomic_load(&hdr[k].nan_mask[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> lane) & 1ull) lin = rt_nanf();
         if (ka.out_linear) ka.out_linear[o + c] = lin;
-        ka.out_rgb8[o + c] = f32_to_u8(__builtin_sqrtf(lin));
+        rgb |= (uint32_t)f32_to_u8(__builtin_sqrtf(lin)) << (8 * c);
       }
+    }
+    // Framebuffer write.  Tiles at least 4 pixels wide in a frame whose width is a multiple of 4: every aligned group
+    // of 4 pixels of a tile row is 12 contiguous, 4-byte-aligned bytes, written as three dwords by its first three
+    // lanes (R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3; the neighbour's bytes arrive by a lane shift) — one store
+    // instruction per flush instead of three byte stores.  Otherwise: bytes.
+    const bool packed = tl >= 2u && (sc.width & 3u) == 0u && (reinterpret_cast<uintptr_t>(ka.out_rgb8) & 3u) == 0u;
+    if (packed) {
+      const uint32_t nxt = (uint32_t)__shfl_down((int)rgb, 1);
+      const uint32_t i = lane & 3u;
+      if (valid && i < 3u) *reinterpret_cast<uint32_t*>(ka.out_rgb8 + o + i) = (rgb >> (8u * i)) | (nxt << (24u - 8u * i));
+    } else if (valid) {
+      ka.out_rgb8[o] = (uint8_t)rgb; ka.out_rgb8[o + 1] = (uint8_t)(rgb >> 8); ka.out_rgb8[o + 2] = (uint8_t)(rgb >> 16);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) {
@@ -384,6 +402,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       const uint32_t expected = sc.max_depth != 0u ? n_valid * sc.spp : 0u;
       unsigned long long* acc = tile_acc + k * acc_stride;
       if (lane < npx) { acc[lane * 3u] = 0ull; acc[lane * 3u + 1u] = 0ull; acc[lane * 3u + 2u] = 0ull; }
+      if (lane < 3u) hdr[k].nan_mask[lane] = 0ull;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) {  // publish: everything before next, next before state
         lds_store(&hdr[k].tile_xy, bx | (by << 16));
@@ -402,6 +421,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   auto open_item = [&](uint32_t k, uint32_t chunk) {
     const KArgs& ka = fresh_args();
     const DevScene& sc = ka.sc;
+    // pairs with the opener's release stores (tile_xy ... before next, next before state): the chunk came from
+    // a relaxed atomicAdd on `next`, so order the header reads behind it explicitly
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const uint32_t xy = bcast(lds_load(&hdr[k].tile_xy));
     const uint32_t bx = xy & 0xFFFFu, by = xy >> 16;
     const uint32_t tl = ka.tile_log2, tw = 1u << tl, npx = 1u << (2u * tl);  // pixel slots of the tile: lanes 0..npx-1
@@ -620,6 +642,16 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
           atomicAdd(&acc[1], sample_to_fixed(L.val[1]));
           atomicAdd(&acc[2], sample_to_fixed(L.val[2]));
           has_ray = false;
+        }
+      }
+      {  // NaN samples (frames one pixel wide or high; NaN scene data): flag the pixel, see sample_is_nan
+        const float vsum = (L.val[0] + L.val[1]) + L.val[2];  // NaN iff a channel is NaN (samples are clamped: no inf - inf)
+        if (wave_any(finished && sample_is_nan(vsum))) {
+          if (finished) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              if (sample_is_nan(L.val[c])) atomicOr(&hdr[my_k].nan_mask[c], 1ull << cur_p);
+          }
         }
       }
       unsigned long long mf = wave_ballot(finished);

@@ -6,7 +6,8 @@ The reference holds no golden images (its integration tests assert nothing, rayt
 oracle itself: they freeze the oracle's output so that a later edit of oracle/ or of the
 RNG addressing cannot silently move the target the GPU path is compared against.  The
 functions the oracle is built from are pinned separately by the reference's known-answer
-tests (tests/test_oracle_kat.py)."""
+tests (tests/test_oracle_kat.py).  Everything in the oracle is IEEE arithmetic (atan2 included: the shared
+double-double routine, not libm), so the files are bit-reproducible on any machine."""
 import os
 import sys
 
@@ -34,8 +35,9 @@ def main():
         sc.c.width, sc.c.height, sc.c.samples_per_pixel, sc.c.max_depth, sc.c.seed = w, h, spp, depth, seed
         rgb, lin, st = oracle.render(pkg.abi, sc.ptr)
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + ".npz"), rgb8=rgb, linear=lin,
-                            segments=np.uint64(st["segments"]), samples=np.uint64(st["samples"]))
-        print(name, rgb.shape, "segments", st["segments"], "mean", lin.mean(axis=(0, 1)))
+                            segments=np.uint64(st["segments"]), samples=np.uint64(st["samples"]),
+                            segments_discarded=np.uint64(st["segments_discarded"]))
+        print(name, rgb.shape, "segments", st["segments"], "discarded", st["segments_discarded"], "mean", lin.mean(axis=(0, 1)))
 
 
 if __name__ == "__main__":

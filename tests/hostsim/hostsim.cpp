@@ -31,6 +31,7 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
       std::memset(&L, 0, sizeof L);
       float acc[3] = {0.f, 0.f, 0.f};                 // accum 0: the reference's sequential f32 sum
       unsigned long long facc[3] = {0ull, 0ull, 0ull};  // accum 1: exact fixed point (pooled-sample kernels)
+      bool fnan[3] = {false, false, false};             // (+ the NaN flags that go with it)
       L.ra.pixel = y * sc.width + x; L.ra.k0 = ds.seed_lo; L.ra.k1 = ds.seed_hi;
       bool need_new = true;
       uint32_t cur_depth = 0; int first_kind = -1;
@@ -100,13 +101,13 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
           }
         }
         if (need_new) {
-          for (int k = 0; k < 3; ++k) { acc[k] += L.val[k]; facc[k] += sample_to_fixed(L.val[k]); }
+          for (int k = 0; k < 3; ++k) { acc[k] += L.val[k]; facc[k] += sample_to_fixed(L.val[k]); fnan[k] = fnan[k] || sample_is_nan(L.val[k]); }
           L.s += 1;
         }
       }
       float scale = 1.0f / (float)sc.samples_per_pixel;
       for (int k = 0; k < 3; ++k) {
-        float lin = (use_cull_flags & 16) ? fixed_to_mean(facc[k], sc.samples_per_pixel) : scale * acc[k];
+        float lin = (use_cull_flags & 16) ? (fnan[k] ? rt_nanf() : fixed_to_mean(facc[k], sc.samples_per_pixel)) : scale * acc[k];
         size_t o = ((size_t)lr * sc.width + x) * 3 + k;
         if (linear) linear[o] = lin;
         if (rgb8) rgb8[o] = f32_to_u8(sqrtf(lin));

@@ -11,7 +11,7 @@ T0=$(date +%s)
 stamp() { echo "$1 rc=$2 t=$(( $(date +%s) - T0 ))s" | tee -a $OUT/summary.txt; }
 rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9" | head -4 > $OUT/device.txt; nproc >> $OUT/device.txt
 timeout 240 python -c 'import __graft_entry__ as g; g.smoke()' > $OUT/smoke.log 2>&1; stamp smoke $?
-timeout 600 python -m pytest tests -m gpu -x -q -s > $OUT/pytest_gpu.log 2>&1; stamp pytest $?
+timeout 1500 python -m pytest tests -m gpu -x -q -s --durations=8 > $OUT/pytest_gpu.log 2>&1; stamp pytest $?
 tail -4 $OUT/pytest_gpu.log
 if [[ " $* " == *" ab "* ]]; then
   timeout 300 python tools/ab_bench.py run --rounds 5 > $OUT/ab.log 2>&1; stamp ab $?
@@ -22,10 +22,10 @@ REPO=$PWD
 if [[ " $* " == *" pmc "* ]]; then
   # HBM traffic: separate PMC passes, counters only (no trace domains), per the microarch guide
   for C in FETCH_SIZE WRITE_SIZE; do
-    ( cd /tmp && timeout 300 rocprofv3 --pmc $C --output-format csv -d "$REPO/$OUT/pmc_$C" -o bench -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ) > $OUT/pmc_$C.log 2>&1; stamp pmc_$C $?
+    ( cd /tmp && timeout 300 rocprofv3 --pmc $C --output-format csv -d "$REPO/$OUT/pmc_$C" -o bench -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs ) > $OUT/pmc_$C.log 2>&1; stamp pmc_$C $?
   done
-  ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$REPO/$OUT/pmc_sq" -o bench -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ) > $OUT/pmc_sq.log 2>&1; stamp pmc_sq $?
-  ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$REPO/$OUT/pmc_sq2" -o bench -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ) > $OUT/pmc_sq2.log 2>&1; stamp pmc_sq2 $?
+  ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$REPO/$OUT/pmc_sq" -o bench -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs ) > $OUT/pmc_sq.log 2>&1; stamp pmc_sq $?
+  ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$REPO/$OUT/pmc_sq2" -o bench -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs ) > $OUT/pmc_sq2.log 2>&1; stamp pmc_sq2 $?
   python tools/pmc_summary.py $OUT > $OUT/pmc_summary.json 2>$OUT/pmc_summary.err; stamp pmc_summary $?
   cat $OUT/pmc_summary.json
 fi
@@ -49,7 +49,7 @@ if [[ " $* " == *" configs "* ]]; then
   cut -c1-160 $OUT/all_configs.log
 fi
 # the bench line last: if profiles/hbm_traffic.json was just refreshed by the caller it is picked up next time
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT/prof" -o bench -- python "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline ) > $OUT/rocprof.log 2>&1
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT/prof" -o bench -- python "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-other-configs ) > $OUT/rocprof.log 2>&1
 stamp rocprof $?
 STATS=$(find $OUT/prof -name "*kernel_stats.csv" 2>/dev/null | head -1)
 if [ -n "$STATS" ]; then cp "$STATS" $OUT/kernel_stats.csv; head -6 "$STATS"; fi
