@@ -143,6 +143,37 @@ struct DevScene {
   const MatCore* matc;         // [n_spheres]
 };
 
+// ------------------------------------------------------------------ f64 square root
+// IEEE sqrt.  The device library's sequence = range scaling (compare, select, ldexp) + v_rsq_f64 + nine
+// mul/fma Newton-Goldschmidt steps + unscaling (ldexp) + the 0 / inf / NaN fix-up (class compare, two
+// selects).  Arguments in [2^-500, 2^500] need neither scaling nor fix-up: the same nine steps on the
+// unscaled value give the same bits (scaling by 2^256 only moves exponents), eight instructions shorter.
+// Everything else (0, denormals, huge, negative, NaN) takes the library's sqrt on a cold path.
+#ifndef RT_FAST_SQRT
+#define RT_FAST_SQRT 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && RT_FAST_SQRT
+__device__ __attribute__((noinline)) inline double rt_sqrt_cold(double x) { return sqrt(x); }
+__device__ __forceinline__ double rt_sqrt(double x) {
+  double g;
+  if (x >= 0x1p-500 && x <= 0x1p+500) {
+    const double y = __builtin_amdgcn_rsq(x);
+    g = x * y;
+    double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+  } else g = rt_sqrt_cold(x);
+  return g;
+}
+#else
+RT_HD double rt_sqrt(double x) { return sqrt(x); }
+#endif
+
 // ------------------------------------------------------------------ point3d.rs
 struct V3 {
   double x, y, z;
@@ -155,7 +186,7 @@ RT_HD V3 muls(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }         
 RT_HD V3 divs(V3 a, double s) { return v3(a.x / s, a.y / s, a.z / s); }            // :161-171
 RT_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }         // :72-74
 RT_HD double length_squared(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }    // :59-61
-RT_HD double length(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }      // :52-57, :63-65
+RT_HD double length(V3 a) { return rt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }   // :52-57, :63-65
 RT_HD V3 unit_vector(V3 a) { double l = length(a); return v3(a.x / l, a.y / l, a.z / l); }  // :67-70
 RT_HD bool near_zero(V3 a) {                                                       // :84-86
   const double eps = 2.220446049250313e-16;
@@ -188,7 +219,7 @@ struct U4 {
 RT_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int round = 0; round < 10; ++round) {
-    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;  // (the compiler emits one v_mad_u64_u32 per product on gfx950)
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
     uint32_t n1 = (uint32_t)p1;
@@ -308,7 +339,7 @@ RT_HD double exact_root(V3 o, V3 d, double a, const SphereGeom& g, double t_min,
   if (c > 0.0 && half_b > 0.0) return -1.0;
   double discriminant = (half_b * half_b) - (a * c);
   if (discriminant >= 0.0) {
-    double sqrtd = sqrt(discriminant);
+    double sqrtd = rt_sqrt(discriminant);
     double root_a = ((-half_b) - sqrtd) / a;
     if (root_a < t_max && root_a > t_min) return root_a;
     double root_b = ((-half_b) + sqrtd) / a;
@@ -346,7 +377,7 @@ RT_HD bool exact_hit_any_order_t(V3 o, V3 d, const RayK& rk, const SphereGeom& g
   double discriminant = (half_b * half_b) - (rk.a * c);
   if (discriminant >= 0.0) {
     const bool tie_ok = best >= 0 && idx < (uint32_t)best;
-    double sqrtd = sqrt(discriminant);
+    double sqrtd = rt_sqrt(discriminant);
     double num = (-half_b) - sqrtd;
     double root = FAST ? div_by_recip(num, rk.a, rk.inv_a) : num / rk.a;
     if (!(root > T_MIN && (root < closest || (tie_ok && root == closest)))) {
@@ -515,7 +546,7 @@ RT_HD V3 reflect(V3 v, V3 n) { return sub(v, muls(n, 2.0 * dot(v, n))); }  // :1
 RT_HD V3 refract(V3 uv, V3 n, double etai_over_etat) {                     // :144-149
   double cos_theta = fmin(dot(neg(uv), n), 1.0);
   V3 r_out_perp = muls(add(uv, muls(n, cos_theta)), etai_over_etat);
-  V3 r_out_parallel = muls(n, -1.0 * sqrt(fabs(1.0 - length_squared(r_out_perp))));
+  V3 r_out_parallel = muls(n, -1.0 * rt_sqrt(fabs(1.0 - length_squared(r_out_perp))));
   return add(r_out_perp, r_out_parallel);
 }
 RT_HD double reflectance(double cosine, double ref_idx) {                  // :151-155
@@ -697,7 +728,7 @@ RT_HD int scatter(const DevScene& sc, const RngAddr& ra, uint32_t node, V3 in_di
       double refraction_ratio = h.front_face ? matcore_inv_ior(m) : m.fuzz_or_ior;  // :180-184 (1/ior precomputed)
       V3 unit_direction = unit_vector_fast(in_dir);
       double cos_theta = fmin(dot(neg(unit_direction), h.normal), 1.0);
-      double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+      double sin_theta = rt_sqrt(1.0 - cos_theta * cos_theta);
       bool do_reflect = refraction_ratio * sin_theta > 1.0;
       if (!do_reflect) {  // (the draw is addressed by counter: taking it early or not at all changes nothing else)
         double u;

@@ -145,6 +145,9 @@ __device__ __forceinline__ const KArgs& fresh_args() {
 #ifndef RT_COOP_RANDOM
 #define RT_COOP_RANDOM 1
 #endif
+#ifndef RT_COOP_LAYERS
+#define RT_COOP_LAYERS 4u  // attempts a failing lane gets per helper round, at most (64 / failing lanes, capped)
+#endif
 // Lanes whose hit is Glass need no point but one Philox call of their own (slot 0, the reflectance
 // draw of materials.rs:189): they make it in round 0, in the instruction stream the others use for
 // attempt 0, and get its first two words back in `glass_u`.
@@ -165,7 +168,7 @@ __device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, bool glass, 
     if (!F) break;
     const uint32_t nf = (uint32_t)__builtin_popcountll(F);
     uint32_t layers = 64u / nf;
-    if (layers > 4u) layers = 4u;
+    if (layers > RT_COOP_LAYERS) layers = RT_COOP_LAYERS;
     const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(F >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)F, 0u));
     if (pending) xch[r] = make_uint4(ra.pixel, ra.sample, node, 0u);
     const uint32_t m = (65536u + nf - 1u) / nf;  // j = lane / nf for lane < 64 by multiplication
@@ -189,7 +192,7 @@ __device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, bool glass, 
     bool found = false;
     if (pending) {
       const unsigned long long mine = A >> r;
-      for (uint32_t l = 0; l < 4u; ++l)
+      for (uint32_t l = 0; l < RT_COOP_LAYERS; ++l)
         if (!found && l < layers && ((mine >> (l * nf)) & 1ull)) { found = true; from = r + l * nf; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -641,17 +644,16 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
           atomicAdd(&acc[0], sample_to_fixed(L.val[0]));
           atomicAdd(&acc[1], sample_to_fixed(L.val[1]));
           atomicAdd(&acc[2], sample_to_fixed(L.val[2]));
-          has_ray = false;
-        }
-      }
-      {  // NaN samples (frames one pixel wide or high; NaN scene data): flag the pixel, see sample_is_nan
-        const float vsum = (L.val[0] + L.val[1]) + L.val[2];  // NaN iff a channel is NaN (samples are clamped: no inf - inf)
-        if (wave_any(finished && sample_is_nan(vsum))) {
-          if (finished) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-              if (sample_is_nan(L.val[c])) atomicOr(&hdr[my_k].nan_mask[c], 1ull << cur_p);
+          // NaN samples (frames one pixel wide or high; NaN scene data) added 0 above: flag the pixel instead.  Samples
+          // are clamped to [0, 1], so the sum of the channels is NaN iff one of them is.  (A plain divergent branch right
+          // here: a wave vote around it, or a cold call, cost 6-12 more spilled registers in the path loop.)
+          if (sample_is_nan((L.val[0] + L.val[1]) + L.val[2])) {
+            const unsigned long long bit = 1ull << cur_p;
+            if (sample_is_nan(L.val[0])) atomicOr(&hdr[my_k].nan_mask[0], bit);
+            if (sample_is_nan(L.val[1])) atomicOr(&hdr[my_k].nan_mask[1], bit);
+            if (sample_is_nan(L.val[2])) atomicOr(&hdr[my_k].nan_mask[2], bit);
           }
+          has_ray = false;
         }
       }
       unsigned long long mf = wave_ballot(finished);
@@ -720,7 +722,7 @@ __global__ void rt_math_probe(const double* x, const double* y, double* out_sqrt
                               double* out_atan2, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  out_sqrt[i] = sqrt(x[i]);
+  out_sqrt[i] = rt_sqrt(x[i]);  // the kernel's square root (RT_FAST_SQRT builds: the short sequence + its cold path)
   out_div[i] = x[i] / y[i];
   out_sqrtf[i] = __builtin_sqrtf((float)x[i]);
   out_atan2[i] = rt_atan2(x[i] - 0.5, y[i] - 0.5);  // the shared routine (csrc/common/rt_atan2.h): must equal its CPU build bit for bit

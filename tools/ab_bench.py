@@ -22,31 +22,24 @@ SRC = os.path.join(ROOT, "rust-raytracer_amd", "csrc", "hip", "rt_hip_api.hip")
 BASE = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 # name -> (extra compile flags, runtime options, environment at scene creation)
 W4 = ["-DRT_WAVES_PER_EU=4"]
+SCAN = ["-DRT_WITH_SCAN_KERNEL"]   # the round-1 cull-scan kernel is compiled into A/B builds only ("variant" 2)
 VARIANTS = {
-    # (the two slow reference arms first: whatever is measured right after a 100+ ms kernel reads ~4 % high)
+    # (slow reference arms first: whatever is measured right after a 100+ ms kernel reads ~4 % high)
     "brute_force_on_gpu": (W4, {"variant": 1}, {}),
-    "round1_scan_kernel": (W4, {"variant": 2}, {}),
+    "round1_scan_kernel": (W4 + SCAN, {"variant": 2}, {}),
     "warmup_default": (W4, {}, {}),
     "default": (W4, {}, {}),
+    "fast_sqrt": (W4 + ["-DRT_FAST_SQRT=1"], {}, {}),
+    "coop_layers8": (W4 + ["-DRT_COOP_LAYERS=8u"], {}, {}),
+    "fast_sqrt_layers8": (W4 + ["-DRT_FAST_SQRT=1", "-DRT_COOP_LAYERS=8u"], {}, {}),
     "waves3": (["-DRT_WAVES_PER_EU=3"], {}, {}),
-    "no_coop_random": (W4 + ["-DRT_COOP_RANDOM=0"], {}, {}),
-    "early_ifcvt": (W4 + ["-mllvm", "-amdgpu-early-ifcvt"], {}, {}),
-    "sched_max_ilp": (W4 + ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], {}, {}),
-    "sched_bias100": (W4 + ["-mllvm", "-amdgpu-schedule-metric-bias=100"], {}, {}),
-    "amdgpu_trackers": (W4 + ["-mllvm", "-amdgpu-use-amdgpu-trackers"], {}, {}),
-    "tall_spheres_in_grid": (W4, {}, {"RT_GRID_LARGE_RATIO": "16"}),
     "tile8x8_chunk8": (W4, {"tile_log2": 3, "chunk_spp": 8}, {}),
-    "tile8x8_chunk16": (W4, {"tile_log2": 3, "chunk_spp": 16}, {}),
     "tile4x4_chunk16": (W4, {"tile_log2": 2, "chunk_spp": 16}, {}),
-    "cells_per_sphere1": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "1"}),
-    "cells_per_sphere1.5": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "1.5"}),
-    "cells_per_sphere2": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "2"}),
-    "cells_per_sphere2.5": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "2.5"}),
-    "cells_per_sphere3": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "3"}),
-    "cells_per_sphere4": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "4"}),
-    "cells_per_sphere6": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "6"}),
-    "cells_per_sphere8": (W4, {}, {"RT_GRID_CELLS_PER_SPHERE": "8"}),
 }
+ARMS_FILE = os.path.join(AB, "arms.json")   # extra arms for one session: {"name": [[flags], {options}, {env}]}
+if os.path.exists(ARMS_FILE):
+    for k_, v_ in json.load(open(ARMS_FILE)).items():
+        VARIANTS[k_] = (list(v_[0]), dict(v_[1]), dict(v_[2]))
 
 
 def build():
