@@ -245,7 +245,9 @@ int rt_hip_hit_probe(const double* rays, const double* spheres, double* out_t, u
  * reference's brute force (exact test on every sphere);
  * "chunk_spp" samples of a pixel per work item (0 = automatic); "tile_log2" pixel tiles of
  * 2^k x 2^k (k = 0..3, -1 = automatic); "samples_per_pixel", "max_depth" (0 .. 2^32-1) and
- * "seed" override the scene's values.  Out-of-range values are RT_ERR_INVALID. */
+ * "seed" override the scene's values; "tile_order" 0 = tiles leave the queue top row first, 1 = bottom row
+ * first, 2 (default) = the tiles whose paths ran deepest in this scene's previous frame first (the frame ends on
+ * its deepest paths; the image does not depend on the order).  Out-of-range values are RT_ERR_INVALID. */
 int rt_hip_set_option(RtHipScene*, const char* key, int64_t value);
 /* Animation (the reference's `anim/frame_%03d.png` workflow, README.md:43-57, main.rs:17): move the
  * camera of a resident scene — the four vectors of camera.rs:52-63 — without touching its tables,

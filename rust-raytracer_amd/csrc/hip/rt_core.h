@@ -150,7 +150,7 @@ struct DevScene {
 // unscaled value give the same bits (scaling by 2^256 only moves exponents), eight instructions shorter.
 // Everything else (0, denormals, huge, negative, NaN) takes the library's sqrt on a cold path.
 #ifndef RT_FAST_SQRT
-#define RT_FAST_SQRT 0
+#define RT_FAST_SQRT 1  // (-0.3 % kernel time, profiles/r02_run1_ab.log, r02_run2_ab.log)
 #endif
 #if defined(__HIP_DEVICE_COMPILE__) && RT_FAST_SQRT
 __device__ __attribute__((noinline)) inline double rt_sqrt_cold(double x) { return sqrt(x); }
@@ -783,10 +783,10 @@ struct Lane {
 };
 
 // raytracer.rs:199-201 + camera.rs:79-84
+// (the four Philox words of the camera jitter — rng(L.ra, NODE_CAMERA, 0) with L.ra.sample = L.s — come from the caller)
 template <class LaneT>
-RT_HD void lane_begin_sample(const DevScene& sc, LaneT& L, uint32_t px, uint32_t py) {
+RT_HD void lane_begin_sample_w(const DevScene& sc, LaneT& L, uint32_t px, uint32_t py, U4 w) {
   L.ra.sample = L.s;
-  U4 w = rng(L.ra, NODE_CAMERA, 0);
   double un = (double)px + u01_53(w.x, w.y), vn = sc.height_d - ((double)py + u01_53(w.z, w.w));
   double u, v;  // raytracer.rs:199-200: un / (width - 1), vn / (height - 1)
   if (sc.inv_wm1 != 0.0 && sc.inv_hm1 != 0.0) { u = div_by_recip(un, sc.wm1, sc.inv_wm1); v = div_by_recip(vn, sc.hm1, sc.inv_hm1); }
@@ -799,6 +799,12 @@ RT_HD void lane_begin_sample(const DevScene& sc, LaneT& L, uint32_t px, uint32_t
   L.d = sub(add(add(llc, muls(hor, u)), muls(ver, v)), origin);
   L.node = 0; L.k = 0; L.in_light = 0;
   fwd_init(L.fwd);
+}
+
+template <class LaneT>
+RT_HD void lane_begin_sample(const DevScene& sc, LaneT& L, uint32_t px, uint32_t py) {
+  L.ra.sample = L.s;
+  lane_begin_sample_w(sc, L, px, py, rng(L.ra, NODE_CAMERA, 0));
 }
 
 // the sample's radiance is known: fold the leaf colour through the forward map.  The caller

@@ -48,6 +48,11 @@ struct RtHipScene {
   int num_cus = 0;
   int cfg_key = -1; size_t cfg_lds = 0; int cfg_per_cu = 0;  // cached launch configuration
   void* d_frame = nullptr; size_t frame_bytes = 0;           // framebuffer of rt_hip_render_to_host
+  // queue order feedback (rt_kernel.hip KArgs::tile_order): depths measured by the last frame of this tile geometry
+  uint32_t* d_tile_depth = nullptr; uint32_t* d_tile_order = nullptr; size_t order_cap = 0;
+  uint64_t order_key = 0;   // geometry (+ row tiles) the order buffers belong to; 0 = none yet
+  bool order_ready = false; // d_tile_order holds an order for order_key
+  int order_mode = 2;       // "tile_order" option: 0 top row first, 1 bottom row first, 2 deepest tiles of the previous frame first
   int chunk_spp = 0;       // 0 = automatic
   int tile_log2 = -1;      // -1 = automatic; else tiles of 2^k x 2^k pixels, k = 0..3
 
@@ -100,7 +105,8 @@ extern "C" void rt_hip_scene_destroy(RtHipScene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (void* p : {s->d_geom, s->d_mat, s->d_cull, s->d_lights, s->d_tex, s->d_sky, (void*)s->d_counters, s->d_matc,
-                  s->d_cell_word, s->d_cell_items, s->d_large, s->d_all, s->d_large_geom, s->d_frame})
+                  s->d_cell_word, s->d_cell_items, s->d_large, s->d_all, s->d_large_geom, s->d_frame, (void*)s->d_tile_depth,
+                  (void*)s->d_tile_order})
     if (p) (void)hipFree(p);
   if (s->ev_start) (void)hipEventDestroy(s->ev_start);
   if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
@@ -192,6 +198,7 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
   if (!std::strcmp(key, "variant")) { if (value < 0 || value > max_variant) return fail(RT_ERR_INVALID, "variant must be 0 (grid walk) or 1 (brute force)"); s->variant = (int)value; return RT_OK; }
   if (!std::strcmp(key, "pool")) { s->pool = value != 0; return RT_OK; }
   if (!std::strcmp(key, "tile_log2")) { if (value < -1 || value > 3) return fail(RT_ERR_INVALID, "tile_log2 must be -1..3"); s->tile_log2 = (int)value; return RT_OK; }
+  if (!std::strcmp(key, "tile_order")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_order must be 0, 1 or 2"); s->order_mode = (int)value; s->order_ready = false; return RT_OK; }
   if (!std::strcmp(key, "chunk_spp")) { if (value < 0) return fail(RT_ERR_INVALID, "chunk_spp must be >= 0"); s->chunk_spp = (int)value; return RT_OK; }
   if (!std::strcmp(key, "samples_per_pixel") || !std::strcmp(key, "max_depth")) {
     if (value < 0 || value > (int64_t)0xFFFFFFFFll) return fail(RT_ERR_INVALID, std::string(key) + " must be in 0 .. 2^32-1");
@@ -342,6 +349,25 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   const bool lds_tables = with_tables.total <= rtk::LDS_TABLES_MAX_BYTES;
   const size_t lds_bytes = lds_tables ? with_tables.total : rtk::lds_layout(0, 0, 0, false).total;
 
+  // queue order: bottom of the image first; from the second frame of a tile geometry on, the tiles whose samples ran
+  // deepest in the previous frame first (their paths are what a frame ends on)
+  ka.order_mode = s->order_mode != 0 ? 1u : 0u;
+  ka.tile_order = nullptr; ka.tile_depth = nullptr;
+  if (s->order_mode == 2) {
+    const uint64_t key = ((uint64_t)ka.n_tiles << 32) ^ ((uint64_t)tl << 28) ^ ((uint64_t)ka.first_tile << 14) ^ ka.tile_stride ^ ((uint64_t)ka.tile_rows << 40) ^ ((uint64_t)local_rows << 8);
+    if (ka.n_tiles > s->order_cap) {
+      if (s->d_tile_depth) (void)hipFree(s->d_tile_depth);
+      if (s->d_tile_order) (void)hipFree(s->d_tile_order);
+      s->d_tile_depth = s->d_tile_order = nullptr; s->order_cap = 0;
+      RT_HIP_TRY(hipMalloc((void**)&s->d_tile_depth, (size_t)ka.n_tiles * 4));
+      RT_HIP_TRY(hipMalloc((void**)&s->d_tile_order, (size_t)ka.n_tiles * 4));
+      s->order_cap = ka.n_tiles;
+    }
+    if (key != s->order_key) { s->order_key = key; s->order_ready = false; }
+    ka.tile_depth = s->d_tile_depth;
+    if (s->order_ready) ka.tile_order = s->d_tile_order;
+  }
+
   RT_HIP_TRY(hipEventRecord(s->ev_start, stream));
   int rc;
   if (s->has_lights) rc = lds_tables ? launch_grid_t<true, false, true>(s, ka, lds_bytes, n_items, stream) : launch_grid_t<true, false, false>(s, ka, lds_bytes, n_items, stream);
@@ -350,6 +376,11 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   if (rc != RT_OK) return rc;
   RT_HIP_TRY(hipGetLastError());
   RT_HIP_TRY(hipEventRecord(s->ev_stop, stream));
+  if (ka.tile_depth) {  // the next frame's order, from this frame's depths (stream-ordered: ready before the next launch reads it)
+    hipLaunchKernelGGL(rtk::rt_order_tiles, dim3(1), dim3(1024), 0, stream, (const uint32_t*)s->d_tile_depth, s->d_tile_order, ka.n_tiles);
+    RT_HIP_TRY(hipGetLastError());
+    s->order_ready = true;
+  }
   s->launched = true; s->in_flight = true;
   return RT_OK;
 }

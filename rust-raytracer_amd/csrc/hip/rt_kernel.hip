@@ -40,6 +40,13 @@ struct KArgs {
   uint32_t tiles_x, n_tiles, n_chunks, chunk_spp;  // a tile's samples are handed out in n_chunks chunks
   uint32_t tile_log2;  // a tile is 2^tile_log2 x 2^tile_log2 pixels (8x8, 4x4, 2x2 or 1x1)
   uint32_t t_slots;    // tile slots per workgroup (tile_slots() of tile_log2)
+  // Queue order.  The frame ends on its deepest paths (50 sequential segments of a lone wave), so the tiles
+  // that breed them should leave the queue FIRST: position i of the queue is tile tile_order[i] (null: n_tiles-1-i, bottom
+  // of the image first — the sky rows last).  tile_depth[tile] receives the deepest camera path seen in the tile; the
+  // next frame's order is sorted by it (rt_order_tiles below).
+  const uint32_t* tile_order;
+  uint32_t* tile_depth;
+  uint32_t order_mode;  // 0: top row first (the round-1 order), 1: reversed / tile_order
 };
 
 #ifndef RT_BLOCK
@@ -87,7 +94,7 @@ struct SlotHdr {
   uint32_t finished;  // samples of this tile added to the pixel sums so far
   uint32_t expected;  // valid pixels of the tile x samples_per_pixel
   uint32_t state;     // SLOT_*
-  uint32_t pad;
+  uint32_t max_depth; // deepest camera path among this tile's samples so far (feeds KArgs.tile_depth)
   unsigned long long nan_mask[3];  // per channel: pixel slots of this tile that received a NaN sample (sample_is_nan)
 };
 static_assert(sizeof(SlotHdr) == 48, "slot header is 48 B");
@@ -142,8 +149,11 @@ __device__ __forceinline__ const KArgs& fresh_args() {
 // post their three words, and each failing lane takes those of its lowest-numbered accepted
 // attempt.  Attempt a is Philox slot 1+a whoever computes it, so the result is bit-identical to
 // the sequential loop.  `xch`: this wave's 64 x uint4 exchange slots.
-#ifndef RT_COOP_RANDOM
-#define RT_COOP_RANDOM 1
+#ifndef RT_FUSED_REFILL
+#define RT_FUSED_REFILL 1
+#endif
+#ifndef RT_DEEP_PATH
+#define RT_DEEP_PATH 8u  // camera paths at least this many segments long mark their tile (SlotHdr::max_depth)
 #endif
 #ifndef RT_COOP_LAYERS
 #define RT_COOP_LAYERS 4u  // attempts a failing lane gets per helper round, at most (64 / failing lanes, capped)
@@ -151,16 +161,19 @@ __device__ __forceinline__ const KArgs& fresh_args() {
 // Lanes whose hit is Glass need no point but one Philox call of their own (slot 0, the reflectance
 // draw of materials.rs:189): they make it in round 0, in the instruction stream the others use for
 // attempt 0, and get its first two words back in `glass_u`.
-__device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, bool glass, const RngAddr& ra, uint32_t node, uint32_t lane, uint4* xch,
-                                                         double& glass_u) {
+// Lanes that just took a new sample (`fresh`; they hold no hit) make the Philox call of its camera jitter (node
+// NODE_CAMERA, slot 0, raytracer.rs:199-200) in the same stream and get its four words back in `cam_w`.
+__device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, bool glass, bool fresh, const RngAddr& ra, uint32_t node, uint32_t lane,
+                                                         uint4* xch, double& glass_u, U4& cam_w) {
   auto point = [](uint32_t x, uint32_t y, uint32_t z) { return v3(range_m1_1(x), range_m1_1(y), range_m1_1(z)); };
-  uint32_t wx = 0, wy = 0, wz = 0;
+  uint32_t wx = 0, wy = 0, wz = 0, ww = 0;
   bool pending = false;
-  if (need || glass) {
-    const U4 w = rng(ra, node, glass ? 0u : 1u);
-    wx = w.x; wy = w.y; wz = w.z;
+  if (need || glass || fresh) {
+    const U4 w = rng(ra, fresh ? NODE_CAMERA : node, (glass || fresh) ? 0u : 1u);
+    wx = w.x; wy = w.y; wz = w.z; ww = w.w;
     pending = need && !(length_squared(point(wx, wy, wz)) < 1.0);
   }
+  cam_w.x = wx; cam_w.y = wy; cam_w.z = wz; cam_w.w = ww;
   glass_u = u01_53(wx, wy);
   uint32_t base = 1;  // next attempt of every lane still pending (wave-uniform)
   for (;;) {
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   unsigned long long* const tile_acc = reinterpret_cast<unsigned long long*>(lds_raw + lay.hdr_off + T * SLOT_HDR_BYTES);
   uint4* const coop_xch = reinterpret_cast<uint4*>(lds_raw + lay.coop_off) + wave * 64u;
   for (uint32_t i = threadIdx.x; i < T; i += BLOCK) {
-    SlotHdr h; h.tile_xy = 0; h.next = 0x80000000u; h.finished = 0; h.expected = 0; h.state = SLOT_FREE; h.pad = 0;
+    SlotHdr h; h.tile_xy = 0; h.next = 0x80000000u; h.finished = 0; h.expected = 0; h.state = SLOT_FREE; h.max_depth = 0;
     h.nan_mask[0] = h.nan_mask[1] = h.nan_mask[2] = 0ull;
     hdr[i] = h;
   }
@@ -342,6 +355,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     } else if (valid) {
       ka.out_rgb8[o] = (uint8_t)rgb; ka.out_rgb8[o + 1] = (uint8_t)(rgb >> 8); ka.out_rgb8[o + 2] = (uint8_t)(rgb >> 16);
     }
+    if (lane == 0 && ka.tile_depth) ka.tile_depth[(xy >> 16) * ka.tiles_x + (xy & 0xFFFFu)] = lds_load(&hdr[k].max_depth);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) {
       lds_store(&hdr[k].next, 0x80000000u);  // nothing to hand out from a free slot
@@ -391,7 +405,10 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       if (lane == 0) ok = atomicCAS(&hdr[k].state, (uint32_t)SLOT_FREE, (uint32_t)SLOT_OPENING) == (uint32_t)SLOT_FREE ? 1u : 0u;
       if (!bcast(ok)) continue;  // another wave claimed it: rescan
       uint32_t tile = 0;
-      if (lane == 0) tile = atomicAdd(ka.queue, 1u);
+      if (lane == 0) {
+        tile = atomicAdd(ka.queue, 1u);
+        if (tile < ka.n_tiles && ka.order_mode != 0u) tile = ka.tile_order ? ka.tile_order[tile] : ka.n_tiles - 1u - tile;
+      }
       tile = bcast(tile);
       if (tile >= ka.n_tiles) {  // the frame's queue is empty
         if (lane == 0) { lds_store(&wg_flags[0], 1u); lds_store(&hdr[k].state, (uint32_t)SLOT_FREE); }
@@ -406,6 +423,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       unsigned long long* acc = tile_acc + k * acc_stride;
       if (lane < npx) { acc[lane * 3u] = 0ull; acc[lane * 3u + 1u] = 0ull; acc[lane * 3u + 2u] = 0ull; }
       if (lane < 3u) hdr[k].nan_mask[lane] = 0ull;
+      if (lane == 3u) hdr[k].max_depth = 0u;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) {  // publish: everything before next, next before state
         lds_store(&hdr[k].tile_xy, bx | (by << 16));
@@ -443,49 +461,279 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     RT_PROF_COUNT(cnt_items);
   };
 
+  // ---- hand out (pixel, sample) pairs to the lanes that ask for one: sets the lane's tile slot / pixel slot / sample /
+  // RNG pixel and returns its pixel coordinates; true for the lanes that received one.  A lane that finishes a sample
+  // takes the next one by ballot + prefix rank — of the next item at once if this one ran dry.
+  auto hand_out = [&](bool want, uint32_t& o_px, uint32_t& o_py) -> bool {
+    const KArgs& kr = fresh_args();
+    const DevScene& sc = kr.sc;
+    const uint32_t tl = kr.tile_log2, tw = 1u << tl, pl = 2u * tl, pmask = (1u << pl) - 1u;
+    bool got = false;
+    for (;;) {
+      const unsigned long long m = wave_ballot(want);
+      if (!m) break;
+      if (it_next < it_total) {  // hand out samples of the current item
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const uint32_t w = it_next + rank;
+        const uint32_t left = it_total - it_next, asked = (uint32_t)__builtin_popcountll(m);
+        it_next += asked < left ? asked : left;
+        const uint32_t p = w & pmask;
+        const uint32_t p_py = (uint32_t)__shfl((int)py_slot, (int)p);
+        const int p_ok = __shfl((int)ok_slot, (int)p);
+        if (want && w < it_total && p_ok) {  // (a slot outside the image consumes its index and asks again)
+          const uint32_t p_px = (it_bx << tl) + (p & (tw - 1u));
+          cur_p = p; my_k = it_k; L.s = it_sbeg + (w >> pl); L.ra.pixel = p_py * sc.width + p_px; L.ra.sample = L.s;
+          o_px = p_px; o_py = p_py;
+          got = true; want = false;
+        }
+        continue;
+      }
+      // the current item has nothing (more) to hand out: on to the next one
+      if (q_done) break;
+      uint32_t k = 0, chunk = 0;
+      const int have = acquire(k, chunk);
+      if (have < 0) {
+        q_done = true;
+#ifdef RT_PROFILE
+        prof_wall_qdone = wall_clock64();
+        prof_in_tail = true;
+#endif
+        break;
+      }
+      if (have == 0) break;  // every tile slot is busy: these lanes wait
+      open_item(k, chunk);
+    }
+    return got;
+  };
+
+  // ---- a sample finished (its radiance is in L.val): add it to its pixel (raytracer.rs:203-205) ...
+  auto add_sample = [&](bool finished) {
+    if (finished) {
+      unsigned long long* acc = tile_acc + my_k * acc_stride + cur_p * 3u;
+      atomicAdd(&acc[0], sample_to_fixed(L.val[0]));
+      atomicAdd(&acc[1], sample_to_fixed(L.val[1]));
+      atomicAdd(&acc[2], sample_to_fixed(L.val[2]));
+      if (L.k >= RT_DEEP_PATH) atomicMax(&hdr[my_k].max_depth, L.k);  // (rare: tiles that breed deep paths go first next frame)
+      // NaN samples (frames one pixel wide or high; NaN scene data) added 0 above: flag the pixel instead.  Samples
+      // are clamped to [0, 1], so the sum of the channels is NaN iff one of them is.  (A plain divergent branch right
+      // here: a wave vote around it, or a cold call, cost 6-12 more spilled registers in the path loop.)
+      if (sample_is_nan((L.val[0] + L.val[1]) + L.val[2])) {
+        const unsigned long long bit = 1ull << cur_p;
+        if (sample_is_nan(L.val[0])) atomicOr(&hdr[my_k].nan_mask[0], bit);
+        if (sample_is_nan(L.val[1])) atomicOr(&hdr[my_k].nan_mask[1], bit);
+        if (sample_is_nan(L.val[2])) atomicOr(&hdr[my_k].nan_mask[2], bit);
+      }
+    }
+  };
+  // ... and count it in its tile (slot `k_of`); whoever adds a tile's last sample converts the sums and writes its pixels
+  auto count_tiles = [&](bool finished, uint32_t k_of) {
+    unsigned long long mf = wave_ballot(finished);
+    if (mf) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      while (mf) {
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)k_of, (int)__builtin_ctzll(mf));
+        const unsigned long long same = wave_ballot(finished && k_of == k);
+        mf &= ~same;
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(same);
+        uint32_t total = 0, expected = 1;
+        if (lane == 0) { total = atomicAdd(&hdr[k].finished, cnt) + cnt; expected = lds_load(&hdr[k].expected); }
+        if (bcast(total) == bcast(expected)) flush_tile(k);
+      }
+    }
+  };
+
+  // ---- hit_world (raytracer.rs:44-59) for the lanes that hold a ray
+  auto hit_world = [&](double& closest, int& best) {
+    // ---------------------------------------------------------- hit_world (raytracer.rs:44-59)
+    const DevScene& sc = fresh_args().sc;
+    const GridDesc& G = sc.grid;
+    const F64PtrK geom_k = (F64PtrK)(uintptr_t)sc.geom;
+    const U32PtrK large_k = (U32PtrK)(uintptr_t)sc.large;
+    const uint32_t n_large = G.n_large;
+    const bool has_grid = G.n[0] != 0u;
+    const RayK rk = ray_consts(L.d);
+    closest = T_MAX;
+    best = -1;
+    if (has_ray) n_segments++;
+    // (1) spheres outside the grid: every lane tests them.  The records are wave-uniform, so they
+    // arrive by scalar loads as SGPR operands; the next record is fetched while this one is tested.
+    if (n_large != 0u) {
+      const F64PtrK lg = (F64PtrK)(uintptr_t)sc.large_geom;
+      SphereGeom g; g.cx = lg[0]; g.cy = lg[1]; g.cz = lg[2]; g.r = lg[3];
+      uint32_t idx = large_k[0];
+      for (uint32_t i = 0; i < n_large; ++i) {
+        const uint32_t nx = i + 1u < n_large ? i + 1u : i;  // (the last round re-reads its own record)
+        const F64PtrK np = lg + (size_t)nx * 4u;
+        SphereGeom gn; gn.cx = np[0]; gn.cy = np[1]; gn.cz = np[2]; gn.r = np[3];
+        const uint32_t idxn = large_k[nx];
+        if (has_ray && rk.fast) exact_hit_any_order_t<true>(L.o, L.d, rk, g, idx, closest, best);
+        g = gn; idx = idxn;
+      }
+    }
+    if (has_ray && rk.fast) n_exact += n_large;
+    RT_PROF(1);
+    // (2) enter the grid
+    GridWalk w;
+    const int mode = !has_ray ? GRID_MISS : (!rk.fast ? GRID_FALLBACK : (has_grid ? grid_begin(G, L.o, L.d, w) : GRID_MISS));
+    if (wave_any(mode == GRID_FALLBACK)) {  // numerically unsafe ray: the reference's full scan, real divisions
+      for (uint32_t idx = 0; idx < sc.n_spheres; ++idx) {
+        const F64PtrK gp = geom_k + (size_t)idx * 4u;
+        SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
+        if (mode == GRID_FALLBACK) { const HitCB r = exact_hit_slow(L.o, L.d, rk.a, g, idx, closest, best); closest = r.closest; best = r.best; }
+      }
+      if (mode == GRID_FALLBACK) n_exact += sc.n_spheres;
+    }
+    if (has_grid) {
+      // (3) walk rounds: every walking lane moves on by up to two cells and/or tests one sphere.
+      // Per-lane walk state: tm = GridWalk.tmax, dt = GridWalk.delta, dl = GridWalk.dl, lin;
+      // the current cell's untested spheres are items [it, end), the next two of them also in `pend`.
+      const bool walk0 = mode == GRID_WALK;
+      float tm0 = w.tmax[0], tm1 = w.tmax[1], tm2 = w.tmax[2];
+      const float dt0 = w.delta[0], dt1 = w.delta[1], dt2 = w.delta[2];
+      const int dl0 = w.dl[0], dl1 = w.dl[1], dl2 = w.dl[2];
+      int lin = walk0 ? w.lin : 0;
+      const double t0 = w.t0;
+      const int lin_max = (int)G.n_cells - 1;
+      // A lane is walking while it <= end (it == end: cell exhausted, move on; it < end: spheres left to
+      // test); a lane that stopped has (it, end) = (1, 0).  Each predicate is ONE compare: a separate
+      // `walking` flag costs a lane-mask AND per use and a VGPR round trip in the loop's exit vote.
+      uint32_t it = 1, end = 0, pend = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
+      if (walk0) {
+        const uint2 e = cell_word[lin];
+        it = e.x & CELL_START_MASK; end = it + (e.x >> CELL_COUNT_SHIFT); pend = e.y;
+      }
+      for (;;) {
+        if (!wave_any(it <= end)) break;
+        // (a) lanes whose cell is exhausted: finished, or on to the next non-empty cell.  The next
+        // TWO cells along the ray are computed and fetched together (one LDS round trip), the
+        // second one is used only if the first is empty.
+        const bool moving = it == end;
+        {  // (no wave vote around the block: the lane mask of `if (moving)` already skips it when empty)
+#ifdef RT_PROFILE
+          if (wave_any(moving)) cnt_w_step++;
+#endif
+          if (moving) {
+            float tc = (float)(closest - t0);
+            tc = tc + fabsf(tc) * 2.384185791015625e-07f;  // grid_done
+            const bool hit = best >= 0;
+            const float tminA = rt_min3f(tm0, tm1, tm2);
+            if (hit && tc < tminA) { it = 1; end = 0; }
+            else {
+              // grid_step x 2
+              const bool ax = tm0 == tminA, ay = !ax && tm1 == tminA, az = !ax && !ay;
+              const float a0 = tm0 + (ax ? dt0 : 0.0f), a1 = tm1 + (ay ? dt1 : 0.0f), a2 = tm2 + (az ? dt2 : 0.0f);
+              const int linA = lin + (ax ? dl0 : (ay ? dl1 : dl2));
+              const float tminB = rt_min3f(a0, a1, a2);
+              const bool bx_ = a0 == tminB, by_ = !bx_ && a1 == tminB, bz_ = !bx_ && !by_;
+              const float b0 = a0 + (bx_ ? dt0 : 0.0f), b1 = a1 + (by_ ? dt1 : 0.0f), b2 = a2 + (bz_ ? dt2 : 0.0f);
+              int linB = linA + (bx_ ? dl0 : (by_ ? dl1 : dl2));
+              linB = linB < 0 ? 0 : (linB > lin_max ? lin_max : linB);  // speculative address: keep it inside the table
+              const uint2 eA = cell_word[linA];
+              const uint2 eB = cell_word[linB];
+              n_steps++;
+              const bool exitA = eA.x == CELL_EXIT, emptyA = (eA.x >> CELL_COUNT_SHIFT) == 0u;
+              const bool doneA = hit && tc < tminB;  // the closest hit lies inside cell A
+              if (exitA || !emptyA || doneA) {  // stay in A (or stop there)
+                tm0 = a0; tm1 = a1; tm2 = a2; lin = linA;
+                it = eA.x & CELL_START_MASK; end = it + (eA.x >> CELL_COUNT_SHIFT); pend = eA.y;
+                if (exitA || emptyA) { it = 1; end = 0; }
+              } else {                           // A is empty: on to B
+                n_steps++;
+                tm0 = b0; tm1 = b1; tm2 = b2; lin = linB;
+                it = eB.x & CELL_START_MASK; end = it + (eB.x >> CELL_COUNT_SHIFT); pend = eB.y;
+                if (eB.x == CELL_EXIT) { it = 1; end = 0; }
+              }
+            }
+          }
+        }
+        const bool testing = it < end;
+        {  // (b) one exact Sphere::hit per lane standing in a cell with spheres left
+#ifdef RT_PROFILE
+          if (wave_any(testing)) cnt_w_test++;
+#endif
+          if (testing) {
+            uint32_t idx = pend & 0xFFFFu;
+            if (idx == 0xFFFFu) idx = cell_items[it];  // third and later items of a cell: from the list
+            pend = (pend >> 16) | 0xFFFF0000u;
+            it++;
+            if (idx != last) {  // a sphere spanning consecutive cells is not re-tested
+              last = idx; n_exact++;
+              exact_hit_any_order_t<true>(L.o, L.d, rk, tb.geom(idx), idx, closest, best);
+            }
+          }
+        }
+      }
+    }
+  };
+
   RT_PROF(5);
   uint32_t idle_spins = 0;
+#if RT_FUSED_REFILL
+  // Loop order: trace -> rays that left the scene finish at once (sky) -> every lane without a path takes its next
+  // sample -> ONE Philox instruction stream serves the hits (unit-sphere point / Glass draw) and the new samples (camera
+  // jitter) -> shade the hits -> start the new samples.  The refill used to be a block of its own at the top of the loop
+  // with its own Philox stream (~100 of the ~1700 vector instructions of an iteration, executed by the ~38 % of lanes
+  // that had finished).  The first iteration of a wave traces nothing and only hands out samples.
+  for (;;) {
+#ifdef RT_PROFILE
+    if (q_done) { prof_tail_iters++; prof_tail_lanes += (uint32_t)__builtin_popcountll(wave_ballot(has_ray)); }
+#endif
+    RT_PROF_COUNT(cnt_w_iter);
+    RT_PROF(0);
+    double closest = T_MAX;
+    int best = -1;
+    if (wave_any(has_ray)) hit_world(closest, best);
+    RT_PROF(3);
+    // (a) a ray that left the scene ends its sample here (raytracer.rs:133-163); light rays return to their parent in (d)
+    bool miss = has_ray && best < 0;
+    if constexpr (HL) miss = miss && !L.in_light;
+    const uint32_t k_miss = my_k;
+    if (wave_any(miss)) {
+      if (miss) {
+        lane_finish_sample(L, sky_color(fresh_args().sc, L.d, L.n_tex_oob));
+        has_ray = false;
+      }
+      add_sample(miss);
+    }
+    RT_PROF(4);
+    // (b) every lane without a path takes its next sample
+    uint32_t n_px = 0, n_py = 0;
+    const bool fresh = hand_out(!has_ray, n_px, n_py);
+    RT_PROF(0);
+    // (c) the random numbers of this iteration, one instruction stream
+    const uint32_t hit_kind = has_ray && best >= 0 ? tb.mat((uint32_t)best).kind : 0xFFFFFFFFu;
+    double glass_u;
+    U4 cam_w;
+    const V3 rnd = coop_random_in_unit_sphere(hit_kind != 0xFFFFFFFFu && material_draws_unit_sphere(hit_kind), hit_kind == RT_MAT_GLASS, fresh,
+                                              L.ra, L.node, lane, coop_xch, glass_u, cam_w);
+    // (d) shade the hits
+    bool finished = false;
+    if (has_ray) finished = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u);
+    RT_PROF(2);
+    if (wave_any(finished)) {
+      if (finished) has_ray = false;
+      add_sample(finished);
+    }
+    count_tiles(miss || finished, miss ? k_miss : my_k);
+    RT_PROF(4);
+    // (e) the new samples start (raytracer.rs:199-201, camera.rs:79-84)
+    if (fresh) { lane_begin_sample_w(fresh_args().sc, L, n_px, n_py, cam_w); has_ray = true; }
+    RT_PROF(0);
+    if (!wave_any(has_ray)) {
+      // nothing in flight.  Done when the frame has nothing left; otherwise (all tile slots are busy with other waves'
+      // long paths) wait a little and ask again — bounded, a wave may always retire: the samples it traced are already
+      // counted in their tiles.
+      if (q_done || ++idle_spins > (1u << 16)) break;
+      __builtin_amdgcn_s_sleep(32);
+    } else idle_spins = 0;
+  }
+#else
   for (;;) {
     // ------------------------------------------------------------ refill lanes that hold no path
     {
-      const KArgs& kr = fresh_args();
-      const DevScene& sc = kr.sc;
-      const uint32_t tl = kr.tile_log2, tw = 1u << tl, pl = 2u * tl, pmask = (1u << pl) - 1u;
-      bool want = !has_ray;
-      for (;;) {
-        const unsigned long long m = wave_ballot(want);
-        if (!m) break;
-        if (it_next < it_total) {  // hand out samples of the current item
-          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          const uint32_t w = it_next + rank;
-          const uint32_t left = it_total - it_next, asked = (uint32_t)__builtin_popcountll(m);
-          it_next += asked < left ? asked : left;
-          const uint32_t p = w & pmask;
-          const uint32_t p_py = (uint32_t)__shfl((int)py_slot, (int)p);
-          const int p_ok = __shfl((int)ok_slot, (int)p);
-          if (want && w < it_total && p_ok) {  // (a slot outside the image consumes its index and asks again)
-            const uint32_t p_px = (it_bx << tl) + (p & (tw - 1u));
-            cur_p = p; my_k = it_k; L.s = it_sbeg + (w >> pl); L.ra.pixel = p_py * sc.width + p_px;
-            lane_begin_sample(sc, L, p_px, p_py);
-            has_ray = true; want = false;
-          }
-          continue;
-        }
-        // the current item has nothing (more) to hand out: on to the next one
-        if (q_done) break;
-        uint32_t k = 0, chunk = 0;
-        const int got = acquire(k, chunk);
-        if (got < 0) {
-          q_done = true;
-#ifdef RT_PROFILE
-          prof_wall_qdone = wall_clock64();
-          prof_in_tail = true;
-#endif
-          break;
-        }
-        if (got == 0) break;  // every tile slot is busy: these lanes wait
-        open_item(k, chunk);
-      }
+      uint32_t n_px = 0, n_py = 0;
+      const bool got = hand_out(!has_ray, n_px, n_py);
+      if (got) { lane_begin_sample(fresh_args().sc, L, n_px, n_py); has_ray = true; }
     }
     if (!wave_any(has_ray)) {
       // nothing in flight.  Done when the frame has nothing left; otherwise (all tile slots are
@@ -502,176 +750,26 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 #endif
     RT_PROF_COUNT(cnt_w_iter);
     RT_PROF(0);
-    {
-      // ---------------------------------------------------------- hit_world (raytracer.rs:44-59)
-      const DevScene& sc = fresh_args().sc;
-      const GridDesc& G = sc.grid;
-      const F64PtrK geom_k = (F64PtrK)(uintptr_t)sc.geom;
-      const U32PtrK large_k = (U32PtrK)(uintptr_t)sc.large;
-      const uint32_t n_large = G.n_large;
-      const bool has_grid = G.n[0] != 0u;
-      const RayK rk = ray_consts(L.d);
-      double closest = T_MAX;
-      int best = -1;
-      if (has_ray) n_segments++;
-      // (1) spheres outside the grid: every lane tests them.  The records are wave-uniform, so they
-      // arrive by scalar loads as SGPR operands; the next record is fetched while this one is tested.
-      if (n_large != 0u) {
-        const F64PtrK lg = (F64PtrK)(uintptr_t)sc.large_geom;
-        SphereGeom g; g.cx = lg[0]; g.cy = lg[1]; g.cz = lg[2]; g.r = lg[3];
-        uint32_t idx = large_k[0];
-        for (uint32_t i = 0; i < n_large; ++i) {
-          const uint32_t nx = i + 1u < n_large ? i + 1u : i;  // (the last round re-reads its own record)
-          const F64PtrK np = lg + (size_t)nx * 4u;
-          SphereGeom gn; gn.cx = np[0]; gn.cy = np[1]; gn.cz = np[2]; gn.r = np[3];
-          const uint32_t idxn = large_k[nx];
-          if (has_ray && rk.fast) exact_hit_any_order_t<true>(L.o, L.d, rk, g, idx, closest, best);
-          g = gn; idx = idxn;
-        }
-      }
-      if (has_ray && rk.fast) n_exact += n_large;
-      RT_PROF(1);
-      // (2) enter the grid
-      GridWalk w;
-      const int mode = !has_ray ? GRID_MISS : (!rk.fast ? GRID_FALLBACK : (has_grid ? grid_begin(G, L.o, L.d, w) : GRID_MISS));
-      if (wave_any(mode == GRID_FALLBACK)) {  // numerically unsafe ray: the reference's full scan, real divisions
-        for (uint32_t idx = 0; idx < sc.n_spheres; ++idx) {
-          const F64PtrK gp = geom_k + (size_t)idx * 4u;
-          SphereGeom g; g.cx = gp[0]; g.cy = gp[1]; g.cz = gp[2]; g.r = gp[3];
-          if (mode == GRID_FALLBACK) { const HitCB r = exact_hit_slow(L.o, L.d, rk.a, g, idx, closest, best); closest = r.closest; best = r.best; }
-        }
-        if (mode == GRID_FALLBACK) n_exact += sc.n_spheres;
-      }
-      if (has_grid) {
-        // (3) walk rounds: every walking lane moves on by up to two cells and/or tests one sphere.
-        // Per-lane walk state: tm = GridWalk.tmax, dt = GridWalk.delta, dl = GridWalk.dl, lin;
-        // the current cell's untested spheres are items [it, end), the next two of them also in `pend`.
-        const bool walk0 = mode == GRID_WALK;
-        float tm0 = w.tmax[0], tm1 = w.tmax[1], tm2 = w.tmax[2];
-        const float dt0 = w.delta[0], dt1 = w.delta[1], dt2 = w.delta[2];
-        const int dl0 = w.dl[0], dl1 = w.dl[1], dl2 = w.dl[2];
-        int lin = walk0 ? w.lin : 0;
-        const double t0 = w.t0;
-        const int lin_max = (int)G.n_cells - 1;
-        // A lane is walking while it <= end (it == end: cell exhausted, move on; it < end: spheres left to
-        // test); a lane that stopped has (it, end) = (1, 0).  Each predicate is ONE compare: a separate
-        // `walking` flag costs a lane-mask AND per use and a VGPR round trip in the loop's exit vote.
-        uint32_t it = 1, end = 0, pend = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
-        if (walk0) {
-          const uint2 e = cell_word[lin];
-          it = e.x & CELL_START_MASK; end = it + (e.x >> CELL_COUNT_SHIFT); pend = e.y;
-        }
-        for (;;) {
-          if (!wave_any(it <= end)) break;
-          // (a) lanes whose cell is exhausted: finished, or on to the next non-empty cell.  The next
-          // TWO cells along the ray are computed and fetched together (one LDS round trip), the
-          // second one is used only if the first is empty.
-          const bool moving = it == end;
-          {  // (no wave vote around the block: the lane mask of `if (moving)` already skips it when empty)
-#ifdef RT_PROFILE
-            if (wave_any(moving)) cnt_w_step++;
-#endif
-            if (moving) {
-              float tc = (float)(closest - t0);
-              tc = tc + fabsf(tc) * 2.384185791015625e-07f;  // grid_done
-              const bool hit = best >= 0;
-              const float tminA = rt_min3f(tm0, tm1, tm2);
-              if (hit && tc < tminA) { it = 1; end = 0; }
-              else {
-                // grid_step x 2
-                const bool ax = tm0 == tminA, ay = !ax && tm1 == tminA, az = !ax && !ay;
-                const float a0 = tm0 + (ax ? dt0 : 0.0f), a1 = tm1 + (ay ? dt1 : 0.0f), a2 = tm2 + (az ? dt2 : 0.0f);
-                const int linA = lin + (ax ? dl0 : (ay ? dl1 : dl2));
-                const float tminB = rt_min3f(a0, a1, a2);
-                const bool bx_ = a0 == tminB, by_ = !bx_ && a1 == tminB, bz_ = !bx_ && !by_;
-                const float b0 = a0 + (bx_ ? dt0 : 0.0f), b1 = a1 + (by_ ? dt1 : 0.0f), b2 = a2 + (bz_ ? dt2 : 0.0f);
-                int linB = linA + (bx_ ? dl0 : (by_ ? dl1 : dl2));
-                linB = linB < 0 ? 0 : (linB > lin_max ? lin_max : linB);  // speculative address: keep it inside the table
-                const uint2 eA = cell_word[linA];
-                const uint2 eB = cell_word[linB];
-                n_steps++;
-                const bool exitA = eA.x == CELL_EXIT, emptyA = (eA.x >> CELL_COUNT_SHIFT) == 0u;
-                const bool doneA = hit && tc < tminB;  // the closest hit lies inside cell A
-                if (exitA || !emptyA || doneA) {  // stay in A (or stop there)
-                  tm0 = a0; tm1 = a1; tm2 = a2; lin = linA;
-                  it = eA.x & CELL_START_MASK; end = it + (eA.x >> CELL_COUNT_SHIFT); pend = eA.y;
-                  if (exitA || emptyA) { it = 1; end = 0; }
-                } else {                           // A is empty: on to B
-                  n_steps++;
-                  tm0 = b0; tm1 = b1; tm2 = b2; lin = linB;
-                  it = eB.x & CELL_START_MASK; end = it + (eB.x >> CELL_COUNT_SHIFT); pend = eB.y;
-                  if (eB.x == CELL_EXIT) { it = 1; end = 0; }
-                }
-              }
-            }
-          }
-          const bool testing = it < end;
-          {  // (b) one exact Sphere::hit per lane standing in a cell with spheres left
-#ifdef RT_PROFILE
-            if (wave_any(testing)) cnt_w_test++;
-#endif
-            if (testing) {
-              uint32_t idx = pend & 0xFFFFu;
-              if (idx == 0xFFFFu) idx = cell_items[it];  // third and later items of a cell: from the list
-              pend = (pend >> 16) | 0xFFFF0000u;
-              it++;
-              if (idx != last) {  // a sphere spanning consecutive cells is not re-tested
-                last = idx; n_exact++;
-                exact_hit_any_order_t<true>(L.o, L.d, rk, tb.geom(idx), idx, closest, best);
-              }
-            }
-          }
-        }
-      }
-      RT_PROF(3);
-
-      // ---------------------------------------------------------- ray_color body
-      bool finished = false;
-#if RT_COOP_RANDOM
-      // the unit-sphere point most hits need is drawn by the whole wave together
-      const uint32_t hit_kind = has_ray && best >= 0 ? tb.mat((uint32_t)best).kind : 0xFFFFFFFFu;
-      double glass_u;
-      const V3 rnd = coop_random_in_unit_sphere(hit_kind != 0xFFFFFFFFu && material_draws_unit_sphere(hit_kind), hit_kind == RT_MAT_GLASS,
-                                                L.ra, L.node, lane, coop_xch, glass_u);
-      if (has_ray) finished = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u);
-#else
-      if (has_ray) finished = lane_shade(fresh_args().sc, tb, L, best, closest);
-#endif
-      RT_PROF(2);
-      if (has_ray) {
-        if (finished) {  // sample finished: add it to its pixel (raytracer.rs:203-205)
-          unsigned long long* acc = tile_acc + my_k * acc_stride + cur_p * 3u;
-          atomicAdd(&acc[0], sample_to_fixed(L.val[0]));
-          atomicAdd(&acc[1], sample_to_fixed(L.val[1]));
-          atomicAdd(&acc[2], sample_to_fixed(L.val[2]));
-          // NaN samples (frames one pixel wide or high; NaN scene data) added 0 above: flag the pixel instead.  Samples
-          // are clamped to [0, 1], so the sum of the channels is NaN iff one of them is.  (A plain divergent branch right
-          // here: a wave vote around it, or a cold call, cost 6-12 more spilled registers in the path loop.)
-          if (sample_is_nan((L.val[0] + L.val[1]) + L.val[2])) {
-            const unsigned long long bit = 1ull << cur_p;
-            if (sample_is_nan(L.val[0])) atomicOr(&hdr[my_k].nan_mask[0], bit);
-            if (sample_is_nan(L.val[1])) atomicOr(&hdr[my_k].nan_mask[1], bit);
-            if (sample_is_nan(L.val[2])) atomicOr(&hdr[my_k].nan_mask[2], bit);
-          }
-          has_ray = false;
-        }
-      }
-      unsigned long long mf = wave_ballot(finished);
-      if (mf) {  // count the finished samples per tile; whoever adds a tile's last sample writes its pixels
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        while (mf) {
-          const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)my_k, (int)__builtin_ctzll(mf));
-          const unsigned long long same = wave_ballot(finished && my_k == k);
-          mf &= ~same;
-          const uint32_t cnt = (uint32_t)__builtin_popcountll(same);
-          uint32_t total = 0, expected = 1;
-          if (lane == 0) { total = atomicAdd(&hdr[k].finished, cnt) + cnt; expected = lds_load(&hdr[k].expected); }
-          if (bcast(total) == bcast(expected)) flush_tile(k);
-        }
-      }
-      RT_PROF(4);
-    }
+    double closest;
+    int best;
+    hit_world(closest, best);
+    RT_PROF(3);
+    // ---------------------------------------------------------- ray_color body
+    // the unit-sphere point most hits need is drawn by the whole wave together
+    const uint32_t hit_kind = has_ray && best >= 0 ? tb.mat((uint32_t)best).kind : 0xFFFFFFFFu;
+    double glass_u;
+    U4 cam_w;
+    const V3 rnd = coop_random_in_unit_sphere(hit_kind != 0xFFFFFFFFu && material_draws_unit_sphere(hit_kind), hit_kind == RT_MAT_GLASS, false,
+                                              L.ra, L.node, lane, coop_xch, glass_u, cam_w);
+    bool finished = false;
+    if (has_ray) finished = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u);
+    RT_PROF(2);
+    if (finished) has_ray = false;
+    add_sample(finished);
+    count_tiles(finished, my_k);
+    RT_PROF(4);
   }
+#endif
 
   // counters: wave reduction, one atomic per wave
   unsigned long long c0 = n_segments, c1 = n_exact, c2 = L.n_tex_oob, c3 = n_steps;
@@ -712,6 +810,36 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         else if (v) atomicAdd(&ka.counters[k], v);
       }
     }
+  }
+}
+
+// --------------------------------------------------------------------------- queue order for the next frame
+// tile_order <- the tiles sorted by descending tile_depth (counting sort over 64 depth buckets, one workgroup).
+// Stream-ordered behind the frame that measured the depths: a few microseconds.
+__global__ __launch_bounds__(1024) void rt_order_tiles(const uint32_t* __restrict__ tile_depth, uint32_t* __restrict__ tile_order, uint32_t n_tiles) {
+  __shared__ uint32_t hist[64], start[64];
+  if (threadIdx.x < 64u) hist[threadIdx.x] = 0u;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n_tiles; i += blockDim.x) {
+    const uint32_t d = tile_depth[i] < 63u ? tile_depth[i] : 63u;
+    atomicAdd(&hist[d], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t o = 0;
+    for (int d = 63; d >= 0; --d) { start[d] = o; o += hist[d]; }
+  }
+  __syncthreads();
+  // scatter, walking the tiles bottom-up in blocks of the workgroup's size: inside a depth bucket the order is
+  // bottom-of-image-first up to a block's worth of shuffling (the image never depends on the order, only the tail does)
+  for (uint32_t base = 0; base < n_tiles; base += blockDim.x) {
+    const uint32_t j = base + threadIdx.x;
+    if (j < n_tiles) {
+      const uint32_t i = n_tiles - 1u - j;
+      const uint32_t d = tile_depth[i] < 63u ? tile_depth[i] : 63u;
+      tile_order[atomicAdd(&start[d], 1u)] = i;
+    }
+    __syncthreads();
   }
 }
 

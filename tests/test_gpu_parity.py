@@ -39,7 +39,7 @@ def torch_cuda():
 def gpu_render(pkg, abi, torch_cuda):
     torch = torch_cuda
 
-    def _render(scene, tiles=None, variant=0, want_linear=True, pool=None, chunk_spp=None, tile_log2=None):
+    def _render(scene, tiles=None, variant=0, want_linear=True, pool=None, chunk_spp=None, tile_log2=None, tile_order=None, frames=1):
         """variant 0: the product kernel (grid walk, tile queue, exact fixed-point pixel sums);
         variant 1: same kernel, the reference's brute force over all spheres.  chunk_spp: samples of a
         pixel per work item; tile_log2: pixel tiles of 2^k x 2^k."""
@@ -54,10 +54,13 @@ def gpu_render(pkg, abi, torch_cuda):
             gs.set_option("chunk_spp", chunk_spp)
         if tile_log2 is not None:
             gs.set_option("tile_log2", tile_log2)
+        if tile_order is not None:
+            gs.set_option("tile_order", tile_order)
         rgb = torch.zeros((rows, sc.width, 3), dtype=torch.uint8, device="cuda:0")
         lin = torch.zeros((rows, sc.width, 3), dtype=torch.float32, device="cuda:0") if want_linear else None
-        gs.render(rgb.data_ptr(), lin.data_ptr() if want_linear else 0, tiles, torch.cuda.current_stream().cuda_stream)
-        st = gs.wait()
+        for _ in range(frames):   # (frames > 1: the later frames use the queue order learnt from the one before)
+            gs.render(rgb.data_ptr(), lin.data_ptr() if want_linear else 0, tiles, torch.cuda.current_stream().cuda_stream)
+            st = gs.wait()
         out = rgb.cpu().numpy(), (lin.cpu().numpy() if want_linear else None), st
         gs.close()
         return out
@@ -152,6 +155,13 @@ def test_work_distribution_stress(gpu_render, load_scene):
             rgb, lin, st = gpu_render(sc, chunk_spp=cs, tile_log2=tl)
             assert np.array_equal(rgb, ref_rgb) and np.array_equal(lin, ref_lin), (tl, cs)
             assert st["segments"] == ref_st["segments"] and st["samples"] == 203 * 117 * 5
+    # the order in which tiles leave the queue (top row first / bottom row first / deepest tiles of the previous frame
+    # first, over three frames of one resident scene) changes nothing either
+    for order in (0, 1, 2):
+        for tl in (None, 0, 3):
+            rgb, lin, st = gpu_render(sc, tile_order=order, tile_log2=tl, frames=3 if order == 2 else 1)
+            assert np.array_equal(rgb, ref_rgb) and np.array_equal(lin, ref_lin), (order, tl)
+            assert st["segments"] == ref_st["segments"]
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])

@@ -26,20 +26,18 @@ SCAN = ["-DRT_WITH_SCAN_KERNEL"]   # the round-1 cull-scan kernel is compiled in
 VARIANTS = {
     # (slow reference arms first: whatever is measured right after a 100+ ms kernel reads ~4 % high)
     "brute_force_on_gpu": (W4, {"variant": 1}, {}),
-    "round1_scan_kernel": (W4 + SCAN, {"variant": 2}, {}),
     "warmup_default": (W4, {}, {}),
     "default": (W4, {}, {}),
-    "fast_sqrt": (W4 + ["-DRT_FAST_SQRT=1"], {}, {}),
-    "coop_layers8": (W4 + ["-DRT_COOP_LAYERS=8u"], {}, {}),
-    "fast_sqrt_layers8": (W4 + ["-DRT_FAST_SQRT=1", "-DRT_COOP_LAYERS=8u"], {}, {}),
-    "waves3": (["-DRT_WAVES_PER_EU=3"], {}, {}),
-    "tile8x8_chunk8": (W4, {"tile_log2": 3, "chunk_spp": 8}, {}),
-    "tile4x4_chunk16": (W4, {"tile_log2": 2, "chunk_spp": 16}, {}),
 }
-ARMS_FILE = os.path.join(AB, "arms.json")   # extra arms for one session: {"name": [[flags], {options}, {env}]}
+# extra arms for one session: tools/ab_arms.json {"name": [[flags], {options}, {env}, "optional source root"]} — the source
+# root is another checkout of this repository (e.g. `git worktree add /tmp/prev <commit>`): the arm is built from ITS kernel
+ARMS_FILE = os.path.join(ROOT, "tools", "ab_arms.json")
+SRC_OF = {}
 if os.path.exists(ARMS_FILE):
     for k_, v_ in json.load(open(ARMS_FILE)).items():
         VARIANTS[k_] = (list(v_[0]), dict(v_[1]), dict(v_[2]))
+        if len(v_) > 3 and v_[3]:
+            SRC_OF[k_] = os.path.join(v_[3], "rust-raytracer_amd", "csrc", "hip", "rt_hip_api.hip")
 
 
 def build():
@@ -47,14 +45,14 @@ def build():
     built = {}
     for name, (flags, _, _) in VARIANTS.items():
         out = os.path.join(AB, f"librt_hip_{name}.so")
-        key = tuple(flags)
+        key = tuple(flags) + (SRC_OF.get(name, SRC),)
         if key in built:  # same binary, different runtime options
             if os.path.lexists(out):
                 os.remove(out)
             os.link(built[key], out)
             continue
         built[key] = out
-        cmd = BASE + flags + [SRC, "-o", out]
+        cmd = BASE + flags + [SRC_OF.get(name, SRC), "-o", out]
         print("+", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 

@@ -40,6 +40,13 @@ if [[ " $* " == *" configs "* ]]; then
     for SH in 0,2,2 1,2,2 0,4,2 3,4,2 0,8,2 3,8,2 7,8,2; do
       echo -n "shard $SH "; timeout 60 python tools/diag.py --shard $SH --reps 10 2>/dev/null | tail -1 | cut -c 50-140
     done
+    echo "# queue order (tile_order 0 = top row first, 1 = bottom row first, 2 = deepest tiles of the previous frame first): 1/8 shards, whole frame"
+    for O in 0 1 2; do
+      for SH in 0,8,2 3,8,2 7,8,2; do
+        echo -n "order $O shard $SH "; timeout 60 python tools/diag.py --shard $SH --reps 10 --opt tile_order=$O 2>/dev/null | tail -1 | cut -c 50-140
+      done
+      echo -n "order $O whole frame "; timeout 60 python tools/diag.py --reps 6 --opt tile_order=$O 2>/dev/null | tail -1 | cut -c 50-140
+    done
     if [ -f build/ab/librt_hip_prof.so ]; then
       echo "# RT_PROFILE build: section shares, wave timeline (full frame, then rank 3 of 8)"
       timeout 60 python tools/diag.py --lib build/ab/librt_hip_prof.so --reps 5 2>/dev/null | tail -1
