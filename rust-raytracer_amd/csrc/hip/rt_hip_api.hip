@@ -52,6 +52,7 @@ struct RtHipScene {
   uint32_t* d_tile_depth = nullptr; uint32_t* d_tile_order = nullptr; size_t order_cap = 0;
   uint64_t order_key = 0;   // geometry (+ row tiles) the order buffers belong to; 0 = none yet
   bool order_ready = false; // d_tile_order holds an order for order_key
+  int order_age = 0;        // frames since the order was last invalidated (geometry / camera / option change)
   int order_mode = 2;       // "tile_order" option: 0 top row first, 1 bottom row first, 2 deepest tiles of the previous frame first
   int chunk_spp = 0;       // 0 = automatic
   int tile_log2 = -1;      // -1 = automatic; else tiles of 2^k x 2^k pixels, k = 0..3
@@ -198,7 +199,7 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
   if (!std::strcmp(key, "variant")) { if (value < 0 || value > max_variant) return fail(RT_ERR_INVALID, "variant must be 0 (grid walk) or 1 (brute force)"); s->variant = (int)value; return RT_OK; }
   if (!std::strcmp(key, "pool")) { s->pool = value != 0; return RT_OK; }
   if (!std::strcmp(key, "tile_log2")) { if (value < -1 || value > 3) return fail(RT_ERR_INVALID, "tile_log2 must be -1..3"); s->tile_log2 = (int)value; return RT_OK; }
-  if (!std::strcmp(key, "tile_order")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_order must be 0, 1 or 2"); s->order_mode = (int)value; s->order_ready = false; return RT_OK; }
+  if (!std::strcmp(key, "tile_order")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_order must be 0, 1 or 2"); s->order_mode = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
   if (!std::strcmp(key, "chunk_spp")) { if (value < 0) return fail(RT_ERR_INVALID, "chunk_spp must be >= 0"); s->chunk_spp = (int)value; return RT_OK; }
   if (!std::strcmp(key, "samples_per_pixel") || !std::strcmp(key, "max_depth")) {
     if (value < 0 || value > (int64_t)0xFFFFFFFFll) return fail(RT_ERR_INVALID, std::string(key) + " must be in 0 .. 2^32-1");
@@ -363,7 +364,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
       RT_HIP_TRY(hipMalloc((void**)&s->d_tile_order, (size_t)ka.n_tiles * 4));
       s->order_cap = ka.n_tiles;
     }
-    if (key != s->order_key) { s->order_key = key; s->order_ready = false; }
+    if (key != s->order_key) { s->order_key = key; s->order_ready = false; s->order_age = 0; }
     ka.tile_depth = s->d_tile_depth;
     if (s->order_ready) ka.tile_order = s->d_tile_order;
   }
@@ -376,7 +377,11 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   if (rc != RT_OK) return rc;
   RT_HIP_TRY(hipGetLastError());
   RT_HIP_TRY(hipEventRecord(s->ev_stop, stream));
-  if (ka.tile_depth) {  // the next frame's order, from this frame's depths (stream-ordered: ready before the next launch reads it)
+  // The next frame's order from this frame's depths (stream-ordered: ready before the next launch reads it).  Which tiles
+  // breed deep paths is a property of scene and camera, so the order is rebuilt after the first two frames of a view
+  // only — later frames of the same view reuse it and pay nothing; rt_hip_set_camera starts over.
+  if (ka.tile_depth && s->order_age < 2) {
+    s->order_age++;
     hipLaunchKernelGGL(rtk::rt_order_tiles, dim3(1), dim3(1024), 0, stream, (const uint32_t*)s->d_tile_depth, s->d_tile_order, ka.n_tiles);
     RT_HIP_TRY(hipGetLastError());
     s->order_ready = true;
@@ -434,6 +439,7 @@ extern "C" int rt_hip_set_camera(RtHipScene* s, const double origin[3], const do
     s->host.cam_horizontal[i] = s->dev.cam_h[i] = horizontal[i];
     s->host.cam_vertical[i] = s->dev.cam_v[i] = vertical[i];
   }
+  s->order_age = 0;  // the previous view's order stays in use (the views of an animation are close); rebuilt from this frame on
   return RT_OK;
 }
 

@@ -814,32 +814,36 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 }
 
 // --------------------------------------------------------------------------- queue order for the next frame
-// tile_order <- the tiles sorted by descending tile_depth (counting sort over 64 depth buckets, one workgroup).
-// Stream-ordered behind the frame that measured the depths: a few microseconds.
+// tile_order <- the tiles sorted by descending tile_depth (counting sort over 64 depth buckets, one workgroup; the
+// histograms and scatter cursors are private to each wave so that the bulk bucket — tiles without a deep path — does not
+// serialise the whole workgroup on one LDS word).  Inside a bucket: bottom of the image first, up to the interleaving of
+// the 16 waves.  Stream-ordered behind the frame that measured the depths.
 __global__ __launch_bounds__(1024) void rt_order_tiles(const uint32_t* __restrict__ tile_depth, uint32_t* __restrict__ tile_order, uint32_t n_tiles) {
-  __shared__ uint32_t hist[64], start[64];
-  if (threadIdx.x < 64u) hist[threadIdx.x] = 0u;
+  __shared__ uint32_t hist[16][64], start[16][64], total[64];
+  const uint32_t w = threadIdx.x >> 6;
+  for (uint32_t i = threadIdx.x; i < 16u * 64u; i += blockDim.x) (&hist[0][0])[i] = 0u;
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n_tiles; i += blockDim.x) {
-    const uint32_t d = tile_depth[i] < 63u ? tile_depth[i] : 63u;
-    atomicAdd(&hist[d], 1u);
+  for (uint32_t j = threadIdx.x; j < n_tiles; j += blockDim.x) {
+    const uint32_t t = tile_depth[n_tiles - 1u - j];
+    atomicAdd(&hist[w][t < 63u ? t : 63u], 1u);
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64u) {
     uint32_t o = 0;
-    for (int d = 63; d >= 0; --d) { start[d] = o; o += hist[d]; }
+    for (uint32_t k = 0; k < 16u; ++k) o += hist[k][threadIdx.x];
+    total[threadIdx.x] = o;
   }
   __syncthreads();
-  // scatter, walking the tiles bottom-up in blocks of the workgroup's size: inside a depth bucket the order is
-  // bottom-of-image-first up to a block's worth of shuffling (the image never depends on the order, only the tail does)
-  for (uint32_t base = 0; base < n_tiles; base += blockDim.x) {
-    const uint32_t j = base + threadIdx.x;
-    if (j < n_tiles) {
-      const uint32_t i = n_tiles - 1u - j;
-      const uint32_t d = tile_depth[i] < 63u ? tile_depth[i] : 63u;
-      tile_order[atomicAdd(&start[d], 1u)] = i;
-    }
-    __syncthreads();
+  if (threadIdx.x < 64u) {  // bucket d starts after all deeper buckets; inside it wave 0's tiles, then wave 1's, ...
+    const uint32_t d = threadIdx.x;
+    uint32_t o = 0;
+    for (uint32_t e = 63u; e > d; --e) o += total[e];
+    for (uint32_t k = 0; k < 16u; ++k) { start[k][d] = o; o += hist[k][d]; }
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < n_tiles; j += blockDim.x) {
+    const uint32_t i = n_tiles - 1u - j, t = tile_depth[i];
+    tile_order[atomicAdd(&start[w][t < 63u ? t : 63u], 1u)] = i;
   }
 }
 
