@@ -62,7 +62,7 @@ struct CullPair {  // 32 B
 #endif
 constexpr uint32_t CULL_CHUNK = RT_CULL_CHUNK;  // pairs per scan chunk; the table is padded to this
 
-// Per-sphere fields every hit needs besides the geometry (32 B; the LDS copy of the material
+// Per-sphere fields every hit needs besides the geometry (48 B; the LDS copy of the material
 // table).  Texture parameters stay in the 64 B SphereMat and are fetched only when a Texture
 // sphere is hit.
 struct MatCore {
@@ -70,6 +70,10 @@ struct MatCore {
   uint32_t kind;
   double fuzz_or_ior;
   double inv_r;  // RN(1/radius) for div_by_recip (sphere.rs:60), or 0: divide the slow way
+  // Glass: r0 of Schlick's reflectance (materials.rs:152-153: ((1 - ri) / (1 + ri))^2) for the two refraction ratios a
+  // hit can have — [0] front face, ri = RN(1/ior); [1] back face, ri = ior — divided and squared once on the host
+  // with the reference's own operations instead of one IEEE division per Glass hit
+  double r0[2];
 };
 // Glass ignores its albedo (attenuation is white, materials.rs:178): those bytes carry 1/ior, the
 // quotient materials.rs:181 computes at every front-face hit, divided once on the host instead.
@@ -549,9 +553,11 @@ RT_HD V3 refract(V3 uv, V3 n, double etai_over_etat) {                     // :1
   V3 r_out_parallel = muls(n, -1.0 * rt_sqrt(fabs(1.0 - length_squared(r_out_perp))));
   return add(r_out_perp, r_out_parallel);
 }
-RT_HD double reflectance(double cosine, double ref_idx) {                  // :151-155
+RT_HD double reflectance_r0(double ref_idx) {                              // :152-153
   double r0 = (1.0 - ref_idx) / (1.0 + ref_idx);
-  r0 = r0 * r0;
+  return r0 * r0;
+}
+RT_HD double reflectance_from_r0(double cosine, double r0) {               // :154
   double x = 1.0 - cosine;
   double x2 = x * x, x4 = x2 * x2;
   return r0 + (1.0 - r0) * (x * x4);  // powi(5)
@@ -728,15 +734,25 @@ RT_HD int scatter(const DevScene& sc, const RngAddr& ra, uint32_t node, V3 in_di
       double refraction_ratio = h.front_face ? matcore_inv_ior(m) : m.fuzz_or_ior;  // :180-184 (1/ior precomputed)
       V3 unit_direction = unit_vector_fast(in_dir);
       double cos_theta = fmin(dot(neg(unit_direction), h.normal), 1.0);
-      double sin_theta = rt_sqrt(1.0 - cos_theta * cos_theta);
-      bool do_reflect = refraction_ratio * sin_theta > 1.0;
+      // :187-188  cannot_refract = refraction_ratio * sqrt(1 - cos^2) > 1.  The square root is only compared: with
+      // s2 = 1 - cos^2 in [0, 1], ratio < 1 makes RN(ratio * sqrt(s2)) <= ratio < 1 (false, also for NaN); otherwise
+      // ratio^2 * s2 decides unless it lies within 1e-9 of 1 (the two roundings of either form are ~1e-16), and only
+      // that sliver (or a NaN) evaluates the reference's expression — one library sqrt less per Glass hit.
+      const double s2 = 1.0 - cos_theta * cos_theta;
+      bool do_reflect = false;
+      if (!(refraction_ratio < 1.0)) {
+        const double t2 = (refraction_ratio * refraction_ratio) * s2;
+        if (t2 > 1.000000001) do_reflect = true;
+        else if (!(t2 < 0.999999999)) do_reflect = refraction_ratio * rt_sqrt(s2) > 1.0;
+      }
       if (!do_reflect) {  // (the draw is addressed by counter: taking it early or not at all changes nothing else)
         double u;
         if (glass_u_pre) u = *glass_u_pre;
         else { U4 w = rng(ra, node, 0); u = u01_53(w.x, w.y); }
-        do_reflect = reflectance(cos_theta, refraction_ratio) > u;
+        do_reflect = reflectance_from_r0(cos_theta, m.r0[h.front_face ? 0 : 1]) > u;
       }
-      out_dir = do_reflect ? reflect(unit_direction, h.normal) : refract(unit_direction, h.normal, refraction_ratio);
+      if (do_reflect) out_dir = reflect(unit_direction, h.normal);
+      else out_dir = refract(unit_direction, h.normal, refraction_ratio);
       return SCATTER_RAY;
     }
     default:

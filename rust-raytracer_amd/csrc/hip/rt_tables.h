@@ -249,7 +249,13 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
     mc.albedo[0] = m.albedo[0]; mc.albedo[1] = m.albedo[1]; mc.albedo[2] = m.albedo[2];
     mc.kind = m.kind; mc.fuzz_or_ior = m.fuzz_or_ior;
     mc.inv_r = recip_safe(s.radius) ? 1.0 / s.radius : 0.0;
-    if (s.kind == RT_MAT_GLASS) matcore_set_inv_ior(mc, 1.0 / s.fuzz_or_ior);  // materials.rs:181: 1.0 / ir, divided once here
+    mc.r0[0] = mc.r0[1] = 0.0;
+    if (s.kind == RT_MAT_GLASS) {
+      const double inv_ior = 1.0 / s.fuzz_or_ior;   // materials.rs:181: 1.0 / ir, divided once here
+      matcore_set_inv_ior(mc, inv_ior);
+      mc.r0[0] = reflectance_r0(inv_ior);           // materials.rs:152-153 for the front-face ratio ...
+      mc.r0[1] = reflectance_r0(s.fuzz_or_ior);     // ... and the back-face ratio
+    }
     t.matc[i] = mc;
     if (s.kind == RT_MAT_LIGHT) t.lights.push_back(i);
     if (s.kind == RT_MAT_LAMBERTIAN || s.kind == RT_MAT_METAL)
