@@ -340,3 +340,29 @@ def test_fuzz_worlds_lane_logic_matches_the_oracle(hostsim, oracle, abi, host, k
     # segments than the literal restatement, same radiance)
     assert 0 < int(h_st["segments"]) <= int(o_st["segments"]) and len(sc.lights()) == 2
     assert_parity(h_rgb, h_lin, o_rgb, o_lin, f"fuzz world {kind}", atol=pooled_atol(sc.c.samples_per_pixel), flip_frac=2e-3)
+
+
+def test_more_than_65535_spheres_fall_back_to_the_full_scan(hostsim, oracle, abi, host):
+    """the reference accepts any object count.  Above 65 535 spheres the u16 item lists of the uniform grid
+    cannot name a sphere: build_grid keeps every sphere in the `large` list (the reference's own scan over all objects,
+    raytracer.rs:52-57) and the frame still equals the oracle's."""
+    import json
+    rng = np.random.default_rng(3)
+    n = 66000
+    objs = [{"center": {"x": 0.0, "y": -1000.0, "z": 0.0}, "radius": 1000.0, "material": {"Lambertian": {"albedo": [0.5, 0.5, 0.5]}}}]
+    xs, zs = rng.uniform(-60, 60, n), rng.uniform(-60, 60, n)
+    for i in range(n):
+        m = {"Lambertian": {"albedo": [0.3, 0.6, 0.2]}} if i % 3 else ({"Metal": {"albedo": [0.8, 0.8, 0.8], "fuzz": 0.1}} if i % 2 else {"Glass": {"index_of_refraction": 1.5}})
+        objs.append({"center": {"x": float(xs[i]), "y": 0.2, "z": float(zs[i])}, "radius": 0.2, "material": m})
+    cfg = {"width": 12, "height": 8, "samples_per_pixel": 2, "max_depth": 6, "sky": {"texture": ""},
+           "camera": {"look_from": {"x": 13.0, "y": 2.0, "z": 3.0}, "look_at": {"x": 0.0, "y": 0.0, "z": 0.0}, "vup": {"x": 0.0, "y": 1.0, "z": 0.0},
+                      "vfov": 20.0, "aspect": 1.5}, "objects": objs}
+    sc = host.Scene.loads(json.dumps(cfg))
+    assert sc.c.n_spheres == n + 1 > 65535
+    info = (C.c_uint32 * 6)()
+    assert hostsim.hostsim_grid_info(sc.ptr, info) == 0
+    assert info[0] == 0 and info[3] == n + 1          # no grid; all spheres in the `large` list
+    o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+    rgb, lin, st = hostsim.render(sc.ptr, None, 3)
+    assert_parity(rgb, lin, o_rgb, o_lin, "66001 spheres")
+    assert st["segments"] == o_st["segments"] and st["exact_tests"] == st["sphere_tests"]

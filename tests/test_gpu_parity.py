@@ -272,6 +272,27 @@ def test_procedural_10k_spheres(gpu_render, oracle, abi, host):
     assert st["grid_steps"] > 0 and st["exact_tests"] < 40 * st["segments"]
 
 
+def test_more_than_65535_spheres(gpu_render, oracle, abi, host):
+    """any object count is accepted (the reference's Vec<Sphere> has no limit): above 65 535 spheres the grid's u16 item
+    lists cannot be built and the kernel scans every sphere like raytracer.rs:52-57 — slow, but the reference's frame"""
+    rng = np.random.default_rng(3)
+    n = 66000
+    objs = [{"center": {"x": 0.0, "y": -1000.0, "z": 0.0}, "radius": 1000.0, "material": {"Lambertian": {"albedo": [0.5, 0.5, 0.5]}}}]
+    xs, zs = rng.uniform(-60, 60, n), rng.uniform(-60, 60, n)
+    for i in range(n):
+        m = {"Lambertian": {"albedo": [0.3, 0.6, 0.2]}} if i % 3 else ({"Metal": {"albedo": [0.8, 0.8, 0.8], "fuzz": 0.1}} if i % 2 else {"Glass": {"index_of_refraction": 1.5}})
+        objs.append({"center": {"x": float(xs[i]), "y": 0.2, "z": float(zs[i])}, "radius": 0.2, "material": m})
+    cfg = {"width": 16, "height": 10, "samples_per_pixel": 2, "max_depth": 6, "sky": {"texture": ""},
+           "camera": {"look_from": {"x": 13.0, "y": 2.0, "z": 3.0}, "look_at": {"x": 0.0, "y": 0.0, "z": 0.0}, "vup": {"x": 0.0, "y": 1.0, "z": 0.0},
+                      "vfov": 20.0, "aspect": 1.6}, "objects": objs}
+    sc = host.Scene.loads(json.dumps(cfg))
+    assert sc.c.n_spheres == n + 1
+    o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+    rgb, lin, st = gpu_render(sc)
+    assert_parity(rgb, lin, o_rgb, o_lin, "66001 spheres", atol=pooled_atol(2))
+    assert st["segments"] == o_st["segments"] and st["grid_steps"] == 0 and st["exact_tests"] == st["sphere_tests"]
+
+
 def test_host_buffer_entry_point(pkg, gpu_render, load_scene):
     """rt_render_rgb8 (host buffers in/out, the drop-in for render()'s loop) == device API"""
     sc = load_scene("cover", 80, 50, 2, 50)
