@@ -365,7 +365,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
       s->order_cap = ka.n_tiles;
     }
     if (key != s->order_key) { s->order_key = key; s->order_ready = false; s->order_age = 0; }
-    ka.tile_depth = s->d_tile_depth;
+    if (s->order_age < 2) ka.tile_depth = s->d_tile_depth;  // (measured only while the order is still being built)
     if (s->order_ready) ka.tile_order = s->d_tile_order;
   }
 
@@ -380,7 +380,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   // The next frame's order from this frame's depths (stream-ordered: ready before the next launch reads it).  Which tiles
   // breed deep paths is a property of scene and camera, so the order is rebuilt after the first two frames of a view
   // only — later frames of the same view reuse it and pay nothing; rt_hip_set_camera starts over.
-  if (ka.tile_depth && s->order_age < 2) {
+  if (ka.tile_depth) {
     s->order_age++;
     hipLaunchKernelGGL(rtk::rt_order_tiles, dim3(1), dim3(1024), 0, stream, (const uint32_t*)s->d_tile_depth, s->d_tile_order, ka.n_tiles);
     RT_HIP_TRY(hipGetLastError());

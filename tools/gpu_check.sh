@@ -55,7 +55,7 @@ if [[ " $* " == *" configs "* ]]; then
   } > $OUT/all_configs.log 2>&1; stamp configs $?
   cut -c1-160 $OUT/all_configs.log
 fi
-# the bench line last: if profiles/hbm_traffic.json was just refreshed by the caller it is picked up next time
+# the bench line last (its roofline reads the newest profiles/rNN_*pmc.json: copy gpurun_out/pmc_summary.json there after a pmc run)
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/$OUT/prof" -o bench -- python "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-other-configs ) > $OUT/rocprof.log 2>&1
 stamp rocprof $?
 STATS=$(find $OUT/prof -name "*kernel_stats.csv" 2>/dev/null | head -1)
