@@ -163,6 +163,14 @@ static inline uint32_t rt_tiles_global_row(const RtRowTiles* tiles, uint32_t lr)
   return (tiles->first_tile + j * tiles->tile_stride) * tiles->tile_rows + r;
 }
 
+/* Where scanline y of the assembled frame sits in a gather buffer of G ranks, each contributing `pad_rows` packed rows
+ * (rank r's rows are rt_tiles_global_row({tile_rows, r, G}, 0..)): the inverse of the packing above, used by the
+ * de-interleave kernel of rt_hip_group_* and by any host that assembles the ranks' tiles itself. */
+static inline uint32_t rt_tiles_stacked_row(uint32_t y, uint32_t n_ranks, uint32_t tile_rows, uint32_t pad_rows) {
+  const uint32_t k = y / tile_rows, r = k % n_ranks, j = k / n_ranks;
+  return r * pad_rows + j * tile_rows + y % tile_rows;
+}
+
 /* ------------------------------------------------------------------------------------
  * librt_host.so — host plumbing (stays on the CPU, like main.rs/config.rs/camera.rs)
  * ---------------------------------------------------------------------------------- */
@@ -185,9 +193,11 @@ void rt_camera_derive(const double look_from[3], const double look_at[3], const 
 void rt_scene_camera(const RtSceneFile*, double out[11]);
 /* raytracer.rs:220-229 find_lights: writes indices of Light spheres in object order */
 uint32_t rt_find_lights(const RtSphere* spheres, uint32_t n, uint32_t* out_idx, uint32_t cap);
-/* materials.rs:213-219 load_texture_image: baseline JPEG -> RGB8 (malloc'd, free with rt_free) */
+/* materials.rs:213-219 load_texture_image: Huffman JPEG (baseline, extended sequential, progressive; 8 bit, 1 or 3
+ * components) -> RGB8 (malloc'd, free with rt_free) */
 int rt_jpeg_decode_file(const char* path, uint8_t** rgb8, uint32_t* w, uint32_t* h);
 int rt_jpeg_decode_mem(const uint8_t* data, size_t len, uint8_t** rgb8, uint32_t* w, uint32_t* h);
+const char* rt_jpeg_last_error(void); /* why the last rt_jpeg_decode_* of this thread returned RT_ERR_TEXTURE */
 /* raytracer.rs:33-42 write_image: PNG, ColorType::RGB(8) */
 int rt_png_write_rgb8(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h);
 void rt_free(void*);
@@ -269,6 +279,9 @@ int rt_hip_group_set_camera(RtHipGroup*, const double origin[3], const double lo
                             const double vertical[3]);
 int rt_hip_group_set_option(RtHipGroup*, const char* key, int64_t value);
 int rt_hip_group_render_to_host(RtHipGroup*, uint8_t* out_rgb8, RtStats* stats);
+/* the group's layout arithmetic as the library compiled it (no GPU needed): rt_tiles_stacked_row() with the group's
+ * tile height; *tile_rows_out receives that height (2) */
+uint32_t rt_hip_group_stacked_row(uint32_t y, uint32_t n_ranks, uint32_t pad_rows, uint32_t* tile_rows_out);
 /* Convenience = the drop-in for render()'s parallel loop (raytracer.rs:254-262): host buffers in,
  * host RGB8 out.  Blocking.  Renders on scene->n_gpus devices (see RtScene.n_gpus / RT_GPUS): the scene
  * is replicated, device r renders scanline tiles r, r+G, ... (2 rows each) on its own host thread and

@@ -54,7 +54,7 @@ struct RcclApi {
   }
 };
 
-// frame[y] <- stacked[rank(y)][local row(y)]: rt_tiles_global_row() inverted (include/rt_abi.h)
+// frame[y] <- stacked[rank(y)][local row(y)]: rt_tiles_stacked_row() of include/rt_abi.h, compiled for the device
 __host__ __device__ inline uint32_t stacked_row_of(uint32_t y, uint32_t G, uint32_t tile_rows, uint32_t pad_rows) {
   const uint32_t k = y / tile_rows, r = k % G, j = k / G;
   return r * pad_rows + j * tile_rows + y % tile_rows;
@@ -152,6 +152,11 @@ void worker_main(RtHipGroup* g, uint32_t r) {
 }  // namespace rtg
 
 extern "C" uint32_t rt_hip_group_size(const RtHipGroup* g) { return g ? g->G : 0u; }
+
+extern "C" uint32_t rt_hip_group_stacked_row(uint32_t y, uint32_t n_ranks, uint32_t pad_rows, uint32_t* tile_rows_out) {
+  if (tile_rows_out) *tile_rows_out = RT_GROUP_TILE_ROWS;
+  return n_ranks ? rtg::stacked_row_of(y, n_ranks, RT_GROUP_TILE_ROWS, pad_rows) : 0u;
+}
 
 extern "C" void rt_hip_group_destroy(RtHipGroup* g) {
   if (!g) return;

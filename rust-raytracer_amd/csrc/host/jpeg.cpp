@@ -1,4 +1,5 @@
-// jpeg.cpp — baseline / extended-sequential Huffman JPEG -> RGB8.
+// jpeg.cpp — Huffman JPEG -> RGB8: baseline / extended sequential (SOF0, SOF1), interleaved or one component per
+// scan, and progressive (SOF2: spectral selection + successive approximation), 8 bits, 1 or 3 components.
 // Stands in for the `jpeg-decoder` crate the reference calls while deserializing textures
 // (reference materials.rs:213-219 load_texture_image, config.rs:36-47).  Texel values of a
 // lossy decode are decoder-specific (IDCT + chroma upsampling), and no reference test pins
@@ -50,9 +51,11 @@ struct Huff {
 
 struct Comp {
   int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
-  int bw = 0, bh = 0;  // blocks per line / column (padded to MCU)
+  int bw = 0, bh = 0;    // blocks per line / column (padded to MCU)
+  int nbx = 0, nby = 0;  // blocks that cover the component itself (what a scan of this component alone walks)
   int pred = 0;
-  std::vector<uint8_t> plane;  // bw*8 x bh*8
+  std::vector<int16_t> coef;   // bw*bh blocks x 64 coefficients, natural order: every scan adds to them
+  std::vector<uint8_t> plane;  // bw*8 x bh*8, after the last scan
 };
 
 struct BitReader {
@@ -144,18 +147,111 @@ struct Decoder {
   Comp comp[3];
   int restart_interval = 0;
   bool adobe = false; int adobe_transform = 0;
-  bool sof_seen = false;
+  bool sof_seen = false, progressive = false;
 
   bool fail(const std::string& m) { err = m; return false; }
 
-  bool decode_scan(const uint8_t* p, const uint8_t* end, const uint8_t** next) {
+  static inline int16_t sat16(int v) { return int16_t(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+  // ---- one block of one scan.  Sequential frames: DC + all AC (ss = 0, se = 63, ah = al = 0).  Progressive frames
+  // (ITU T.81 annex G): DC first / refinement, AC first / refinement with end-of-band runs shared across blocks.
+  bool block_sequential(BitReader& br, Comp& cp, int16_t* blk) {
+    const Huff& hd = dc[cp.td]; const Huff& ha = ac[cp.ta];
+    int t = decode_sym(br, hd);
+    if (t < 0 || t > 11) return fail("bad DC huffman code");
+    cp.pred += t ? extend(br.get(t), t) : 0;
+    blk[0] = sat16(cp.pred);
+    for (int k = 1; k < 64;) {
+      int rs = decode_sym(br, ha);
+      if (rs < 0) return fail("bad AC huffman code");
+      int r = rs >> 4, sz = rs & 15;
+      if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+      k += r;
+      if (k > 63) return fail("AC index overflow");
+      blk[kZigzag[k]] = sat16(extend(br.get(sz), sz));
+      ++k;
+    }
+    return true;
+  }
+  bool block_dc_first(BitReader& br, Comp& cp, int16_t* blk, int al) {
+    int t = decode_sym(br, dc[cp.td]);
+    if (t < 0 || t > 11) return fail("bad DC huffman code");
+    cp.pred += t ? extend(br.get(t), t) : 0;
+    blk[0] = sat16(cp.pred * (1 << al));
+    return true;
+  }
+  static void block_dc_refine(BitReader& br, int16_t* blk, int al) {
+    if (br.get(1)) blk[0] = int16_t(blk[0] | (1 << al));
+  }
+  bool block_ac_first(BitReader& br, const Huff& ha, int16_t* blk, int ss, int se, int al, int& eobrun) {
+    if (eobrun > 0) { --eobrun; return true; }
+    for (int k = ss; k <= se; ++k) {
+      int rs = decode_sym(br, ha);
+      if (rs < 0) return fail("bad AC huffman code");
+      int r = rs >> 4, sz = rs & 15;
+      if (sz) {
+        k += r;
+        if (k > 63) return fail("AC index overflow");
+        blk[kZigzag[k]] = sat16(extend(br.get(sz), sz) * (1 << al));
+      } else if (r == 15) {
+        k += 15;
+      } else {
+        eobrun = (1 << r) - 1;
+        if (r) eobrun += br.get(r);
+        break;
+      }
+    }
+    return true;
+  }
+  bool block_ac_refine(BitReader& br, const Huff& ha, int16_t* blk, int ss, int se, int al, int& eobrun) {
+    const int p1 = 1 << al, m1 = -(1 << al);
+    auto correct = [&](int16_t& c) { if (br.get(1) && (c & p1) == 0) c = sat16(c + (c >= 0 ? p1 : m1)); };
+    int k = ss;
+    if (eobrun == 0) {
+      for (; k <= se; ++k) {
+        int rs = decode_sym(br, ha);
+        if (rs < 0) return fail("bad AC huffman code");
+        int r = rs >> 4, sz = rs & 15, val = 0;
+        if (sz) {
+          if (sz != 1) return fail("bad AC refinement code");
+          val = br.get(1) ? p1 : m1;
+        } else if (r != 15) {
+          eobrun = 1 << r;
+          if (r) eobrun += br.get(r);
+          break;
+        }
+        // pass over the coefficients that are already non-zero (each takes a correction bit) and r zero ones
+        for (; k <= se; ++k) {
+          int16_t& c = blk[kZigzag[k]];
+          if (c != 0) correct(c);
+          else if (--r < 0) break;
+        }
+        if (val) {
+          if (k > se) return fail("AC refinement runs past the band");
+          blk[kZigzag[k]] = int16_t(val);
+        }
+      }
+    }
+    if (eobrun > 0) {  // end of band: the remaining non-zero coefficients still take their correction bits
+      for (; k <= se; ++k) {
+        int16_t& c = blk[kZigzag[k]];
+        if (c != 0) correct(c);
+      }
+      --eobrun;
+    }
+    return true;
+  }
+
+  // ---- one scan (SOS): `ns` components (indices into comp[]), spectral band ss..se, successive approximation ah / al
+  bool decode_scan(const uint8_t* p, const uint8_t* end, const uint8_t** next, const int* ci, int ns, int ss, int se, int ah, int al) {
     BitReader br{p, end};
-    int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
-    int coef[64];
-    int rst_left = restart_interval;
-    for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
-    for (int my = 0; my < mcuy; ++my)
-      for (int mx = 0; mx < mcux; ++mx) {
+    int units_x, units_y;  // MCUs of an interleaved scan, or the blocks of the one component of a non-interleaved scan
+    if (ns > 1) { units_x = (width + 8 * hmax - 1) / (8 * hmax); units_y = (height + 8 * vmax - 1) / (8 * vmax); }
+    else { units_x = comp[ci[0]].nbx; units_y = comp[ci[0]].nby; }
+    int rst_left = restart_interval, eobrun = 0;
+    for (int i = 0; i < ns; ++i) comp[ci[i]].pred = 0;
+    for (int uy = 0; uy < units_y; ++uy)
+      for (int ux = 0; ux < units_x; ++ux) {
         if (restart_interval && rst_left == 0) {
           // byte-align, expect RSTn
           br.reset();
@@ -163,38 +259,48 @@ struct Decoder {
           while (q + 1 < end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
           if (q + 1 >= end) return fail("missing restart marker");
           br.p = q + 2;
-          for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
+          for (int i = 0; i < ns; ++i) comp[ci[i]].pred = 0;
+          eobrun = 0;
           rst_left = restart_interval;
         }
-        for (int c = 0; c < ncomp; ++c) {
-          Comp& cp = comp[c];
-          const Huff& hd = dc[cp.td]; const Huff& ha = ac[cp.ta];
-          const uint16_t* q = qt[cp.tq];
-          for (int by = 0; by < cp.v; ++by)
-            for (int bx = 0; bx < cp.h; ++bx) {
-              std::memset(coef, 0, sizeof coef);
-              int t = decode_sym(br, hd);
-              if (t < 0 || t > 11) return fail("bad DC huffman code");
-              int diff = t ? extend(br.get(t), t) : 0;
-              cp.pred += diff;
-              coef[0] = cp.pred * q[0];
-              for (int k = 1; k < 64;) {
-                int rs = decode_sym(br, ha);
-                if (rs < 0) return fail("bad AC huffman code");
-                int r = rs >> 4, s = rs & 15;
-                if (s == 0) { if (r == 15) { k += 16; continue; } break; }
-                k += r;
-                if (k > 63) return fail("AC index overflow");
-                coef[kZigzag[k]] = extend(br.get(s), s) * q[k];
-                ++k;
-              }
-              int px = (mx * cp.h + bx) * 8, py = (my * cp.v + by) * 8;
-              idct_block(coef, cp.plane.data() + size_t(py) * (cp.bw * 8) + px, cp.bw * 8);
+        for (int i = 0; i < ns; ++i) {
+          Comp& cp = comp[ci[i]];
+          const int nv = ns > 1 ? cp.v : 1, nh = ns > 1 ? cp.h : 1;
+          for (int by = 0; by < nv; ++by)
+            for (int bx = 0; bx < nh; ++bx) {
+              const int gx = ns > 1 ? ux * cp.h + bx : ux, gy = ns > 1 ? uy * cp.v + by : uy;
+              int16_t* blk = cp.coef.data() + (size_t(gy) * cp.bw + gx) * 64;
+              bool ok = true;
+              if (!progressive) ok = block_sequential(br, cp, blk);
+              else if (ss == 0) { if (ah == 0) ok = block_dc_first(br, cp, blk, al); else block_dc_refine(br, blk, al); }
+              else if (ah == 0) ok = block_ac_first(br, ac[cp.ta], blk, ss, se, al, eobrun);
+              else ok = block_ac_refine(br, ac[cp.ta], blk, ss, se, al, eobrun);
+              if (!ok) return false;
             }
         }
         if (restart_interval) --rst_left;
       }
     *next = br.p;
+    return true;
+  }
+
+  // after the last scan: dequantise + inverse DCT of every block
+  bool reconstruct() {
+    for (int c = 0; c < ncomp; ++c) {
+      Comp& cp = comp[c];
+      if (!qt_present[cp.tq]) return fail("missing quantisation table");
+      int qnat[64];
+      for (int k = 0; k < 64; ++k) qnat[kZigzag[k]] = qt[cp.tq][k];
+      cp.plane.assign(size_t(cp.bw) * 8 * cp.bh * 8, 0);
+      int dq[64];
+      for (int by = 0; by < cp.bh; ++by)
+        for (int bx = 0; bx < cp.bw; ++bx) {
+          const int16_t* blk = cp.coef.data() + (size_t(by) * cp.bw + bx) * 64;
+          for (int k = 0; k < 64; ++k) dq[k] = int(blk[k]) * qnat[k];
+          idct_block(dq, cp.plane.data() + size_t(by) * 8 * (cp.bw * 8) + size_t(bx) * 8, cp.bw * 8);
+        }
+      std::vector<int16_t>().swap(cp.coef);
+    }
     return true;
   }
 
@@ -233,7 +339,9 @@ struct Decoder {
           std::memcpy(h.vals, s, total); s += total;
           if (!h.build()) return fail("bad DHT (over-subscribed code lengths)");
         }
-      } else if (m == 0xC0 || m == 0xC1) {
+      } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+        if (sof_seen) return fail("more than one frame header");
+        progressive = m == 0xC2;
         if (L < 8) return fail("truncated SOF");
         if (s[0] != 8) return fail("only 8-bit JPEG supported");
         height = be16(s + 1); width = be16(s + 3); ncomp = s[5];
@@ -250,13 +358,16 @@ struct Decoder {
         int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
         for (int c = 0; c < ncomp; ++c) {
           comp[c].bw = mcux * comp[c].h; comp[c].bh = mcuy * comp[c].v;
-          comp[c].plane.assign(size_t(comp[c].bw) * 8 * comp[c].bh * 8, 0);
+          const int cw = (width * comp[c].h + hmax - 1) / hmax, ch = (height * comp[c].v + vmax - 1) / vmax;
+          comp[c].nbx = (cw + 7) / 8; comp[c].nby = (ch + 7) / 8;
+          if (size_t(comp[c].bw) * comp[c].bh > (size_t(1) << 26)) return fail("image too large");
+          comp[c].coef.assign(size_t(comp[c].bw) * comp[c].bh * 64, 0);
         }
         sof_seen = true;
-      } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+      } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
         char what[192];
-        std::snprintf(what, sizeof what, "JPEG frame type SOF%d (%s) not supported: baseline / extended-sequential Huffman only",
-                      m - 0xC0, m == 0xC2 ? "progressive" : (m >= 0xC9 ? "arithmetic coding" : "lossless / differential"));
+        std::snprintf(what, sizeof what, "JPEG frame type SOF%d (%s) not supported: Huffman baseline / extended sequential / progressive only",
+                      m - 0xC0, m >= 0xC9 ? "arithmetic coding" : "lossless / differential");
         return fail(what);
       } else if (m == 0xDD) {
         if (L < 4) return fail("truncated DRI");
@@ -267,19 +378,38 @@ struct Decoder {
         if (!sof_seen) return fail("SOS before SOF");
         if (L < 3) return fail("truncated SOS");
         int ns = s[0];
-        if (ns != ncomp) return fail("non-interleaved (multi-scan) baseline JPEG not supported");
+        if (ns < 1 || ns > ncomp) return fail("bad SOS component count");
         if (L < 6 + 2 * ns) return fail("truncated SOS");
+        int ci[3];
         for (int i = 0; i < ns; ++i) {
           int cid = s[1 + 2 * i], tbl = s[2 + 2 * i];
           int c = -1;
           for (int k = 0; k < ncomp; ++k) if (comp[k].id == cid) c = k;
           if (c < 0) return fail("bad SOS component");
+          for (int j = 0; j < i; ++j) if (ci[j] == c) return fail("SOS names a component twice");
+          ci[i] = c;
           comp[c].td = tbl >> 4; comp[c].ta = tbl & 15;
-          if (comp[c].td > 3 || comp[c].ta > 3 || !dc[comp[c].td].present || !ac[comp[c].ta].present || !qt_present[comp[c].tq])
-            return fail("scan references a missing table");
+          if (comp[c].td > 3 || comp[c].ta > 3) return fail("bad SOS table id");
+        }
+        const int ss = s[1 + 2 * ns], sp_end = s[2 + 2 * ns], ah = s[3 + 2 * ns] >> 4, al = s[3 + 2 * ns] & 15;
+        if (!progressive) {
+          if (ss != 0 || sp_end != 63 || ah != 0 || al != 0) return fail("bad SOS parameters for a sequential frame");
+        } else {
+          if (ss > sp_end || sp_end > 63 || al > 13 || ah > 13 || (ss == 0 && sp_end != 0) || (ss > 0 && ns != 1) || (ah != 0 && ah != al + 1))
+            return fail("bad SOS parameters for a progressive frame");
+        }
+        for (int i = 0; i < ns; ++i) {  // the tables this scan decodes with must have been defined
+          const Comp& cp = comp[ci[i]];
+          const bool need_dc = !progressive || (ss == 0 && ah == 0), need_ac = !progressive || ss > 0;
+          if ((need_dc && !dc[cp.td].present) || (need_ac && !ac[cp.ta].present)) return fail("scan references a missing table");
+        }
+        if (ns > 1) {  // an interleaved scan must fit T.81's limit of 10 blocks per MCU
+          int blocks = 0;
+          for (int i = 0; i < ns; ++i) blocks += comp[ci[i]].h * comp[ci[i]].v;
+          if (blocks > 10) return fail("too many blocks per MCU");
         }
         const uint8_t* next = nullptr;
-        if (!decode_scan(se, end, &next)) return false;
+        if (!decode_scan(se, end, &next, ci, ns, ss, sp_end, ah, al)) return false;
         scanned = true;
         p = next;
         continue;
@@ -287,8 +417,9 @@ struct Decoder {
       p += 2 + L;
     }
     if (!scanned) return fail("no image data");
-    return true;
+    return reconstruct();
   }
+
 
   // libjpeg-style "fancy" (triangle filter) upsampling of one component to full size
   void upsample(const Comp& c, std::vector<uint8_t>& out) const {

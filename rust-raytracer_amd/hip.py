@@ -50,6 +50,8 @@ def lib():
         L.rt_hip_group_set_camera.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 4
         L.rt_hip_group_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.rt_hip_group_render_to_host.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.RtStats)]
+        L.rt_hip_group_stacked_row.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.rt_hip_group_stacked_row.restype = C.c_uint32
         for name in ("RtSphere", "RtTexture", "RtScene", "RtRowTiles", "RtStats"):   # the binding's own layout check
             if L.rt_abi_sizeof(name.encode()) != C.sizeof(getattr(abi, name)):
                 raise ImportError(f"{LIB_PATH}: sizeof({name}) = {L.rt_abi_sizeof(name.encode())} but abi.py has "

@@ -42,6 +42,7 @@ def lib():
         L.rt_find_lights.restype = C.c_uint32
         L.rt_jpeg_decode_file.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.rt_png_write_rgb8.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.rt_jpeg_last_error.restype = C.c_char_p
         L.rt_free.argtypes = [C.c_void_p]
         L.rt_free.restype = None
         _LIB = L
@@ -131,7 +132,9 @@ def jpeg_decode_mem(data):
     buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
     px = C.POINTER(C.c_uint8)()
     w, h = C.c_uint32(), C.c_uint32()
-    _check(lib().rt_jpeg_decode_mem(buf, len(data), C.byref(px), C.byref(w), C.byref(h)))
+    rc = lib().rt_jpeg_decode_mem(buf, len(data), C.byref(px), C.byref(w), C.byref(h))
+    if rc != abi.RT_OK:
+        raise RtError(rc, lib().rt_jpeg_last_error().decode("utf-8", "replace"))
     try:
         return np.ctypeslib.as_array(px, shape=(h.value, w.value, 3)).copy()
     finally:

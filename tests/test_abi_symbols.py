@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST_SYMS = {"rt_scene_camera", "rt_scene_load_file", "rt_scene_load_string", "rt_scene_get", "rt_scene_get_mut", "rt_scene_free", "rt_scene_to_json",
-             "rt_host_last_error", "rt_camera_derive", "rt_find_lights", "rt_jpeg_decode_file", "rt_jpeg_decode_mem",
+             "rt_host_last_error", "rt_camera_derive", "rt_find_lights", "rt_jpeg_decode_file", "rt_jpeg_decode_mem", "rt_jpeg_last_error",
              "rt_png_write_rgb8", "rt_free"}
 
 
@@ -17,7 +17,7 @@ def declared_functions():
     text = open(os.path.join(ROOT, "include", "rt_abi.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text))
-    return names - {"rt_tiles_local_rows", "rt_tiles_global_row"}  # static inline helpers
+    return names - {"rt_tiles_local_rows", "rt_tiles_global_row", "rt_tiles_stacked_row"}  # static inline helpers
 
 
 def test_every_declared_symbol_is_exported(pkg):
@@ -143,3 +143,23 @@ def test_tiles_helpers(abi):
                 assert len(g) == abi.tiles_local_rows(h, t)
                 rows += g
             assert sorted(rows) == list(range(h))
+
+
+def test_group_deinterleave_layout_inverts_the_rank_packing(pkg, abi):
+    """The de-interleave of rt_hip_group_* (frame[y] <- gather buffer row), as librt_hip.so compiled it, against the
+    packing every rank uses (RtRowTiles{2, r, G}: abi.tiles_global_rows): every scanline is found exactly once, for
+    ragged heights and more ranks than tiles.  Runs without a GPU (pure layout arithmetic of the library)."""
+    L = pkg.hip.lib()
+    tr = C.c_uint32()
+    L.rt_hip_group_stacked_row(0, 1, 1, C.byref(tr))
+    assert tr.value == 2
+    for h in (1, 2, 3, 7, 45, 800, 2160):
+        for world in (1, 2, 3, 8, 16):
+            shards = [abi.tiles_global_rows(h, abi.RtRowTiles(tr.value, r, world)) for r in range(world)]
+            pad = max(len(s) for s in shards)
+            seen = {}
+            for r, rows in enumerate(shards):
+                for lr, y in enumerate(rows):
+                    seen[r * pad + lr] = y                      # what rank r wrote at packed row lr
+            got = [seen.get(L.rt_hip_group_stacked_row(y, world, pad, None)) for y in range(h)]
+            assert got == list(range(h)), (h, world)

@@ -479,6 +479,22 @@ def test_group_in_library_sharding_is_bit_identical(pkg, gpu_render, load_scene,
         grp.close()
 
 
+def test_full_size_cfg4_through_the_8_rank_group(pkg, gpu_render, load_scene):
+    """BASELINE configs[3] at FULL size (3840x2160, spp 512, textured): the in-library group with 8 ranks (sharing this
+    box's GPU) against the single launch — byte-identical frame, same path count; two frames (the second with the queue
+    order learnt from the first)."""
+    sc = load_scene("scenes/cfg4_cover_4k_textured_spp512.json")
+    assert (sc.c.width, sc.c.height, sc.c.samples_per_pixel) == (3840, 2160, 512)
+    rgb, _, st = gpu_render(sc, want_linear=False)
+    grp = _with_env({"RT_GPUS_EMULATE": "1"}, lambda: pkg.hip.HipGroup(sc.ptr, 8))
+    for _ in range(2):
+        out, gst = grp.render_to_host()
+        assert np.array_equal(out, rgb)
+        assert gst["n_gpus_used"] == 8 and gst["samples"] == st["samples"] == 3840 * 2160 * 512 and gst["segments"] == st["segments"]
+    print(f"cfg4 full size: single launch {st['kernel_ms']:.1f} ms; 8 emulated ranks on one GPU: slowest rank {gst['kernel_ms']:.1f} ms, frame {gst['frame_ms']:.1f} ms")
+    grp.close()
+
+
 def test_group_gather_through_rccl_one_rank(pkg, gpu_render, load_scene):
     """the RCCL leg of the group (dlopen, ncclCommInitAll, in-place ncclGather inside a group call, de-interleave
     kernel) with the only communicator a 1-GPU box allows: one rank (RT_GATHER_SELFTEST=1)"""
