@@ -59,11 +59,11 @@ if [[ " $* " == *" sweep "* ]]; then
   {
     echo "# chunk_spp x tile_log2 on the whole headline frame (kernel_ms, best of 6; tile_order feedback on)"
     for TL in 1 2 3; do for CS in 4 8 16 32 64; do
-      echo -n "tile_log2=$TL chunk_spp=$CS "; timeout 60 python tools/diag.py --reps 6 --opt tile_log2=$TL chunk_spp=$CS 2>/dev/null | tail -1 | cut -c 50-100
+      echo -n "tile_log2=$TL chunk_spp=$CS "; timeout 60 python tools/diag.py --reps 6 --opt tile_log2=$TL chunk_spp=$CS 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['kernel_ms'])"
     done; done
     echo "# 1/8 shard (rank 3)"
     for TL in 0 1 2; do for CS in 8 16 32 64 128; do
-      echo -n "tile_log2=$TL chunk_spp=$CS "; timeout 60 python tools/diag.py --shard 3,8,2 --reps 8 --opt tile_log2=$TL chunk_spp=$CS 2>/dev/null | tail -1 | cut -c 50-100
+      echo -n "tile_log2=$TL chunk_spp=$CS "; timeout 60 python tools/diag.py --shard 3,8,2 --reps 8 --opt tile_log2=$TL chunk_spp=$CS 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['kernel_ms'])"
     done; done
   } > $OUT/sweep.log 2>&1; stamp sweep $?
   cat $OUT/sweep.log
