@@ -55,7 +55,9 @@ struct RtHipScene {
   int order_age = 0;        // frames since the order was last invalidated (geometry / camera / option change)
   int order_mode = 2;       // "tile_order" option: 0 top row first, 1 bottom row first, 2 deepest tiles of the previous frame first
   int chunk_spp = 0;       // 0 = automatic
-  int tile_log2 = -1;      // -1 = automatic; else tiles of 2^k x 2^k pixels, k = 0..3
+  int tile_log2 = -1;      // -1 = automatic; else tiles of 4^k pixels, k = 0..3
+  int tile_shape = 0;      // 0: 2^k x 2^k squares (default: 0.9 % faster); 1: runs of 4^k pixels of one scanline (contiguous
+                           // framebuffer bytes: HBM writes 10.9 -> 5.9 MiB per 1200x800 frame, profiles/r02_run8_*)
 
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   hipStream_t last_stream = nullptr;
@@ -199,6 +201,7 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
   if (!std::strcmp(key, "variant")) { if (value < 0 || value > max_variant) return fail(RT_ERR_INVALID, "variant must be 0 (grid walk) or 1 (brute force)"); s->variant = (int)value; return RT_OK; }
   if (!std::strcmp(key, "pool")) { s->pool = value != 0; return RT_OK; }
   if (!std::strcmp(key, "tile_log2")) { if (value < -1 || value > 3) return fail(RT_ERR_INVALID, "tile_log2 must be -1..3"); s->tile_log2 = (int)value; return RT_OK; }
+  if (!std::strcmp(key, "tile_shape")) { if (value < 0 || value > 1) return fail(RT_ERR_INVALID, "tile_shape must be 0 (square) or 1 (scanline runs)"); s->tile_shape = (int)value; return RT_OK; }
   if (!std::strcmp(key, "tile_order")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_order must be 0, 1 or 2"); s->order_mode = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
   if (!std::strcmp(key, "chunk_spp")) { if (value < 0) return fail(RT_ERR_INVALID, "chunk_spp must be >= 0"); s->chunk_spp = (int)value; return RT_OK; }
   if (!std::strcmp(key, "samples_per_pixel") || !std::strcmp(key, "max_depth")) {
@@ -309,21 +312,26 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   // 2x2 or 1x1 tiles, so that the heaviest tile (glass: 10x the mean) is a small part of a
   // workgroup's share and the long-path regions spread over many workgroups.
   const uint64_t want_tiles = (uint64_t)s->num_cus * 100u;
-  uint32_t tl = (uint32_t)s->tile_log2;
+  // tile geometry: 4^tl pixels, as a run of one scanline (default) or a square
+  const bool flat = s->tile_shape != 0;
+  auto tiles_xy = [&](uint32_t t, uint32_t& tx, uint32_t& ty) {
+    const uint32_t wl = flat ? 2u * t : t, hl = flat ? 0u : t;
+    tx = (s->host.width + (1u << wl) - 1) >> wl; ty = (local_rows + (1u << hl) - 1) >> hl;
+  };
+  uint32_t tl = (uint32_t)s->tile_log2, tx = 0, ty = 0;
   if (s->tile_log2 < 0) {
     tl = 3;
-    while (tl > 0 && (uint64_t)((s->host.width + (1u << tl) - 1) >> tl) * ((local_rows + (1u << tl) - 1) >> tl) < want_tiles) tl--;
+    for (;;) { tiles_xy(tl, tx, ty); if (tl == 0 || (uint64_t)tx * ty >= want_tiles) break; tl--; }
   }
   // a slot header packs (tile column | tile row << 16), and the queue cursor is 32 bits
-  while (tl < 3 && (((s->host.width + (1u << tl) - 1) >> tl) > 65535u || ((local_rows + (1u << tl) - 1) >> tl) > 65535u ||
-                    (uint64_t)((s->host.width + (1u << tl) - 1) >> tl) * ((local_rows + (1u << tl) - 1) >> tl) >= (1ull << 31))) tl++;
-  if (((s->host.width + (1u << tl) - 1) >> tl) > 65535u || ((local_rows + (1u << tl) - 1) >> tl) > 65535u ||
-      (uint64_t)((s->host.width + (1u << tl) - 1) >> tl) * ((local_rows + (1u << tl) - 1) >> tl) >= (1ull << 31))
-    return fail(RT_ERR_UNSUPPORTED, "frame too large for the tile queue (more than 65535 tiles on an axis or 2^31 tiles)");
+  auto too_many = [&](uint32_t t) { tiles_xy(t, tx, ty); return tx > 65535u || ty > 65535u || (uint64_t)tx * ty >= (1ull << 31); };
+  while (tl < 3 && too_many(tl)) tl++;
+  if (too_many(tl)) return fail(RT_ERR_UNSUPPORTED, "frame too large for the tile queue (more than 65535 tiles on an axis or 2^31 tiles)");
   ka.tile_log2 = tl;
+  ka.tile_wl = flat ? 2u * tl : tl; ka.tile_hl = flat ? 0u : tl;
   ka.t_slots = rtk::tile_slots(tl);
-  ka.tiles_x = (s->host.width + (1u << tl) - 1) >> tl;
-  ka.n_tiles = ka.tiles_x * ((local_rows + (1u << tl) - 1) >> tl);
+  ka.tiles_x = tx;
+  ka.n_tiles = tx * ty;
   // A tile's samples are handed out to the waves of its workgroup in chunks: an item's latency
   // is what the last wave of a frame waits for, but below ~128 samples per item the acquire /
   // finish overhead shows (measured, profiles/r01_run4_tiles.log): 8x8 -> 8 samples per pixel,
@@ -355,7 +363,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   ka.order_mode = s->order_mode != 0 ? 1u : 0u;
   ka.tile_order = nullptr; ka.tile_depth = nullptr;
   if (s->order_mode == 2) {
-    const uint64_t key = ((uint64_t)ka.n_tiles << 32) ^ ((uint64_t)tl << 28) ^ ((uint64_t)ka.first_tile << 14) ^ ka.tile_stride ^ ((uint64_t)ka.tile_rows << 40) ^ ((uint64_t)local_rows << 8);
+    const uint64_t key = ((uint64_t)ka.n_tiles << 32) ^ ((uint64_t)tl << 28) ^ ((uint64_t)flat << 27) ^ ((uint64_t)ka.first_tile << 14) ^ ka.tile_stride ^ ((uint64_t)ka.tile_rows << 40) ^ ((uint64_t)local_rows << 8);
     if (ka.n_tiles > s->order_cap) {
       if (s->d_tile_depth) (void)hipFree(s->d_tile_depth);
       if (s->d_tile_order) (void)hipFree(s->d_tile_order);

@@ -38,7 +38,9 @@ struct KArgs {
   uint32_t* queue;               // tile cursor (zeroed before the launch)
   uint32_t local_rows, tile_rows, first_tile, tile_stride;
   uint32_t tiles_x, n_tiles, n_chunks, chunk_spp;  // a tile's samples are handed out in n_chunks chunks
-  uint32_t tile_log2;  // a tile is 2^tile_log2 x 2^tile_log2 pixels (8x8, 4x4, 2x2 or 1x1)
+  uint32_t tile_log2;  // a tile has 4^tile_log2 pixels (64, 16, 4 or 1) ...
+  uint32_t tile_wl, tile_hl;  // ... 2^tile_wl wide, 2^tile_hl high (tile_wl + tile_hl == 2 * tile_log2): square (8x8 ... 1x1) by
+                              // default, or 64x1, 16x1, 4x1, 1x1 — one tile is one contiguous run of framebuffer bytes
   uint32_t t_slots;    // tile slots per workgroup (tile_slots() of tile_log2)
   // Queue order.  The frame ends on its deepest paths (50 sequential segments of a lone wave), so the tiles
   // that breed them should leave the queue FIRST: position i of the queue is tile tile_order[i] (null: n_tiles-1-i, bottom
@@ -328,8 +330,8 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     const DevScene& sc = ka.sc;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const uint32_t xy = bcast(lds_load(&hdr[k].tile_xy));
-    const uint32_t tl = ka.tile_log2, tw = 1u << tl;
-    const uint32_t px = ((xy & 0xFFFFu) << tl) + (lane & (tw - 1u)), lr = ((xy >> 16) << tl) + (lane >> tl);
+    const uint32_t tl = ka.tile_log2, wl = ka.tile_wl, tw = 1u << wl;
+    const uint32_t px = ((xy & 0xFFFFu) << wl) + (lane & (tw - 1u)), lr = ((xy >> 16) << ka.tile_hl) + (lane >> wl);
     const unsigned long long* acc = tile_acc + k * (3u << (2u * tl));
     const bool valid = lane < (1u << (2u * tl)) && px < sc.width && lr < ka.local_rows;
     const size_t o = ((size_t)lr * sc.width + px) * 3;
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     // of 4 pixels of a tile row is 12 contiguous, 4-byte-aligned bytes, written as three dwords by its first three
     // lanes (R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3; the neighbour's bytes arrive by a lane shift) — one store
     // instruction per flush instead of three byte stores.  Otherwise: bytes.
-    const bool packed = tl >= 2u && (sc.width & 3u) == 0u && (reinterpret_cast<uintptr_t>(ka.out_rgb8) & 3u) == 0u;
+    const bool packed = wl >= 2u && (sc.width & 3u) == 0u && (reinterpret_cast<uintptr_t>(ka.out_rgb8) & 3u) == 0u;
     if (packed) {
       const uint32_t nxt = (uint32_t)__shfl_down((int)rgb, 1);
       const uint32_t i = lane & 3u;
@@ -414,9 +416,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         if (lane == 0) { lds_store(&wg_flags[0], 1u); lds_store(&hdr[k].state, (uint32_t)SLOT_FREE); }
         continue;
       }
-      const uint32_t tl = ka.tile_log2, tw = 1u << tl, npx = 1u << (2u * tl);
+      const uint32_t tl = ka.tile_log2, wl = ka.tile_wl, tw = 1u << wl, npx = 1u << (2u * tl);
       const uint32_t by = tile / ka.tiles_x, bx = tile - by * ka.tiles_x;
-      const uint32_t px = (bx << tl) + (lane & (tw - 1u)), lr = (by << tl) + (lane >> tl);
+      const uint32_t px = (bx << wl) + (lane & (tw - 1u)), lr = (by << ka.tile_hl) + (lane >> wl);
       const uint32_t n_valid = (uint32_t)__builtin_popcountll(wave_ballot(lane < npx && px < sc.width && lr < ka.local_rows));
       // max_depth == 0: ray_color returns black before tracing anything (raytracer.rs:80-82)
       const uint32_t expected = sc.max_depth != 0u ? n_valid * sc.spp : 0u;
@@ -447,9 +449,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const uint32_t xy = bcast(lds_load(&hdr[k].tile_xy));
     const uint32_t bx = xy & 0xFFFFu, by = xy >> 16;
-    const uint32_t tl = ka.tile_log2, tw = 1u << tl, npx = 1u << (2u * tl);  // pixel slots of the tile: lanes 0..npx-1
-    const uint32_t px = (bx << tl) + (lane & (tw - 1u));
-    const uint32_t lr = (by << tl) + (lane >> tl);  // local (packed) row
+    const uint32_t tl = ka.tile_log2, wl = ka.tile_wl, tw = 1u << wl, npx = 1u << (2u * tl);  // pixel slots of the tile: lanes 0..npx-1
+    const uint32_t px = (bx << wl) + (lane & (tw - 1u));
+    const uint32_t lr = (by << ka.tile_hl) + (lane >> wl);  // local (packed) row
     uint32_t py = lr;  // global scanline (raytracer.rs:255: band index, 0 = top)
     if (ka.tile_rows != 0u) py = (ka.first_tile + (lr / ka.tile_rows) * ka.tile_stride) * ka.tile_rows + lr % ka.tile_rows;
     const uint32_t s_begin = chunk * ka.chunk_spp;
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   auto hand_out = [&](bool want, uint32_t& o_px, uint32_t& o_py) -> bool {
     const KArgs& kr = fresh_args();
     const DevScene& sc = kr.sc;
-    const uint32_t tl = kr.tile_log2, tw = 1u << tl, pl = 2u * tl, pmask = (1u << pl) - 1u;
+    const uint32_t wl = kr.tile_wl, tw = 1u << wl, pl = 2u * kr.tile_log2, pmask = (1u << pl) - 1u;
     bool got = false;
     for (;;) {
       const unsigned long long m = wave_ballot(want);
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         const uint32_t p_py = (uint32_t)__shfl((int)py_slot, (int)p);
         const int p_ok = __shfl((int)ok_slot, (int)p);
         if (want && w < it_total && p_ok) {  // (a slot outside the image consumes its index and asks again)
-          const uint32_t p_px = (it_bx << tl) + (p & (tw - 1u));
+          const uint32_t p_px = (it_bx << wl) + (p & (tw - 1u));
           cur_p = p; my_k = it_k; L.s = it_sbeg + (w >> pl); L.ra.pixel = p_py * sc.width + p_px; L.ra.sample = L.s;
           o_px = p_px; o_py = p_py;
           got = true; want = false;

@@ -39,7 +39,7 @@ def torch_cuda():
 def gpu_render(pkg, abi, torch_cuda):
     torch = torch_cuda
 
-    def _render(scene, tiles=None, variant=0, want_linear=True, pool=None, chunk_spp=None, tile_log2=None, tile_order=None, frames=1):
+    def _render(scene, tiles=None, variant=0, want_linear=True, pool=None, chunk_spp=None, tile_log2=None, tile_order=None, frames=1, tile_shape=None):
         """variant 0: the product kernel (grid walk, tile queue, exact fixed-point pixel sums);
         variant 1: same kernel, the reference's brute force over all spheres.  chunk_spp: samples of a
         pixel per work item; tile_log2: pixel tiles of 2^k x 2^k."""
@@ -56,6 +56,8 @@ def gpu_render(pkg, abi, torch_cuda):
             gs.set_option("tile_log2", tile_log2)
         if tile_order is not None:
             gs.set_option("tile_order", tile_order)
+        if tile_shape is not None:
+            gs.set_option("tile_shape", tile_shape)
         rgb = torch.zeros((rows, sc.width, 3), dtype=torch.uint8, device="cuda:0")
         lin = torch.zeros((rows, sc.width, 3), dtype=torch.float32, device="cuda:0") if want_linear else None
         for _ in range(frames):   # (frames > 1: the later frames use the queue order learnt from the one before)
@@ -150,11 +152,19 @@ def test_work_distribution_stress(gpu_render, load_scene):
     frame and the path count never change, run after run."""
     sc = load_scene("cover", 203, 117, 5, 50)  # neither dimension a multiple of any tile size
     ref_rgb, ref_lin, ref_st = gpu_render(sc)
-    for tl, cs in ((0, 1), (0, 5), (1, 1), (2, 2), (3, 1), (3, 5), (1, 3)):
-        for _ in range(2):
-            rgb, lin, st = gpu_render(sc, chunk_spp=cs, tile_log2=tl)
-            assert np.array_equal(rgb, ref_rgb) and np.array_equal(lin, ref_lin), (tl, cs)
-            assert st["segments"] == ref_st["segments"] and st["samples"] == 203 * 117 * 5
+    for shape in (0, 1):   # tiles as squares (8x8 ... 1x1, the default) and as scanline runs (64x1 ... 1x1)
+        for tl, cs in ((0, 1), (0, 5), (1, 1), (2, 2), (3, 1), (3, 5), (1, 3)):
+            for _ in range(2):
+                rgb, lin, st = gpu_render(sc, chunk_spp=cs, tile_log2=tl, tile_shape=shape)
+                assert np.array_equal(rgb, ref_rgb) and np.array_equal(lin, ref_lin), (shape, tl, cs)
+                assert st["segments"] == ref_st["segments"] and st["samples"] == 203 * 117 * 5
+    # a frame whose width is a multiple of 4 takes the dword-packed framebuffer stores (tiles >= 4 pixels wide), others bytes
+    for w in (204, 202):
+        sc2 = load_scene("cover", w, 31, 3, 50)
+        a_rgb, a_lin, _ = gpu_render(sc2, tile_log2=0)          # 1-pixel tiles: always byte stores
+        for shape, tl in ((1, 1), (1, 2), (1, 3), (0, 2), (0, 3)):
+            b_rgb, b_lin, _ = gpu_render(sc2, tile_log2=tl, tile_shape=shape)
+            assert np.array_equal(a_rgb, b_rgb) and np.array_equal(a_lin, b_lin), (w, shape, tl)
     # the order in which tiles leave the queue (top row first / bottom row first / deepest tiles of the previous frame
     # first, over three frames of one resident scene) changes nothing either
     for order in (0, 1, 2):
