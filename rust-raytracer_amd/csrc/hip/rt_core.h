@@ -372,11 +372,34 @@ RT_HD RayK ray_consts(V3 d) {
   k.fast = recip_safe(k.a);  // false for NaN too
   return k;
 }
+#ifndef RT_FLAT_HIT
+#define RT_FLAT_HIT 1  // (-1.5 % kernel time, profiles/r02_run9_ab.log)
+#endif
 template <bool FAST>
 RT_HD bool exact_hit_any_order_t(V3 o, V3 d, const RayK& rk, const SphereGeom& g, uint32_t idx, double& closest, int& best) {
   V3 oc = sub(o, v3(g.cx, g.cy, g.cz));
   double half_b = dot(oc, d);
   double c = length_squared(oc) - g.r * g.r;
+#if RT_FLAT_HIT
+  // one divergent region instead of four nested ones: both roots are always formed and the winner is taken by selects
+  // (the nested form's merge points each copy closest / best; the far root costs 6 instructions more)
+  const double discriminant = (half_b * half_b) - (rk.a * c);
+  bool hit = false;
+  if (!(c > 0.0 && half_b > 0.0) && discriminant >= 0.0) {  // (exact shortcut, see exact_root)
+    const bool tie_ok = best >= 0 && idx < (uint32_t)best;
+    const double sqrtd = rt_sqrt(discriminant);
+    const double num_a = (-half_b) - sqrtd, num_b = (-half_b) + sqrtd;
+    const double root_a = FAST ? div_by_recip(num_a, rk.a, rk.inv_a) : num_a / rk.a;
+    const double root_b = FAST ? div_by_recip(num_b, rk.a, rk.inv_a) : num_b / rk.a;
+    const bool ok_a = root_a > T_MIN && (root_a < closest || (tie_ok && root_a == closest));
+    const bool ok_b = root_b > T_MIN && (root_b < closest || (tie_ok && root_b == closest));
+    hit = ok_a || ok_b;
+    const double root = ok_a ? root_a : root_b;
+    closest = hit ? root : closest;
+    best = hit ? (int)idx : best;
+  }
+  return hit;
+#else
   if (c > 0.0 && half_b > 0.0) return false;  // exact shortcut, see exact_root
   double discriminant = (half_b * half_b) - (rk.a * c);
   if (discriminant >= 0.0) {
@@ -393,6 +416,7 @@ RT_HD bool exact_hit_any_order_t(V3 o, V3 d, const RayK& rk, const SphereGeom& g
     return true;
   }
   return false;
+#endif
 }
 // a ray whose |d|^2 is outside div_by_recip's range: the reference's own arithmetic (cold).
 // Everything travels BY VALUE: a reference parameter of a real call would pin the caller's

@@ -154,8 +154,11 @@ __device__ __forceinline__ const KArgs& fresh_args() {
 #ifndef RT_FUSED_REFILL
 #define RT_FUSED_REFILL 1
 #endif
+#ifndef RT_HANDOUT_DIRECT
+#define RT_HANDOUT_DIRECT 0
+#endif
 #ifndef RT_DEEP_PATH
-#define RT_DEEP_PATH 8u  // camera paths at least this many segments long mark their tile (SlotHdr::max_depth)
+#define RT_DEEP_PATH 2u  // camera paths at least this many segments long mark their tile (SlotHdr::max_depth); 2 / 3 / 4 / 6 / 8 / 16: 13.96 / 13.98 / 13.98 / 14.01 / 14.05 / 14.5 ms (profiles/r02_run10_ab.log)
 #endif
 #ifndef RT_COOP_LAYERS
 #define RT_COOP_LAYERS 4u  // attempts a failing lane gets per helper round, at most (64 / failing lanes, capped)
@@ -480,10 +483,22 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         const uint32_t left = it_total - it_next, asked = (uint32_t)__builtin_popcountll(m);
         it_next += asked < left ? asked : left;
         const uint32_t p = w & pmask;
+        const uint32_t p_px = (it_bx << wl) + (p & (tw - 1u));
+#if RT_HANDOUT_DIRECT
+        // whole frames (no row tiles): the pixel slot's scanline is plain arithmetic — no lane shuffles
+        uint32_t p_py; int p_ok;
+        if (kr.tile_rows == 0u) {
+          p_py = (it_by << kr.tile_hl) + (p >> wl);
+          p_ok = p_px < sc.width && p_py < kr.local_rows;
+        } else {
+          p_py = (uint32_t)__shfl((int)py_slot, (int)p);
+          p_ok = __shfl((int)ok_slot, (int)p);
+        }
+#else
         const uint32_t p_py = (uint32_t)__shfl((int)py_slot, (int)p);
         const int p_ok = __shfl((int)ok_slot, (int)p);
+#endif
         if (want && w < it_total && p_ok) {  // (a slot outside the image consumes its index and asks again)
-          const uint32_t p_px = (it_bx << wl) + (p & (tw - 1u));
           cur_p = p; my_k = it_k; L.s = it_sbeg + (w >> pl); L.ra.pixel = p_py * sc.width + p_px; L.ra.sample = L.s;
           o_px = p_px; o_py = p_py;
           got = true; want = false;
