@@ -38,7 +38,8 @@ def build_host(force=False):
 def build_hip(force=False):
     out = os.path.join(HERE, "librt_hip.so")
     src = _srcs("csrc/hip/rt_hip_api.hip")
-    deps = src + _srcs("csrc/hip/rt_kernel.hip", "csrc/hip/rt_kernel_scan.hip", "csrc/hip/rt_core.h", "csrc/hip/rt_tables.h") + [os.path.join(ROOT, "include/rt_abi.h")]
+    deps = src + _srcs("csrc/hip/rt_kernel.hip", "csrc/hip/rt_hip_group.hip", "csrc/hip/rt_core.h", "csrc/hip/rt_tables.h",
+                       "csrc/common/rt_atan2.h") + [os.path.join(ROOT, "include/rt_abi.h")]
     if force or _newer(out, deps):
         _run(["hipcc", *HIPFLAGS, "-shared", *src, "-o", out])
     return out

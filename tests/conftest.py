@@ -56,6 +56,7 @@ def hostsim(abi):
     src = os.path.join(d, "hostsim.cpp")
     deps = [src] + [os.path.join(ROOT, "rust-raytracer_amd", "csrc", "hip", f) for f in ("rt_core.h", "rt_tables.h")]
     deps.append(os.path.join(ROOT, "include", "rt_abi.h"))
+    deps.append(os.path.join(ROOT, "rust-raytracer_amd", "csrc", "common", "rt_atan2.h"))
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mfma", "-fopenmp", "-Wno-unknown-pragmas",
                         "-shared", src, "-o", so], check=True)
