@@ -204,6 +204,7 @@ def main():
             lats.append((time.perf_counter() - l0) * 1e3)
             assert (frames[0] is not None) == (rank == 0)
         lat_ms = sorted(lats[2:])[len(lats[2:]) // 2]   # median of 5 after 2 warm-ups
+        gs.wait()
     # the whole frame on ONE GPU (rank 0), for the N = 1 reference inside the same line
     n1_kernel_ms = None
     if world > 1:
