@@ -415,6 +415,21 @@ def test_full_size_headline_config_properties(gpu_render, oracle, abi, load_scen
     assert lin[:40].mean() > lin[-40:].mean()
 
 
+def test_full_size_cfg1_test_scene(gpu_render, oracle, abi, load_scene):
+    """BASELINE configs[0] at FULL size (test_scene 800x600, spp 16, depth 8: a Light, earth / moon textures, sky texture,
+    Metal, hollow Glass with a negative radius): the WHOLE frame against the oracle's whole frame — radiance, RGB8, path
+    count (minus the light loops the reference discards), no out-of-range texel."""
+    sc = load_scene("test")
+    c = sc.c
+    assert (c.width, c.height, c.samples_per_pixel, c.max_depth, c.n_spheres) == (800, 600, 16, 8, 7) and len(sc.lights()) == 1
+    rgb, lin, st = gpu_render(sc)
+    o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+    err, flips = assert_parity(rgb, lin, o_rgb, o_lin, "cfg1 whole frame", atol=pooled_atol(16), flip_frac=5e-4)
+    assert st["segments"] == o_st["segments"] - o_st["segments_discarded"] and o_st["segments_discarded"] > 0
+    assert st["tex_oob"] == 0 == o_st["tex_oob"] and st["samples"] == 800 * 600 * 16
+    print(f"cfg1 full size: whole frame vs oracle, max |dlin| {err:.2e}, rgb8 flips {flips}, kernel {st['kernel_ms']:.2f} ms")
+
+
 def test_full_size_cfg3_textured_4k(gpu_render, oracle, abi, load_scene):
     """BASELINE configs[2] at FULL size: cover world at 3840x2160, spp 1024, earth / moon textures on the three big
     spheres + beach sky texture (the texture-fetch path: sphere_uv's atan2, get_albedo, sky lookup).  Whole frame on
