@@ -318,7 +318,7 @@ def main():
             csec, ost, rows = cpu_run(stride)
             out["cpu_baseline"] = {"value": round(ost["samples"] / csec / 1e6, 4), "unit": "Msamples/s",
                                    "cores": cores, "kind": "port",
-                                   "sample": f"every {stride}th scanline of the same frame ({rows} rows, {ost['samples'] / 1e6:.2f} Msamples, "
+                                   "sample": f"{'every scanline' if stride == 1 else ('every 2nd scanline' if stride == 2 else ('every 3rd scanline' if stride == 3 else f'every {stride}th scanline'))} of the same frame ({rows} rows, {ost['samples'] / 1e6:.2f} Msamples, "
                                              f"{csec:.1f} s); C oracle, OpenMP over 32-pixel blocks of a scanline, -O3 -march=native -ffp-contract=off",
                                    "gpu_over_cpu": round(value / (ost["samples"] / csec / 1e6), 1)}
         line = json.dumps(out)
