@@ -797,14 +797,62 @@ struct LightFrame {  // one ray_color activation that is summing over the lights
   uint32_t j;        // next light
   uint32_t node;     // its RNG node (children are child_node(node, j))
 };
+// The suspended outer activations of a lane (nesting levels below the active one).  They are indexed by a per-lane
+// depth and therefore live in scratch memory; a SEPARATE object from the Lane on purpose: one variable-index access
+// into any part of an object keeps the WHOLE object in memory (the compiler cannot split it), and with this array inside
+// Lane every lane field went through scratch in the lit kernels (720 B per lane, 197 MB per launch, L2-thrashing: lit
+// scenes ran 2.5x slower per segment than unlit ones).  Fields apart, so that no block copy touches `cur` either.
+template <bool HAS_LIGHTS>
+struct LightStack {};
+template <>
+struct LightStack<true> {
+  double P[RT_MAX_LIGHT_NEST - 1][3];
+  float a[RT_MAX_LIGHT_NEST - 1][6];  // a[0..2], acc[0..2]
+  uint32_t j[RT_MAX_LIGHT_NEST - 1][2];  // j, node
+};
+// The activation summing over the lights right now (nesting level `top`; 0 = the camera-path hit), and the camera
+// path's scattered direction to resume with.  Touched a few times per light-sampling hit (about 4 % of the segments of
+// a one-light scene) but alive across every walk in between: 20 registers per lane that the 128-VGPR kernel does not
+// have (117 spills, each a scratch round trip the wave waits for).  So it is "parked": the kernel points `pk` at a
+// per-lane record in LDS, the host simulator at a local.
+struct LightParked {
+  LightFrame cur;
+  V3 saved_d;
+};
+static_assert(sizeof(LightParked) == 80, "parked light state is 80 B per lane");
 template <bool HAS_LIGHTS>
 struct LightState {};
 template <>
 struct LightState<true> {
-  LightFrame fr[RT_MAX_LIGHT_NEST];  // fr[0] = the camera-path hit, fr[m] = nesting level m
-  V3 saved_d;                        // scattered direction of the camera path, resumed afterwards
+  LightParked* pk;
+  LightStack<true>* stack; // levels 0..top-1: touched only when a light ray's own hit starts sampling the lights again
+                           // (probability 0.1 n_lights) and when that nested activation returns
   int top;
 };
+
+RT_HD void light_frame_push(LightState<true>& ls) {  // stack[top] <- cur; ++top
+  const int t = ls.top;
+  LightStack<true>& k = *ls.stack;
+  const LightFrame& c = ls.pk->cur;
+  k.P[t][0] = c.P.x; k.P[t][1] = c.P.y; k.P[t][2] = c.P.z;
+  k.a[t][0] = c.a[0]; k.a[t][1] = c.a[1]; k.a[t][2] = c.a[2];
+  k.a[t][3] = c.acc[0]; k.a[t][4] = c.acc[1]; k.a[t][5] = c.acc[2];
+  k.j[t][0] = c.j; k.j[t][1] = c.node;
+  ls.top = t + 1;
+}
+RT_HD void light_frame_pop(LightState<true>& ls) {  // --top; cur <- stack[top]
+  const int t = ls.top - 1;
+  const LightStack<true>& k = *ls.stack;
+  LightFrame& c = ls.pk->cur;
+  c.P.x = k.P[t][0]; c.P.y = k.P[t][1]; c.P.z = k.P[t][2];
+  c.a[0] = k.a[t][0]; c.a[1] = k.a[t][1]; c.a[2] = k.a[t][2];
+  c.acc[0] = k.a[t][3]; c.acc[1] = k.a[t][4]; c.acc[2] = k.a[t][5];
+  c.j = k.j[t][0]; c.node = k.j[t][1];
+  ls.top = t;
+}
+// Lane setup: `stk` and `*pk` must outlive the lane.
+template <class LaneT> RT_HD void lane_attach_light_state(LaneT&, LightStack<false>&, LightParked*) {}
+template <class LaneT> RT_HD void lane_attach_light_state(LaneT& L, LightStack<true>& stk, LightParked* pk) { L.ls.stack = &stk; L.ls.pk = pk; L.ls.top = 0; }
 
 template <bool HAS_LIGHTS, bool SIMPLE = false>
 struct Lane {
@@ -902,7 +950,7 @@ RT_HD bool lane_continue_main(const DevScene& sc, LaneT& L, V3 point, V3 out_dir
 // aim the current ray at light j of frame `top` (raytracer.rs:104-106)
 template <class Tables>
 RT_HD void lane_aim_light(const DevScene& sc, const Tables& tb, Lane<true>& L) {
-  LightFrame& f = L.ls.fr[L.ls.top];
+  LightFrame& f = L.ls.pk->cur;
   const SphereGeom lg = tb.geom(sc.lights[f.j]);
   L.o = f.P;
   L.d = sub(v3(lg.cx, lg.cy, lg.cz), f.P);
@@ -913,17 +961,17 @@ RT_HD void lane_aim_light(const DevScene& sc, const Tables& tb, Lane<true>& L) {
 template <class Tables>
 RT_HD bool lane_light_return(const DevScene& sc, const Tables& tb, Lane<true>& L, Rgb tc) {
   for (;;) {
-    LightFrame& f = L.ls.fr[L.ls.top];
+    LightFrame& f = L.ls.pk->cur;
     f.acc[0] += f.a[0] * tc.r; f.acc[1] += f.a[1] * tc.g; f.acc[2] += f.a[2] * tc.b;
     f.j += 1;
     if (f.j < sc.n_lights) { lane_aim_light(sc, tb, L); return false; }
     float nl = (float)sc.n_lights;
     float light[3] = {f.acc[0] / nl, f.acc[1] / nl, f.acc[2] / nl};
     if (L.ls.top == 0)  // back on the camera path: clamp(light + albedo*child), child = scattered ray
-      return lane_continue_main(sc, L, f.P, L.ls.saved_d, light, f.a);
+      return lane_continue_main(sc, L, f.P, L.ls.pk->saved_d, light, f.a);
     // a nested activation (max_depth 2, depth 1): its own child is depth 0 = black (:117-122)
     tc = rgb(clamp01(light[0] + f.a[0] * 0.0f), clamp01(light[1] + f.a[1] * 0.0f), clamp01(light[2] + f.a[2] * 0.0f));
-    L.ls.top -= 1;
+    light_frame_pop(L.ls);  // the activation that shot the light ray goes on
   }
 }
 
@@ -959,8 +1007,8 @@ RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, d
         double prob = m.kind == RT_MAT_GLASS ? 0.05 : 0.1;
         U4 w = rng(L.ra, L.node, 0);
         if (u01_53(w.z, w.w) > (1.0 - (double)sc.n_lights * prob)) {
-          L.ls.top += 1;
-          LightFrame& f = L.ls.fr[L.ls.top];
+          light_frame_push(L.ls);  // suspend the activation whose light ray this is
+          LightFrame& f = L.ls.pk->cur;
           f.P = h.point; f.a[0] = att[0]; f.a[1] = att[1]; f.a[2] = att[2];
           f.acc[0] = f.acc[1] = f.acc[2] = 0.0f; f.j = 0; f.node = L.node;
           lane_aim_light(sc, tb, L);
@@ -981,10 +1029,10 @@ RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, d
       U4 w = rng(L.ra, L.node, 0);
       if (u01_53(w.z, w.w) > (1.0 - (double)sc.n_lights * prob)) {
         L.ls.top = 0;
-        LightFrame& f = L.ls.fr[0];
+        LightFrame& f = L.ls.pk->cur;
         f.P = h.point; f.a[0] = att[0]; f.a[1] = att[1]; f.a[2] = att[2];
         f.acc[0] = f.acc[1] = f.acc[2] = 0.0f; f.j = 0; f.node = L.node;
-        L.ls.saved_d = out_dir;
+        L.ls.pk->saved_d = out_dir;
         lane_aim_light(sc, tb, L);
         return false;
       }

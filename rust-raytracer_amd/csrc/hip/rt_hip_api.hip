@@ -354,9 +354,9 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   ka.n_chunks = spp ? (spp + chunk_spp - 1) / chunk_spp : 1;
   const uint32_t n_items = ka.n_tiles * ka.n_chunks;
   const rtc::GridDesc& G = ka.sc.grid;
-  const rtk::LdsLayout with_tables = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true);
+  const rtk::LdsLayout with_tables = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, s->has_lights);
   const bool lds_tables = with_tables.total <= rtk::LDS_TABLES_MAX_BYTES;
-  const size_t lds_bytes = lds_tables ? with_tables.total : rtk::lds_layout(0, 0, 0, false).total;
+  const size_t lds_bytes = lds_tables ? with_tables.total : rtk::lds_layout(0, 0, 0, false, s->has_lights).total;
 
   // queue order: bottom of the image first; from the second frame of a tile geometry on, the tiles whose samples ran
   // deepest in the previous frame first (their paths are what a frame ends on)

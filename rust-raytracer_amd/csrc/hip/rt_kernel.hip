@@ -111,13 +111,14 @@ __host__ __device__ inline uint32_t tile_slots(uint32_t tile_log2) {
   return t > T_SLOTS_MAX ? T_SLOTS_MAX : t;
 }
 struct LdsLayout {
-  uint32_t hdr_off, coop_off, geom_off, matc_off, cell_off, item_off, total;
+  uint32_t hdr_off, coop_off, park_off, geom_off, matc_off, cell_off, item_off, total;
 };
-__host__ __device__ inline LdsLayout lds_layout(uint32_t n_spheres, uint32_t n_cells, uint32_t n_items, bool tables) {
+__host__ __device__ inline LdsLayout lds_layout(uint32_t n_spheres, uint32_t n_cells, uint32_t n_items, bool tables, bool lights) {
   LdsLayout l;
   uint32_t o = LDS_FLAGS_BYTES;
   l.hdr_off = o; o += LDS_SLOT_BUDGET;  // [t_slots headers][t_slots x npx x 3 u64 sums], sized by tile_slots()
   l.coop_off = o; o += WAVES * 64u * 16u;  // per wave: 64 x 16 B exchange slots of coop_random_in_unit_sphere
+  l.park_off = o; if (lights) o += (uint32_t)BLOCK * (uint32_t)sizeof(LightParked);  // per lane: rt_core.h LightParked
   l.geom_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(SphereGeom);
   l.matc_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(MatCore);
   l.cell_off = o; if (tables) o += n_cells * 8u;
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   RT_PROF_DECL
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const LdsLayout lay = lds_layout(sc.n_spheres, G.n_cells, G.n_items, LDS_TABLES);
+  const LdsLayout lay = lds_layout(sc.n_spheres, G.n_cells, G.n_items, LDS_TABLES, HL);
   uint32_t* const wg_flags = reinterpret_cast<uint32_t*>(lds_raw);  // [0] the frame's tile queue is empty, [1] slot opened last
   SlotHdr* const hdr = reinterpret_cast<SlotHdr*>(lds_raw + lay.hdr_off);
   const uint32_t T = ka.t_slots, acc_stride = 3u << (2u * ka.tile_log2);  // u64 words of pixel sums per slot
@@ -302,7 +303,8 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   L.ra.pixel = 0; L.ra.sample = 0; L.ra.k0 = sc.seed_lo; L.ra.k1 = sc.seed_hi;
   L.o = v3(0, 0, 0); L.d = v3(0, 0, 1);
   fwd_init(L.fwd);
-  if constexpr (HL) L.ls.top = 0;
+  LightStack<HL> light_stack;
+  lane_attach_light_state(L, light_stack, reinterpret_cast<LightParked*>(lds_raw + lay.park_off) + threadIdx.x);
   uint32_t n_segments = 0, n_exact = 0, n_steps = 0;  // per-lane counters (one exec-masked add each)
   uint32_t cnt_w_iter = 0, cnt_w_step = 0, cnt_w_test = 0, cnt_items = 0;  // wave trip counts (RT_PROFILE builds)
 

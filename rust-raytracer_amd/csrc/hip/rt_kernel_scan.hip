@@ -99,7 +99,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   L.ra.pixel = py * sc.width + px; L.ra.sample = 0; L.ra.k0 = sc.seed_lo; L.ra.k1 = sc.seed_hi;
   L.o = v3(0, 0, 0); L.d = v3(0, 0, 1);
   fwd_init(L.fwd);
-  if constexpr (HL) L.ls.top = 0;
+  LightStack<HL> light_stack;
+  LightParked light_parked;
+  lane_attach_light_state(L, light_stack, &light_parked);
   float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;  // !POOL: pixel_colors (raytracer.rs:197)
   uint32_t cur_p = lane;                         // POOL: tile pixel slot of the current sample
   uint32_t next_w = 0;                           // POOL: wave-uniform cursor into the sample pool

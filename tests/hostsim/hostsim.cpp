@@ -29,6 +29,9 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
     for (uint32_t x = 0; x < sc.width; ++x) {
       Lane<HL> L;
       std::memset(&L, 0, sizeof L);
+      LightStack<HL> light_stack;
+      LightParked light_parked;
+      lane_attach_light_state(L, light_stack, &light_parked);
       float acc[3] = {0.f, 0.f, 0.f};                 // accum 0: the reference's sequential f32 sum
       unsigned long long facc[3] = {0ull, 0ull, 0ull};  // accum 1: exact fixed point (pooled-sample kernels)
       bool fnan[3] = {false, false, false};             // (+ the NaN flags that go with it)
