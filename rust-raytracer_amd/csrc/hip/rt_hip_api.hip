@@ -201,7 +201,7 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
   if (!std::strcmp(key, "variant")) { if (value < 0 || value > max_variant) return fail(RT_ERR_INVALID, "variant must be 0 (grid walk) or 1 (brute force)"); s->variant = (int)value; return RT_OK; }
   if (!std::strcmp(key, "pool")) { s->pool = value != 0; return RT_OK; }
   if (!std::strcmp(key, "tile_log2")) { if (value < -1 || value > 3) return fail(RT_ERR_INVALID, "tile_log2 must be -1..3"); s->tile_log2 = (int)value; return RT_OK; }
-  if (!std::strcmp(key, "tile_shape")) { if (value < 0 || value > 1) return fail(RT_ERR_INVALID, "tile_shape must be 0 (square) or 1 (scanline runs)"); s->tile_shape = (int)value; return RT_OK; }
+  if (!std::strcmp(key, "tile_shape")) { if (value < 0 || value > 3) return fail(RT_ERR_INVALID, "tile_shape must be 0 (square), 1 (scanline runs), 2 (4:1) or 3 (16:1)"); s->tile_shape = (int)value; return RT_OK; }
   if (!std::strcmp(key, "tile_order")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_order must be 0, 1 or 2"); s->order_mode = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
   if (!std::strcmp(key, "chunk_spp")) { if (value < 0) return fail(RT_ERR_INVALID, "chunk_spp must be >= 0"); s->chunk_spp = (int)value; return RT_OK; }
   if (!std::strcmp(key, "samples_per_pixel") || !std::strcmp(key, "max_depth")) {
@@ -313,9 +313,10 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   // workgroup's share and the long-path regions spread over many workgroups.
   const uint64_t want_tiles = (uint64_t)s->num_cus * 100u;
   // tile geometry: 4^tl pixels, as a run of one scanline (default) or a square
-  const bool flat = s->tile_shape != 0;
+  // (shape 0: 2^t x 2^t; 1: 4^t x 1; 2 and 3: the square widened / flattened once or twice, 16x4 and 32x2 at t = 3)
+  auto widen = [&](uint32_t t) { const uint32_t k = s->tile_shape == 0 ? 0u : (s->tile_shape == 1 ? t : (uint32_t)s->tile_shape - 1u); return k < t ? k : t; };
   auto tiles_xy = [&](uint32_t t, uint32_t& tx, uint32_t& ty) {
-    const uint32_t wl = flat ? 2u * t : t, hl = flat ? 0u : t;
+    const uint32_t wl = t + widen(t), hl = t - widen(t);
     tx = (s->host.width + (1u << wl) - 1) >> wl; ty = (local_rows + (1u << hl) - 1) >> hl;
   };
   uint32_t tl = (uint32_t)s->tile_log2, tx = 0, ty = 0;
@@ -328,7 +329,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   while (tl < 3 && too_many(tl)) tl++;
   if (too_many(tl)) return fail(RT_ERR_UNSUPPORTED, "frame too large for the tile queue (more than 65535 tiles on an axis or 2^31 tiles)");
   ka.tile_log2 = tl;
-  ka.tile_wl = flat ? 2u * tl : tl; ka.tile_hl = flat ? 0u : tl;
+  ka.tile_wl = tl + widen(tl); ka.tile_hl = tl - widen(tl);
   ka.t_slots = rtk::tile_slots(tl);
   ka.tiles_x = tx;
   ka.n_tiles = tx * ty;
@@ -363,7 +364,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   ka.order_mode = s->order_mode != 0 ? 1u : 0u;
   ka.tile_order = nullptr; ka.tile_depth = nullptr;
   if (s->order_mode == 2) {
-    const uint64_t key = ((uint64_t)ka.n_tiles << 32) ^ ((uint64_t)tl << 28) ^ ((uint64_t)flat << 27) ^ ((uint64_t)ka.first_tile << 14) ^ ka.tile_stride ^ ((uint64_t)ka.tile_rows << 40) ^ ((uint64_t)local_rows << 8);
+    const uint64_t key = ((uint64_t)ka.n_tiles << 32) ^ ((uint64_t)tl << 28) ^ ((uint64_t)s->tile_shape << 26) ^ ((uint64_t)ka.first_tile << 14) ^ ka.tile_stride ^ ((uint64_t)ka.tile_rows << 40) ^ ((uint64_t)local_rows << 8);
     if (ka.n_tiles > s->order_cap) {
       if (s->d_tile_depth) (void)hipFree(s->d_tile_depth);
       if (s->d_tile_order) (void)hipFree(s->d_tile_order);

@@ -152,8 +152,8 @@ def test_work_distribution_stress(gpu_render, load_scene):
     frame and the path count never change, run after run."""
     sc = load_scene("cover", 203, 117, 5, 50)  # neither dimension a multiple of any tile size
     ref_rgb, ref_lin, ref_st = gpu_render(sc)
-    for shape in (0, 1):   # tiles as squares (8x8 ... 1x1, the default) and as scanline runs (64x1 ... 1x1)
-        for tl, cs in ((0, 1), (0, 5), (1, 1), (2, 2), (3, 1), (3, 5), (1, 3)):
+    for shape in (0, 1, 2, 3):   # tiles as squares (8x8 ... 1x1, the default), scanline runs (64x1 ... 1x1), 16x4, 32x2
+        for tl, cs in ((0, 1), (0, 5), (1, 1), (2, 2), (3, 1), (3, 5), (1, 3)) if shape < 2 else ((1, 1), (2, 2), (3, 1), (3, 5)):
             for _ in range(2):
                 rgb, lin, st = gpu_render(sc, chunk_spp=cs, tile_log2=tl, tile_shape=shape)
                 assert np.array_equal(rgb, ref_rgb) and np.array_equal(lin, ref_lin), (shape, tl, cs)
@@ -162,7 +162,7 @@ def test_work_distribution_stress(gpu_render, load_scene):
     for w in (204, 202):
         sc2 = load_scene("cover", w, 31, 3, 50)
         a_rgb, a_lin, _ = gpu_render(sc2, tile_log2=0)          # 1-pixel tiles: always byte stores
-        for shape, tl in ((1, 1), (1, 2), (1, 3), (0, 2), (0, 3)):
+        for shape, tl in ((1, 1), (1, 2), (1, 3), (0, 2), (0, 3), (2, 3), (3, 3), (2, 1)):
             b_rgb, b_lin, _ = gpu_render(sc2, tile_log2=tl, tile_shape=shape)
             assert np.array_equal(a_rgb, b_rgb) and np.array_equal(a_lin, b_lin), (w, shape, tl)
     # the order in which tiles leave the queue (top row first / bottom row first / deepest tiles of the previous frame
@@ -267,6 +267,28 @@ def test_many_lights_nested_sampling(gpu_render, oracle, abi, host):
         assert_parity(rgb, lin, o_rgb, o_lin, f"3 lights variant {variant}", atol=pooled_atol(16))
         assert o_lin.max() > 0.05 and st["segments"] > st["samples"]
         assert o_st["segments_discarded"] > 0 and st["segments"] == o_st["segments"] - o_st["segments_discarded"]
+
+
+def test_lit_cover_scene_tables_beside_the_parked_light_state(gpu_render, oracle, abi, host):
+    """lights in a gridded scene: the lit kernel keeps each lane's active light frame in LDS (80 B x 1024 lanes), so the
+    cover scene's tables no longer fit beside it and are read through L2 — and with two lights every fifth hit of depth
+    0/1 samples them.  Same frame as the oracle's, grid or brute force."""
+    cfg = json.load(open(os.path.join(ROOT, "scenes", "cfg2_cover_1200x800_spp128.json")))
+    cfg.update(width=96, height=64, samples_per_pixel=8)
+    cfg["objects"].append({"center": {"x": 0.0, "y": 30.0, "z": 10.0}, "radius": 8.0, "material": {"Light": {}}})
+    cfg["objects"].append({"center": {"x": 3.0, "y": 2.5, "z": 2.0}, "radius": 0.4, "material": {"Light": {}}})
+    sc = host.Scene.loads(json.dumps(cfg))
+    assert len(sc.lights()) == 2 and sc.c.n_spheres == 486
+    o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+    for variant in (0, 1):
+        rgb, lin, st = gpu_render(sc, variant=variant)
+        assert_parity(rgb, lin, o_rgb, o_lin, f"lit cover variant {variant}", atol=pooled_atol(8))
+        assert st["segments"] == o_st["segments"] - o_st["segments_discarded"]
+    assert st["exact_tests"] == st["sphere_tests"]
+    rgb, lin, st = gpu_render(sc, variant=0)
+    assert st["grid_steps"] > 0 and st["exact_tests"] < 0.05 * st["sphere_tests"]
+    # a small lit scene (tables AND parked frames in LDS) is what test_matches_oracle_and_golden[test_*] and
+    # test_many_lights_nested_sampling render
 
 
 def test_procedural_10k_spheres(gpu_render, oracle, abi, host):

@@ -57,8 +57,8 @@ if [[ " $* " == *" configs "* ]]; then
 fi
 if [[ " $* " == *" sweep "* ]]; then
   {
-    echo "# tile shape (0 = squares, 1 = scanline runs): whole frame, 1/8 shard, cfg3 4K"
-    for SH in 0 1; do
+    echo "# tile shape (0 = squares, 1 = scanline runs, 2 = 16x4, 3 = 32x2): whole frame, 1/8 shard, cfg3 4K"
+    for SH in 0 2 3 1; do
       echo -n "tile_shape=$SH whole "; timeout 60 python tools/diag.py --reps 6 --opt tile_shape=$SH 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['kernel_ms'])"
       echo -n "tile_shape=$SH shard 3/8 "; timeout 60 python tools/diag.py --shard 3,8,2 --reps 8 --opt tile_shape=$SH 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['kernel_ms'])"
       echo -n "tile_shape=$SH cfg3 "; timeout 60 python tools/diag.py --scene scenes/cfg3_cover_4k_textured.json --reps 2 --opt tile_shape=$SH 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['kernel_ms'])"
