@@ -291,55 +291,69 @@ extern "C" int rt_hip_group_render_to_host(RtHipGroup* g, uint8_t* out_rgb8, RtS
     std::unique_lock<std::mutex> lk(g->mu);
     g->cv_done.wait(lk, [&] { return g->n_done == G; });
   }
+  // whatever fails from here on, every stream is drained and every scene is released before the error is returned
+  // (a scene left "in flight" would refuse the caller's next frame)
+  auto drain = [&]() {
+    const std::string keep = g_err;
+    for (uint32_t q = 0; q < G; ++q) { (void)hipSetDevice(g->device[q]); (void)hipStreamSynchronize(g->stream[q]); g->scene[q]->in_flight = false; }
+    (void)hipGetLastError();
+    g_err = keep;
+  };
   for (uint32_t r = 0; r < G; ++r)
     if (g->rc[r] != RT_OK) {
-      for (uint32_t q = 0; q < G; ++q) { (void)hipSetDevice(g->device[q]); (void)hipStreamSynchronize(g->stream[q]); g->scene[q]->in_flight = false; }
+      drain();
       return fail(g->rc[r], "rank " + std::to_string(r) + ": " + g->err[r]);
     }
-  RT_HIP_TRY(hipSetDevice(g->device[0]));
-  hipStream_t s0 = g->stream[0];
-  if (g->gather) {
-    if (g->rccl) {  // ONE gather over xGMI: every rank's packed tiles -> rank 0's `stacked`, stream-ordered after its kernel
-      ncclResult_t nr = g->api.GroupStart();
-      for (uint32_t r = 0; r < G && nr == ncclSuccess; ++r)
-        nr = g->api.Gather(g->d_tiles[r], g->d_stacked, g->pad_bytes, ncclUint8, 0, g->comm[r], g->stream[r]);
-      const ncclResult_t ne = g->api.GroupEnd();
-      if (nr == ncclSuccess) nr = ne;
-      if (nr != ncclSuccess) return fail(RT_ERR_HIP, std::string("ncclGather: ") + g->api.GetErrorString(nr));
-    } else {
-      for (uint32_t r = 1; r < G; ++r) RT_HIP_TRY(hipStreamWaitEvent(s0, g->ev_done[r], 0));
-    }
-    hipLaunchKernelGGL(rtg::deinterleave_rows, dim3(g->height), dim3(256), 0, s0, static_cast<const uint8_t*>(g->d_stacked),
-                       static_cast<uint8_t*>(g->d_frame), g->height, (uint32_t)g->row_bytes, G, RT_GROUP_TILE_ROWS, g->pad_rows);
-    RT_HIP_TRY(hipGetLastError());
-  }
-  RT_HIP_TRY(hipEventRecord(g->ev_assembled, s0));
-  RT_HIP_TRY(hipMemcpyAsync(out_rgb8, g->d_frame, (size_t)g->height * g->row_bytes, hipMemcpyDeviceToHost, s0));
-  RT_HIP_TRY(hipStreamSynchronize(s0));
-  const double frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   RtStats total;
   std::memset(&total, 0, sizeof total);
-  for (uint32_t r = 0; r < G; ++r) {  // (also drains the other ranks' streams: with RCCL their gather kernels)
-    RtStats st;
-    const int rc = rt_hip_wait(g->scene[r], &st);
-    if (rc != RT_OK) return rc;
-    total.samples += st.samples; total.segments += st.segments; total.sphere_tests += st.sphere_tests;
-    total.exact_tests += st.exact_tests; total.tex_oob += st.tex_oob; total.grid_steps += st.grid_steps;
-    for (int k = 0; k < 4; ++k) total.wave_iters[k] += st.wave_iters[k];
-    if (st.kernel_ms > total.kernel_ms) total.kernel_ms = st.kernel_ms;  // the slowest rank
-  }
-  if (stats) {
-    *stats = total;
-    stats->n_gpus_used = G;
-    stats->frame_ms = frame_ms;
-    if (g->gather && g->scene[0]->launched) {
-      RT_HIP_TRY(hipSetDevice(g->device[0]));
-      float ms = 0.f;
-      RT_HIP_TRY(hipEventElapsedTime(&ms, g->scene[0]->ev_stop, g->ev_assembled));
-      stats->gather_ms = ms;  // rank 0's kernel end -> frame in scanline order on device 0 (includes waiting for slower ranks)
+  double frame_ms = 0.0;
+  auto assemble = [&]() -> int {
+    RT_HIP_TRY(hipSetDevice(g->device[0]));
+    hipStream_t s0 = g->stream[0];
+    if (g->gather) {
+      if (g->rccl) {  // ONE gather over xGMI: every rank's packed tiles -> rank 0's `stacked`, stream-ordered after its kernel
+        ncclResult_t nr = g->api.GroupStart();
+        for (uint32_t r = 0; r < G && nr == ncclSuccess; ++r)
+          nr = g->api.Gather(g->d_tiles[r], g->d_stacked, g->pad_bytes, ncclUint8, 0, g->comm[r], g->stream[r]);
+        const ncclResult_t ne = g->api.GroupEnd();
+        if (nr == ncclSuccess) nr = ne;
+        if (nr != ncclSuccess) return fail(RT_ERR_HIP, std::string("ncclGather: ") + g->api.GetErrorString(nr));
+      } else {
+        for (uint32_t r = 1; r < G; ++r) RT_HIP_TRY(hipStreamWaitEvent(s0, g->ev_done[r], 0));
+      }
+      hipLaunchKernelGGL(rtg::deinterleave_rows, dim3(g->height), dim3(256), 0, s0, static_cast<const uint8_t*>(g->d_stacked),
+                         static_cast<uint8_t*>(g->d_frame), g->height, (uint32_t)g->row_bytes, G, RT_GROUP_TILE_ROWS, g->pad_rows);
+      RT_HIP_TRY(hipGetLastError());
     }
-  }
-  return RT_OK;
+    RT_HIP_TRY(hipEventRecord(g->ev_assembled, s0));
+    RT_HIP_TRY(hipMemcpyAsync(out_rgb8, g->d_frame, (size_t)g->height * g->row_bytes, hipMemcpyDeviceToHost, s0));
+    RT_HIP_TRY(hipStreamSynchronize(s0));
+    frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (uint32_t r = 0; r < G; ++r) {  // (also drains the other ranks' streams: with RCCL their gather kernels)
+      RtStats st;
+      const int rc = rt_hip_wait(g->scene[r], &st);
+      if (rc != RT_OK) return rc;
+      total.samples += st.samples; total.segments += st.segments; total.sphere_tests += st.sphere_tests;
+      total.exact_tests += st.exact_tests; total.tex_oob += st.tex_oob; total.grid_steps += st.grid_steps;
+      for (int k = 0; k < 4; ++k) total.wave_iters[k] += st.wave_iters[k];
+      if (st.kernel_ms > total.kernel_ms) total.kernel_ms = st.kernel_ms;  // the slowest rank
+    }
+    if (stats) {
+      *stats = total;
+      stats->n_gpus_used = G;
+      stats->frame_ms = frame_ms;
+      if (g->gather && g->scene[0]->launched) {
+        RT_HIP_TRY(hipSetDevice(g->device[0]));
+        float ms = 0.f;
+        RT_HIP_TRY(hipEventElapsedTime(&ms, g->scene[0]->ev_stop, g->ev_assembled));
+        stats->gather_ms = ms;  // rank 0's kernel end -> frame in scanline order on device 0 (includes waiting for slower ranks)
+      }
+    }
+    return RT_OK;
+  };
+  const int rc = assemble();
+  if (rc != RT_OK) drain();
+  return rc;
 }
 
 // drop-in for the parallel loop of render() (raytracer.rs:254-263): host scene in, host RGB8 out

@@ -42,7 +42,10 @@ const Value& field(const Value& obj, const char* key, const char* where) {
 }
 double as_f64(const Value& v, const char* what) {
   if (v.kind != Value::Number) bad(std::string("expected number for ") + what);
-  return std::strtod(v.text.c_str(), nullptr);
+  const double x = std::strtod(v.text.c_str(), nullptr);
+  // serde_json rejects a literal beyond f64's range ("number out of range"); it never yields an infinity
+  if (!std::isfinite(x)) bad(std::string("number out of range for ") + what);
+  return x;
 }
 float as_f32(const Value& v, const char* what) {
   // serde_json parses the literal as f64 and casts (`as f32`)
@@ -282,6 +285,7 @@ void build_scene(const Value& root, RtSceneFile& sf) {
 template <typename F>
 std::string shortest(F x, int max_prec, bool is32) {
   if (x == 0) return std::signbit(x) ? "-0.0" : "0.0";
+  if (!std::isfinite(x)) return "null";  // serde_json writes non-finite floats as null (an f32 field cast from 1e39 is +inf)
   char buf[64];
   int prec = 0;
   for (; prec <= max_prec; ++prec) {

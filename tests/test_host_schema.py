@@ -86,6 +86,8 @@ def test_reference_scenes_load(host, abi):
     (CFG_DEFAULT_SKY.replace('"width":100', '"width":1.5'), "RT_ERR_PARSE"), (CFG_DEFAULT_SKY.replace("Lambertian", "Plastic"), "RT_ERR_PARSE"),
     (CFG_DEFAULT_SKY.replace('[0.8,0.3,0.3]', '[0.8,0.3]'), "RT_ERR_PARSE"),
     (CFG_DEFAULT_SKY.replace('"sky":{"texture":""}', '"sky":{"texture":"nope.jpg"}'), "RT_ERR_TEXTURE"),
+    (CFG_DEFAULT_SKY.replace('"radius":0.5', '"radius":1e999'), "RT_ERR_PARSE"),   # serde_json: "number out of range"
+    ("[" * 100000, "RT_ERR_PARSE"),                                               # serde_json: recursion limit
 ])
 def test_errors_instead_of_panics(host, abi, text, code):
     """main.rs:14-15 / materials.rs:214 expect() panics become error codes."""
@@ -98,6 +100,16 @@ def test_missing_file(host, abi):
     with pytest.raises(host.RtError) as e:
         host.Scene.load("/nonexistent/scene.json")
     assert e.value.code == abi.RT_ERR_IO and "Unable to read config file." in str(e.value)
+
+
+def test_f32_field_beyond_f32_range_is_infinity_and_serialises_as_null(host):
+    """serde_json reads the literal as f64 and casts (`as f32`): 1e39 is a valid f64 and becomes +inf in an albedo;
+    to_string writes non-finite floats as null.  (Found by fuzzing under ASan: the number formatter used to index past
+    the text "inf".)"""
+    sc = host.Scene.loads(CFG_DEFAULT_SKY.replace("[0.8,0.3,0.3]", "[1e39,-1e39,0.3]"))
+    a = sc.c.spheres[0].albedo
+    assert a[0] == float("inf") and a[1] == float("-inf")
+    assert '"albedo":[null,null,0.3]' in sc.to_json()
 
 
 def test_unknown_fields_ignored_and_int_floats(host):
