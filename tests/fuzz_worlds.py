@@ -63,3 +63,40 @@ def fuzz_world_json(rng, kind, w=72, h=48, spp=3, depth=12):
            "vup": {"x": 0.0, "y": 1.0, "z": 0.0}, "vfov": 50.0, "aspect": w / h}
     return json.dumps({"width": w, "height": h, "samples_per_pixel": spp, "max_depth": depth, "sky": {"texture": ""},
                        "camera": cam, "objects": objs})
+
+
+def adversarial_scene(host, seed):
+    """A few hundred ordinary spheres with records no JSON file can carry patched in through the C structs: NaN / +-inf /
+    1e300 / denormal / zero / negative radii, NaN / inf / 1e308 centres, three coincident spheres, one light."""
+    import json
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    n = 300
+    objs = []
+    for i in range(n):
+        c = rng.uniform(-4, 4, 3)
+        c[1] = rng.uniform(0, 0.6)
+        kind = rng.integers(0, 10)
+        mat = ({"Lambertian": {"albedo": [float(x) for x in rng.uniform(0.1, 0.9, 3)]}} if kind < 6 else
+               {"Metal": {"albedo": [0.8, 0.8, 0.8], "fuzz": float(rng.uniform(0, 0.3))}} if kind < 8 else {"Glass": {"index_of_refraction": 1.5}})
+        if i == 7:
+            mat = {"Light": {}}
+        objs.append({"center": {"x": float(c[0]), "y": float(c[1]), "z": float(c[2])}, "radius": float(rng.uniform(0.05, 0.3)), "material": mat})
+    cfg = {"width": 64, "height": 40, "samples_per_pixel": 2, "max_depth": 6, "sky": {"texture": ""},
+           "camera": {"look_from": {"x": 9.0, "y": 2.0, "z": 3.0}, "look_at": {"x": 0.0, "y": 0.3, "z": 0.0}, "vup": {"x": 0.0, "y": 1.0, "z": 0.0},
+                      "vfov": 35.0, "aspect": 1.6}, "objects": objs}
+    sc = host.Scene.loads(json.dumps(cfg))
+    sp = sc.c.spheres
+    odd = [("radius", float("nan")), ("radius", float("inf")), ("radius", 0.0), ("radius", 1e-310), ("radius", 1e300), ("radius", -0.2),
+           ("radius", 40.0), ("cx", float("nan")), ("cy", float("-inf")), ("cz", 1e308), ("cx", float("inf"))]
+    picks = rng.choice(np.arange(8, n), size=2 * len(odd), replace=False)
+    for k, i in enumerate(picks):
+        what, v = odd[k % len(odd)]
+        if what == "radius":
+            sp[i].radius = v
+        else:
+            sp[i].center["xyz".index(what[1])] = v
+    for j in range(3):   # three coincident spheres (the lowest index wins ties, raytracer.rs:52-57)
+        sp[int(picks[0]) + 1 + j].center[0], sp[int(picks[0]) + 1 + j].center[2] = 0.5, 0.5
+        sp[int(picks[0]) + 1 + j].center[1], sp[int(picks[0]) + 1 + j].radius = 0.3, 0.3
+    return sc

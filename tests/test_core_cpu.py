@@ -54,6 +54,28 @@ def test_core_matches_oracle(name, hostsim, oracle, abi, load_scene):
         assert np.array_equal(rgb, images[0][0]) and np.array_equal(lin, images[0][1])
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_adversarial_sphere_records(hostsim, oracle, abi, host, seed):
+    """NaN / inf / 1e300 / denormal / zero radii and NaN / inf / 1e308 centres among ordinary spheres (records only the C
+    ABI can carry): the lane logic with the grid walk, with brute force, and the oracle agree — same NaN pixels, same
+    bits elsewhere; per segment the walk and the object-order scan pick the same (t, sphere)."""
+    from fuzz_worlds import adversarial_scene
+    sc = adversarial_scene(host, seed)
+    o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+    nan = np.isnan(o_lin)
+    out = []
+    for mode in (3, 0):
+        rgb, lin, st = hostsim.render(sc.ptr, None, mode)
+        assert np.array_equal(np.isnan(lin), nan), mode
+        assert np.abs(np.where(nan, 0.0, lin) - np.where(nan, 0.0, o_lin)).max() <= 1e-6, mode
+        assert np.abs(rgb.astype(int) - o_rgb.astype(int)).max() <= 1
+        assert st["segments"] == o_st["segments"] - o_st["segments_discarded"]
+        out.append((rgb, np.where(nan, 0.0, lin)))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    _, _, st = hostsim.render(sc.ptr, None, 4)
+    assert st["kernel_ms"] == 0.0 and st["grid_steps"] > 0
+
+
 def test_grid_walk_matches_brute_force_per_segment(hostsim, load_scene, host):
     """audit mode 4: for EVERY ray segment of these renders, the grid walk and the reference's
     object-order scan over all spheres (raytracer.rs:52-57) return the same (t, sphere) bits."""

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from fuzz_worlds import fuzz_world_json
+from fuzz_worlds import adversarial_scene, fuzz_world_json
 from conftest import dvec
 from parity import assert_parity, pooled_atol
 
@@ -289,6 +289,27 @@ def test_lit_cover_scene_tables_beside_the_parked_light_state(gpu_render, oracle
     assert st["grid_steps"] > 0 and st["exact_tests"] < 0.05 * st["sphere_tests"]
     # a small lit scene (tables AND parked frames in LDS) is what test_matches_oracle_and_golden[test_*] and
     # test_many_lights_nested_sampling render
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_adversarial_spheres_on_the_gpu(gpu_render, oracle, abi, host, seed):
+    """sphere records no JSON file can carry but the C ABI can: NaN / +-inf / 1e300 / denormal / zero radii, NaN / inf /
+    1e308 centres, coincident spheres — among a few hundred ordinary ones, so the grid is built around them (non-finite
+    records go to the `large` list) and rays leave their surfaces with non-finite or astronomically large coordinates
+    (the walk's fallback).  Grid walk, brute force and the oracle must agree: same NaN pixels, same bits elsewhere.
+    (tools/fuzz/fuzz_tables.cpp runs thousands of such sets through the CPU build of the same code under ASan.)"""
+    sc = adversarial_scene(host, seed)
+    o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+    nan = np.isnan(o_lin)
+    for variant in (0, 1):
+        rgb, lin, st = gpu_render(sc, variant=variant)
+        assert np.array_equal(np.isnan(lin), nan), variant
+        assert np.abs(np.where(nan, 0.0, lin) - np.where(nan, 0.0, o_lin)).max() <= pooled_atol(2), variant
+        assert np.abs(rgb.astype(int) - o_rgb.astype(int)).max() <= 1
+        assert st["segments"] == o_st["segments"] - o_st["segments_discarded"], variant
+    assert st["exact_tests"] == st["sphere_tests"]
+    rgb, lin, st = gpu_render(sc, variant=0)
+    assert st["grid_steps"] > 0
 
 
 def test_procedural_10k_spheres(gpu_render, oracle, abi, host):
