@@ -158,6 +158,13 @@ def test_work_distribution_stress(gpu_render, load_scene):
                 rgb, lin, st = gpu_render(sc, chunk_spp=cs, tile_log2=tl, tile_shape=shape)
                 assert np.array_equal(rgb, ref_rgb) and np.array_equal(lin, ref_lin), (shape, tl, cs)
                 assert st["segments"] == ref_st["segments"] and st["samples"] == 203 * 117 * 5
+    # the lit kernel (parked light frames in LDS beside the tile slots) under the same contention
+    lit = load_scene("test", 101, 67, 6, 8)
+    l_rgb, l_lin, l_st = gpu_render(lit)
+    for shape, tl, cs in ((0, 0, 1), (0, 1, 2), (0, 3, 1), (1, 2, 3), (2, 3, 6), (3, 3, 2)):
+        rgb, lin, st = gpu_render(lit, chunk_spp=cs, tile_log2=tl, tile_shape=shape)
+        assert np.array_equal(rgb, l_rgb) and np.array_equal(lin, l_lin), ("lit", shape, tl, cs)
+        assert st["segments"] == l_st["segments"]
     # a frame whose width is a multiple of 4 takes the dword-packed framebuffer stores (tiles >= 4 pixels wide), others bytes
     for w in (204, 202):
         sc2 = load_scene("cover", w, 31, 3, 50)
