@@ -35,6 +35,7 @@ Extra objects on that line (N = 1):
 """
 import argparse
 import glob
+import re
 import json
 import os
 import sys
@@ -70,7 +71,9 @@ def _latest_pmc():
             continue
         m = j.get("mean_per_launch", {})
         if "SQ_THREAD_CYCLES_VALU" in m and "SQ_ACTIVE_INST_VALU" in m:
-            key = (os.path.basename(p).split("_")[0], os.path.getmtime(p))
+            b = os.path.basename(p)
+            run = re.search(r"run(\d+)", b)
+            key = (b.split("_")[0], int(run.group(1)) if run else -1, os.path.getmtime(p))
             if best is None or key > best[0]:
                 best = (key, p, j)
     return (best[1], best[2]) if best else (None, None)
