@@ -597,16 +597,19 @@ RT_HD uint64_t sat_u64_f32(float x) {  // Rust `f32 as usize`
   return (uint64_t)x;
 }
 // materials.rs:236-254 (out-of-range index: clamp + count; the reference panics)
+RT_HD Rgb texel_fetch(const DevScene& sc, const SphereMat& m, uint64_t col, uint64_t row, uint32_t& tex_oob) {
+  uint64_t base_pixel = 3 * (row * m.tex_w + col);
+  if (m.tex_nbytes < 3) { tex_oob++; return rgb(0.f, 0.f, 0.f); }
+  if (base_pixel > m.tex_nbytes - 3) { tex_oob++; base_pixel = (m.tex_nbytes / 3 - 1) * 3; }
+  const uint8_t* px = sc.tex + m.tex_off + base_pixel;
+  return rgb((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+}
 RT_HD Rgb texture_albedo(const DevScene& sc, const SphereMat& m, double u, double v, uint32_t& tex_oob) {
   double rot = u + m.h_offset;
   if (rot > 1.0) rot = rot - 1.0;
   double uu = rot * (double)m.tex_w;
   double vv = (1.0 - v) * (double)(m.tex_h - 1);
-  uint64_t base_pixel = 3 * (sat_u64(floor(vv)) * m.tex_w + sat_u64(floor(uu)));
-  if (m.tex_nbytes < 3) { tex_oob++; return rgb(0.f, 0.f, 0.f); }
-  if (base_pixel > m.tex_nbytes - 3) { tex_oob++; base_pixel = (m.tex_nbytes / 3 - 1) * 3; }
-  const uint8_t* px = sc.tex + m.tex_off + base_pixel;
-  return rgb((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+  return texel_fetch(sc, m, sat_u64(floor(uu)), sat_u64(floor(vv)), tex_oob);
 }
 
 // ------------------------------------------------------------------ colour: forward form
@@ -711,6 +714,102 @@ RT_HD_COLD UV sphere_uv(V3 point, SphereGeom g) {  // by value: see exact_hit_sl
   r.v = n.y * 0.5 + 0.5;
   return r;
 }
+// ---- the texel of a Texture hit without the exact (u, v) ---------------------------------------------------------
+// sphere_uv + texture_albedo only ever use (u, v) through floor(rot * width) and floor((1 - v) * (height - 1)): three
+// correctly-rounded divisions, a correctly-rounded double-double atan2 and a fourth division (270 instructions) to pick
+// one of a few thousand columns.  texel_fast computes the same two numbers in plain f64 with |error| < 1e-14 (unit
+// vector through one reciprocal square root; atan through two quotients, a five-point table and eight Taylor terms)
+// and reports a texel only when both lie further than TEXEL_EPS x size from the next integer and the wrap test
+// `rot > 1` is further than TEXEL_EPS from deciding differently: then the exact values floor to the same texel.
+// Anything else — a boundary closer than that, a non-finite or negative coordinate, a texture wider than 1e11 pixels —
+// answers false and the caller takes the exact path.  (tests/test_core_cpu.py: 10^7 hit points against the exact path,
+// with the boundary cases aimed at; audited again per Texture hit by hostsim mode 4.)
+RT_HD double rt_nan() { return __builtin_nan(""); }
+constexpr double TEXEL_EPS = 4e-12;  // >> the fast path's error in u and v (< 1e-14), << a texel of any real texture
+RT_HD double rt_fast_quot(double x, double b) {  // x / b to ~1.5 ulp, b normal and positive
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(b);
+  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+  const double q = x * y;
+  return __builtin_fma(__builtin_fma(-q, b, x), y, q);
+#else
+  return x / b;
+#endif
+}
+// (Three small real calls instead of one function: interprocedural register allocation lets the kernel keep its lane
+//  state in whatever registers its callees leave alone; sphere_uv takes 29, and a cold function that needs 52 costs
+//  the path loop 17 spilled registers — 4 % of the whole frame, textures or not.)
+RT_HD UV fast_uv_core(V3 point, const SphereGeom& g) {  // (u, v) of sphere_uv to ~1e-15, or u = NaN: ask the exact path
+  UV out; out.u = rt_nan(); out.v = 0.0;
+  V3 pc = sub(point, v3(g.cx, g.cy, g.cz));
+  const double l2 = length_squared(pc);
+  if (!(l2 > 1e-280 && l2 < 1e280)) return out;
+#if defined(__HIP_DEVICE_COMPILE__)
+  double rs = __builtin_amdgcn_rsq(l2);
+  rs = rs * __builtin_fma(__builtin_fma(-l2 * rs, rs, 1.0), 0.5, 1.0);
+  rs = rs * __builtin_fma(__builtin_fma(-l2 * rs, rs, 1.0), 0.5, 1.0);
+#else
+  const double rs = 1.0 / sqrt(l2);
+#endif
+  const double nx = pc.x * rs, nz = pc.z * rs;
+  out.v = __builtin_fma(pc.y * rs, 0.5, 0.5);
+  // angle = atan2(nx, nz) in [-pi, pi]
+  const double ax = fabs(nx), az = fabs(nz);
+  const double mx = ax > az ? ax : az, mn = ax > az ? az : ax;
+  if (!(mx > 1e-3)) return out;                 // (a unit vector has max(|x|, |z|) > 1e-3 unless it points along y)
+  const double t = rt_fast_quot(mn, mx);          // in [0, 1]
+  const double kf = floor(t * 4.0 + 0.5);         // nearest of c = 0, 1/4, 1/2, 3/4, 1
+  const double c = kf * 0.25;
+  const double atan_c = kf < 0.5 ? 0.0 : (kf < 1.5 ? 0.24497866312686414 : (kf < 2.5 ? 0.4636476090008061 : (kf < 3.5 ? 0.6435011087932844 : 0.7853981633974483)));
+  const double z = rt_fast_quot(t - c, __builtin_fma(t, c, 1.0));  // |z| <= 1/8: atan(t) = atan(c) + atan(z)
+  const double s = z * z;
+  double p = -1.0 / 15.0;
+  p = __builtin_fma(p, s, 1.0 / 13.0);
+  p = __builtin_fma(p, s, -1.0 / 11.0);
+  p = __builtin_fma(p, s, 1.0 / 9.0);
+  p = __builtin_fma(p, s, -1.0 / 7.0);
+  p = __builtin_fma(p, s, 1.0 / 5.0);
+  p = __builtin_fma(p, s, -1.0 / 3.0);
+  double r = atan_c + __builtin_fma(p * s, z, z);  // atan(mn / mx) in [0, pi/4]
+  if (ax > az) r = 1.5707963267948966 - r;         // atan(|nx| / |nz|)
+  if (nz < 0.0) r = 3.141592653589793 - r;
+  if (nx < 0.0) r = -r;
+  out.u = __builtin_fma(r, 0.15915494309189535, 0.5);
+  return out;
+}
+// does (u, v) +- TEXEL_EPS name one texel?  Then (col, row) is what the exact (u, v) floors to as well.
+RT_HD bool texel_sure(double u, double v, double h_offset, uint64_t tex_w, uint64_t tex_h, uint64_t& col, uint64_t& row) {
+  const double wd = (double)tex_w, hd = (double)(tex_h - 1);
+  double rot = u + h_offset;
+  if (!(fabs(rot - 1.0) > TEXEL_EPS)) return false;  // (false for NaN as well: every comparison below is, too)
+  if (rot > 1.0) rot = rot - 1.0;
+  const double uu = rot * wd, vv = (1.0 - v) * hd;
+  const double fu = floor(uu), fv = floor(vv);
+  const double du = uu - fu, dv = vv - fv;
+  const double eu = wd * TEXEL_EPS, ev = hd * TEXEL_EPS;
+  const bool row_sure = (dv > ev && 1.0 - dv > ev) || (hd == 0.0 && vv == 0.0);  // (a one-row texture: vv = (1 - v) * 0)
+  if (!(du > eu && 1.0 - du > eu && row_sure && fu >= 0.0 && fv >= 0.0 && fu < 4.5e15 && fv < 4.5e15)) return false;
+  col = (uint64_t)fu; row = (uint64_t)fv;
+  return true;
+}
+RT_HD bool texel_fast(V3 point, const SphereGeom& g, double h_offset, uint64_t tex_w, uint64_t tex_h, uint64_t& col, uint64_t& row) {
+  const UV a = fast_uv_core(point, g);
+  return texel_sure(a.u, a.v, h_offset, tex_w, tex_h, col, row);
+}
+// (u, v) for texture_albedo: the fast pair when it is sure of its texel (texture_albedo repeats texel_sure's arithmetic
+// on it, bit for bit, and so floors to that texel), else u = NaN: take sphere_uv.
+RT_HD_COLD UV fast_uv(V3 point, SphereGeom g, const SphereMat* mats, uint32_t idx) {
+  UV a = fast_uv_core(point, g);
+  uint64_t col, row;
+  if (!texel_sure(a.u, a.v, mats[idx].h_offset, mats[idx].tex_w, mats[idx].tex_h, col, row)) a.u = rt_nan();
+  return a;
+}
+RT_HD UV sphere_uv_for_texel(V3 point, const SphereGeom& g, const SphereMat* mats, uint32_t idx) {
+  const UV a = fast_uv(point, g, mats, idx);
+  if (a.u == a.u) return a;
+  return sphere_uv(point, g);
+}
 // unit_vector (point3d.rs:67-70) with one real division: 1/l, then div_by_recip per component
 RT_HD V3 unit_vector_fast(V3 a) {
   double l = length(a);
@@ -742,7 +841,7 @@ RT_HD int scatter(const DevScene& sc, const RngAddr& ra, uint32_t node, V3 in_di
       V3 target = add(h.point, sd);
       out_dir = sub(target, h.point);  // (p + d) - p, as the reference computes it
       if (m.kind == RT_MAT_TEXTURE) {
-        const UV uv = sphere_uv(h.point, g);
+        const UV uv = sphere_uv_for_texel(h.point, g, sc.mat, idx);
         Rgb a = texture_albedo(sc, sc.mat[idx], uv.u, uv.v, tex_oob);
         att[0] = a.r; att[1] = a.g; att[2] = a.b;
       }

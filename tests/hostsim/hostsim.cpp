@@ -197,6 +197,24 @@ extern "C" int hostsim_hit_world(const RtScene* scene, const double o[3], const 
 }
 
 // rt_core.h div_by_recip over arrays (property test against the IEEE quotient)
+// texel of a Texture hit: the fast path's answer (ok, col, row) beside the exact path's (materials.rs:236-254 through
+// sphere_uv); n points, 3 doubles each; out: 5 x u64 per point {fast_ok, fast col, fast row, exact col, exact row}
+extern "C" void hostsim_texels(const double* points, uint64_t n, const double centre_radius[4], double h_offset, uint64_t tex_w,
+                               uint64_t tex_h, uint64_t* out) {
+  const SphereGeom g{centre_radius[0], centre_radius[1], centre_radius[2], centre_radius[3]};
+#pragma omp parallel for
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    const V3 p = v3(points[3 * i], points[3 * i + 1], points[3 * i + 2]);
+    uint64_t col = 0, row = 0;
+    const bool ok = texel_fast(p, g, h_offset, tex_w, tex_h, col, row);
+    const UV uv = sphere_uv(p, g);
+    double rot = uv.u + h_offset;
+    if (rot > 1.0) rot = rot - 1.0;
+    out[5 * i] = ok; out[5 * i + 1] = col; out[5 * i + 2] = row;
+    out[5 * i + 3] = sat_u64(floor(rot * (double)tex_w)); out[5 * i + 4] = sat_u64(floor((1.0 - uv.v) * (double)(tex_h - 1)));
+  }
+}
+
 extern "C" void hostsim_div_by_recip(const double* x, const double* b, double* out, uint64_t n) {
 #pragma omp parallel for
   for (int64_t i = 0; i < (int64_t)n; ++i) out[i] = div_by_recip(x[i], b[i], 1.0 / b[i]);
