@@ -799,15 +799,10 @@ RT_HD bool texel_fast(V3 point, const SphereGeom& g, double h_offset, uint64_t t
 }
 // (u, v) for texture_albedo: the fast pair when it is sure of its texel (texture_albedo repeats texel_sure's arithmetic
 // on it, bit for bit, and so floors to that texel), else u = NaN: take sphere_uv.
-RT_HD_COLD UV fast_uv(V3 point, SphereGeom g, const SphereMat* mats, uint32_t idx) {
-  UV a = fast_uv_core(point, g);
+RT_HD_COLD UV sphere_uv_for_texel(V3 point, SphereGeom g, const SphereMat* mats, uint32_t idx) {
+  const UV a = fast_uv_core(point, g);
   uint64_t col, row;
-  if (!texel_sure(a.u, a.v, mats[idx].h_offset, mats[idx].tex_w, mats[idx].tex_h, col, row)) a.u = rt_nan();
-  return a;
-}
-RT_HD UV sphere_uv_for_texel(V3 point, const SphereGeom& g, const SphereMat* mats, uint32_t idx) {
-  const UV a = fast_uv(point, g, mats, idx);
-  if (a.u == a.u) return a;
+  if (texel_sure(a.u, a.v, mats[idx].h_offset, mats[idx].tex_w, mats[idx].tex_h, col, row)) return a;
   return sphere_uv(point, g);
 }
 // unit_vector (point3d.rs:67-70) with one real division: 1/l, then div_by_recip per component
