@@ -256,7 +256,9 @@ int rt_hip_hit_probe(const double* rays, const double* spheres, double* out_t, u
  * "chunk_spp" samples of a pixel per work item (0 = automatic); "tile_log2" pixel tiles of
  * 4^k pixels (k = 0..3, -1 = automatic); "tile_shape" 0 (default) = a 2^k x 2^k square, 1 = a run of 4^k pixels of one
  * scanline (one contiguous piece of the framebuffer: half the HBM write traffic, 0.9 % slower), 2 and 3 = the square widened
- * once and twice (16x4 and 32x2 at k = 3); "samples_per_pixel", "max_depth" (0 .. 2^32-1) and
+ * once and twice (16x4 and 32x2 at k = 3); "tile_affinity" 1 (default) = on large frames, runs of 512 pixels of a
+ * tile row are handed out by the XCD they belong to first (a framebuffer line then fills up in ONE L2 before it is written
+ * back: half the HBM traffic, +0.5 % time), 0 = one queue; "samples_per_pixel", "max_depth" (0 .. 2^32-1) and
  * "seed" override the scene's values; "tile_order" 0 = tiles leave the queue top row first, 1 = bottom row
  * first, 2 (default) = the tiles whose paths ran deepest in this scene's previous frame first (the frame ends on
  * its deepest paths; the image does not depend on the order).  Out-of-range values are RT_ERR_INVALID. */

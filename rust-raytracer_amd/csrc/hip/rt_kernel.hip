@@ -49,7 +49,18 @@ struct KArgs {
   const uint32_t* tile_order;
   uint32_t* tile_depth;
   uint32_t order_mode;  // 0: top row first (the round-1 order), 1: reversed / tile_order
+  // XCD affinity of the queue (aff_group_log2 != 0xFFFFFFFF).  Each XCD has its own L2, and a framebuffer line (128 B
+  // = ten 4-pixel tile rows) written piecemeal by workgroups of different XCDs goes to HBM as partial sectors from every
+  // one of them: 3.6 x the framebuffer's bytes.  So runs of 2^aff_group_log2 consecutive tiles (1.5 KB of a scanline)
+  // belong to XCD (run mod 8): a workgroup takes tiles from the queue of the XCD it runs on (queue[x], xcd_cnt[x] tiles;
+  // position j of it = tile_order[xcd_off[x] + j], or the j-th tile of XCD x by arithmetic) and from the other seven only
+  // when its own is empty.  The lines of a run then collect all their bytes in one L2 before they are written back.
+  uint32_t aff_group_log2;
+  uint32_t xcd_cnt[8], xcd_off[8];
 };
+// tiles of XCD x in image order: the j-th one (aff_group_log2 = gl)
+__host__ __device__ inline uint32_t xcd_tile(uint32_t x, uint32_t j, uint32_t gl) { return ((((j >> gl) << 3) + x) << gl) + (j & ((1u << gl) - 1u)); }
+__host__ __device__ inline uint32_t tile_xcd(uint32_t tile, uint32_t gl) { return (tile >> gl) & 7u; }
 
 #ifndef RT_BLOCK
 #define RT_BLOCK 1024
@@ -255,7 +266,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     h.nan_mask[0] = h.nan_mask[1] = h.nan_mask[2] = 0ull;
     hdr[i] = h;
   }
-  if (threadIdx.x == 0) { wg_flags[0] = 0u; wg_flags[1] = 0u; wg_flags[2] = 0u; }
+  if (threadIdx.x == 0) { wg_flags[0] = 0u; wg_flags[1] = 0u; wg_flags[2] = 0u; wg_flags[3] = 0u; }
+  // the XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0; MI355X_MICROARCH.md): affinity only, never correctness
+  const uint32_t my_xcd = (uint32_t)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;
   unsigned long long* const wg_counters = reinterpret_cast<unsigned long long*>(lds_raw + 32);
   if (threadIdx.x < 32u) wg_counters[threadIdx.x] = 0ull;
   if constexpr (!LDS_TABLES) __syncthreads();
@@ -413,8 +426,23 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       if (!bcast(ok)) continue;  // another wave claimed it: rescan
       uint32_t tile = 0;
       if (lane == 0) {
-        tile = atomicAdd(ka.queue, 1u);
-        if (tile < ka.n_tiles && ka.order_mode != 0u) tile = ka.tile_order ? ka.tile_order[tile] : ka.n_tiles - 1u - tile;
+        if (ka.aff_group_log2 == 0xFFFFFFFFu) {
+          tile = atomicAdd(ka.queue, 1u);
+          if (tile < ka.n_tiles && ka.order_mode != 0u) tile = ka.tile_order ? ka.tile_order[tile] : ka.n_tiles - 1u - tile;
+        } else {  // this XCD's queue first, then the others'
+          tile = ka.n_tiles;
+          uint32_t dry = lds_load(&wg_flags[3]);  // queues this workgroup has seen empty
+          for (uint32_t q = 0; q < 8u && tile == ka.n_tiles; ++q) {
+            const uint32_t x = (my_xcd + q) & 7u;
+            if ((dry >> x) & 1u) continue;
+            const uint32_t cnt = ka.xcd_cnt[x];
+            uint32_t j = atomicAdd(&ka.queue[x], 1u);
+            if (j >= cnt) { dry |= 1u << x; continue; }
+            if (ka.tile_order) tile = ka.tile_order[ka.xcd_off[x] + j];
+            else tile = xcd_tile(x, ka.order_mode != 0u ? cnt - 1u - j : j, ka.aff_group_log2);
+          }
+          __hip_atomic_fetch_or(&wg_flags[3], dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
       tile = bcast(tile);
       if (tile >= ka.n_tiles) {  // the frame's queue is empty
@@ -837,32 +865,40 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 // histograms and scatter cursors are private to each wave so that the bulk bucket — tiles without a deep path — does not
 // serialise the whole workgroup on one LDS word).  Inside a bucket: bottom of the image first, up to the interleaving of
 // the 16 waves.  Stream-ordered behind the frame that measured the depths.
-__global__ __launch_bounds__(1024) void rt_order_tiles(const uint32_t* __restrict__ tile_depth, uint32_t* __restrict__ tile_order, uint32_t n_tiles) {
-  __shared__ uint32_t hist[16][64], start[16][64], total[64];
+__global__ __launch_bounds__(1024) void rt_order_tiles(const uint32_t* __restrict__ tile_depth, uint32_t* __restrict__ tile_order, uint32_t n_tiles,
+                                                       uint32_t aff_group_log2) {
+  // key = depth bucket (64 of them), or with XCD affinity (XCD of the tile, 32 depth buckets): the XCDs' segments one
+  // after the other (they start at KArgs.xcd_off: both are the per-XCD tile counts), deepest first inside each
+  __shared__ uint32_t hist[16][256], start[16][256], total[256];
   const uint32_t w = threadIdx.x >> 6;
-  for (uint32_t i = threadIdx.x; i < 16u * 64u; i += blockDim.x) (&hist[0][0])[i] = 0u;
+  const bool aff = aff_group_log2 != 0xFFFFFFFFu;
+  auto key_of = [&](uint32_t tile, uint32_t depth) -> uint32_t {
+    if (!aff) return 63u - (depth < 63u ? depth : 63u);                                  // ascending key = descending depth
+    return (tile_xcd(tile, aff_group_log2) << 5) | (31u - (depth < 31u ? depth : 31u));
+  };
+  for (uint32_t i = threadIdx.x; i < 16u * 256u; i += blockDim.x) (&hist[0][0])[i] = 0u;
   __syncthreads();
   for (uint32_t j = threadIdx.x; j < n_tiles; j += blockDim.x) {
-    const uint32_t t = tile_depth[n_tiles - 1u - j];
-    atomicAdd(&hist[w][t < 63u ? t : 63u], 1u);
+    const uint32_t i = n_tiles - 1u - j;
+    atomicAdd(&hist[w][key_of(i, tile_depth[i])], 1u);
   }
   __syncthreads();
-  if (threadIdx.x < 64u) {
+  if (threadIdx.x < 256u) {
     uint32_t o = 0;
     for (uint32_t k = 0; k < 16u; ++k) o += hist[k][threadIdx.x];
     total[threadIdx.x] = o;
   }
   __syncthreads();
-  if (threadIdx.x < 64u) {  // bucket d starts after all deeper buckets; inside it wave 0's tiles, then wave 1's, ...
+  if (threadIdx.x < 256u) {  // key d starts after all smaller keys; inside it wave 0's tiles, then wave 1's, ...
     const uint32_t d = threadIdx.x;
     uint32_t o = 0;
-    for (uint32_t e = 63u; e > d; --e) o += total[e];
+    for (uint32_t e = 0; e < d; ++e) o += total[e];
     for (uint32_t k = 0; k < 16u; ++k) { start[k][d] = o; o += hist[k][d]; }
   }
   __syncthreads();
   for (uint32_t j = threadIdx.x; j < n_tiles; j += blockDim.x) {
-    const uint32_t i = n_tiles - 1u - j, t = tile_depth[i];
-    tile_order[atomicAdd(&start[w][t < 63u ? t : 63u], 1u)] = i;
+    const uint32_t i = n_tiles - 1u - j;
+    tile_order[atomicAdd(&start[w][key_of(i, tile_depth[i])], 1u)] = i;
   }
 }
 

@@ -39,7 +39,8 @@ def torch_cuda():
 def gpu_render(pkg, abi, torch_cuda):
     torch = torch_cuda
 
-    def _render(scene, tiles=None, variant=0, want_linear=True, pool=None, chunk_spp=None, tile_log2=None, tile_order=None, frames=1, tile_shape=None):
+    def _render(scene, tiles=None, variant=0, want_linear=True, pool=None, chunk_spp=None, tile_log2=None, tile_order=None, frames=1, tile_shape=None,
+                tile_affinity=None):
         """variant 0: the product kernel (grid walk, tile queue, exact fixed-point pixel sums);
         variant 1: same kernel, the reference's brute force over all spheres.  chunk_spp: samples of a
         pixel per work item; tile_log2: pixel tiles of 2^k x 2^k."""
@@ -58,6 +59,8 @@ def gpu_render(pkg, abi, torch_cuda):
             gs.set_option("tile_order", tile_order)
         if tile_shape is not None:
             gs.set_option("tile_shape", tile_shape)
+        if tile_affinity is not None:
+            gs.set_option("tile_affinity", tile_affinity)
         rgb = torch.zeros((rows, sc.width, 3), dtype=torch.uint8, device="cuda:0")
         lin = torch.zeros((rows, sc.width, 3), dtype=torch.float32, device="cuda:0") if want_linear else None
         for _ in range(frames):   # (frames > 1: the later frames use the queue order learnt from the one before)
@@ -453,6 +456,11 @@ def test_full_size_headline_config_properties(gpu_render, oracle, abi, load_scen
     assert 2.0 < st["segments"] / st["samples"] < 3.5  # SURVEY §8d measured ~2.66
     rgb2, lin2, st2 = gpu_render(sc)
     assert np.array_equal(rgb, rgb2) and np.array_equal(lin, lin2) and st2["segments"] == st["segments"]
+    # the per-XCD tile queues (on by default at this size; three frames: the depth-sorted per-XCD order kicks in) and
+    # the single queue hand out the same frame, whatever the tile size
+    for aff, tl, frames in ((0, None, 1), (1, None, 3), (1, 3, 3), (1, 1, 1), (0, 3, 1)):
+        a_rgb, a_lin, a_st = gpu_render(sc, tile_affinity=aff, tile_log2=tl, frames=frames)
+        assert np.array_equal(a_rgb, rgb) and np.array_equal(a_lin, lin) and a_st["segments"] == st["segments"], (aff, tl)
     # shard invariance: rank 3 of 8 renders exactly its scanlines of the full frame
     t = abi.RtRowTiles(8, 3, 8)
     rows = abi.tiles_global_rows(800, t)
