@@ -96,7 +96,8 @@ def adversarial_scene(host, seed):
             sp[i].radius = v
         else:
             sp[i].center["xyz".index(what[1])] = v
+    base = min(int(picks[0]), n - 4)   # (the spheres array is a raw C pointer: stay inside it)
     for j in range(3):   # three coincident spheres (the lowest index wins ties, raytracer.rs:52-57)
-        sp[int(picks[0]) + 1 + j].center[0], sp[int(picks[0]) + 1 + j].center[2] = 0.5, 0.5
-        sp[int(picks[0]) + 1 + j].center[1], sp[int(picks[0]) + 1 + j].radius = 0.3, 0.3
+        sp[base + 1 + j].center[0], sp[base + 1 + j].center[2] = 0.5, 0.5
+        sp[base + 1 + j].center[1], sp[base + 1 + j].radius = 0.3, 0.3
     return sc
