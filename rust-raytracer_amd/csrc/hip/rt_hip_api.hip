@@ -371,7 +371,8 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   ka.aff_group_log2 = 0xFFFFFFFFu;
   for (int x = 0; x < 8; ++x) { ka.xcd_cnt[x] = 0; ka.xcd_off[x] = 0; }
   {
-    const uint32_t gl = ka.tile_wl >= 9u ? 0u : 9u - ka.tile_wl;
+    static const uint32_t run_px_log2 = [] { const char* e = std::getenv("RT_AFF_RUN_LOG2"); const int v = e ? std::atoi(e) : 9; return (uint32_t)(v < 3 ? 3 : (v > 14 ? 14 : v)); }();  // (development knob)
+    const uint32_t gl = ka.tile_wl >= run_px_log2 ? 0u : run_px_log2 - ka.tile_wl;
     const uint32_t n_groups = (ka.n_tiles + (1u << gl) - 1u) >> gl;
     if (s->tile_affinity && n_groups >= 256u) {
       ka.aff_group_log2 = gl;
