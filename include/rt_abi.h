@@ -258,7 +258,7 @@ int rt_hip_hit_probe(const double* rays, const double* spheres, double* out_t, u
  * scanline (one contiguous piece of the framebuffer: half the HBM write traffic, 0.9 % slower), 2 and 3 = the square widened
  * once and twice (16x4 and 32x2 at k = 3); "tile_affinity" 1 (default) = on large frames, runs of 512 pixels of a
  * tile row are handed out by the XCD they belong to first (a framebuffer line then fills up in ONE L2 before it is written
- * back: half the HBM traffic, +0.5 % time), 0 = one queue; "samples_per_pixel", "max_depth" (0 .. 2^32-1) and
+ * back: half the HBM traffic, +0.5 % time), 0 = one queue, 2 = per-XCD queues on any frame of 8 or more runs (tests); "samples_per_pixel", "max_depth" (0 .. 2^32-1) and
  * "seed" override the scene's values; "tile_order" 0 = tiles leave the queue top row first, 1 = bottom row
  * first, 2 (default) = the tiles whose paths ran deepest in this scene's previous frame first (the frame ends on
  * its deepest paths; the image does not depend on the order).  Out-of-range values are RT_ERR_INVALID. */

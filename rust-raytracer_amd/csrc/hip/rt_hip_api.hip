@@ -203,7 +203,7 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
   if (!std::strcmp(key, "pool")) { s->pool = value != 0; return RT_OK; }
   if (!std::strcmp(key, "tile_log2")) { if (value < -1 || value > 3) return fail(RT_ERR_INVALID, "tile_log2 must be -1..3"); s->tile_log2 = (int)value; return RT_OK; }
   if (!std::strcmp(key, "tile_shape")) { if (value < 0 || value > 3) return fail(RT_ERR_INVALID, "tile_shape must be 0 (square), 1 (scanline runs), 2 (4:1) or 3 (16:1)"); s->tile_shape = (int)value; return RT_OK; }
-  if (!std::strcmp(key, "tile_affinity")) { if (value < 0 || value > 1) return fail(RT_ERR_INVALID, "tile_affinity must be 0 or 1"); s->tile_affinity = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
+  if (!std::strcmp(key, "tile_affinity")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_affinity must be 0 (off), 1 (large frames) or 2 (any frame of 8+ runs: tests)"); s->tile_affinity = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
   if (!std::strcmp(key, "tile_order")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_order must be 0, 1 or 2"); s->order_mode = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
   if (!std::strcmp(key, "chunk_spp")) { if (value < 0) return fail(RT_ERR_INVALID, "chunk_spp must be >= 0"); s->chunk_spp = (int)value; return RT_OK; }
   if (!std::strcmp(key, "samples_per_pixel") || !std::strcmp(key, "max_depth")) {
@@ -374,7 +374,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
     static const uint32_t run_px_log2 = [] { const char* e = std::getenv("RT_AFF_RUN_LOG2"); const int v = e ? std::atoi(e) : 9; return (uint32_t)(v < 3 ? 3 : (v > 14 ? 14 : v)); }();  // (development knob)
     const uint32_t gl = ka.tile_wl >= run_px_log2 ? 0u : run_px_log2 - ka.tile_wl;
     const uint32_t n_groups = (ka.n_tiles + (1u << gl) - 1u) >> gl;
-    if (s->tile_affinity && n_groups >= 256u) {
+    if ((s->tile_affinity == 1 && n_groups >= 256u) || (s->tile_affinity == 2 && n_groups >= 8u)) {
       ka.aff_group_log2 = gl;
       for (uint32_t g = 0; g < 8u && g < n_groups; ++g) {  // groups g, g + 8, ...: all full but possibly the frame's last
         const uint32_t mine = (n_groups - 1u - g) / 8u + 1u;

@@ -161,6 +161,11 @@ def test_work_distribution_stress(gpu_render, load_scene):
                 rgb, lin, st = gpu_render(sc, chunk_spp=cs, tile_log2=tl, tile_shape=shape)
                 assert np.array_equal(rgb, ref_rgb) and np.array_equal(lin, ref_lin), (shape, tl, cs)
                 assert st["segments"] == ref_st["segments"] and st["samples"] == 203 * 117 * 5
+    # per-XCD queues forced on for this small, ragged frame (tile_affinity = 2): partial last run, one-pixel tiles, every
+    # queue order, stealing from the first tile on — same frame
+    for tl, cs, order in ((0, 1, 2), (0, 5, 1), (1, 1, 0), (2, 2, 2), (3, 1, 2), (3, 5, 0)):
+        rgb, lin, st = gpu_render(sc, chunk_spp=cs, tile_log2=tl, tile_order=order, tile_affinity=2, frames=3 if order == 2 else 1)
+        assert np.array_equal(rgb, ref_rgb) and np.array_equal(lin, ref_lin) and st["segments"] == ref_st["segments"], ("affinity", tl, cs, order)
     # the lit kernel (parked light frames in LDS beside the tile slots) under the same contention
     lit = load_scene("test", 101, 67, 6, 8)
     l_rgb, l_lin, l_st = gpu_render(lit)
