@@ -138,7 +138,8 @@ typedef struct RtStats {
   uint64_t segments_discarded;
   uint32_t n_gpus_used; /* rt_render_rgb8: devices the frame was sharded over (1 elsewhere) */
   uint32_t reserved0;
-  double gather_ms; /* rt_render_rgb8, n_gpus_used > 1: end of the slowest rank's kernel -> frame assembled on device 0 */
+  double gather_ms; /* n_gpus_used > 1: end of RANK 0's kernel -> frame in scanline order on device 0 (events of one device only:
+                     * includes waiting for slower ranks, the gather and the de-interleave) */
   double setup_ms;  /* rt_render_rgb8: HIP context + table build + scene upload, NOT part of frame_ms
                      * (frame_ms is the window the reference times, raytracer.rs:259-263: the parallel loop
                      * until the pixels are in the caller's buffer) */
@@ -228,8 +229,9 @@ void rt_hip_scene_destroy(RtHipScene*);
  * Limits (all return RT_ERR_* instead of misbehaving):
  *   - NOT re-entrant per scene: an RtHipScene owns ONE tile-queue cursor, counter block and event pair.
  *     Launches of one scene must be ordered on ONE stream at a time (back-to-back launches on the same
- *     stream are fine; rt_hip_wait then reports the last one).  Launching on a second stream before
- *     rt_hip_wait() returned for the first is RT_ERR_INVALID.  Use one RtHipScene per concurrent stream
+ *     stream are fine; rt_hip_wait then reports the last one).  Launching on a second stream while the
+ *     first stream still holds unfinished work of this scene is RT_ERR_INVALID (finished = rt_hip_wait()
+ *     returned, or the caller drained that stream itself: hipStreamQuery says so).  Use one RtHipScene per concurrent stream
  *     (tables are ~100 KB + textures); distinct scenes and distinct devices are fully independent.
  *   - frames wider than 524 280 pixels or with more than 2^31 pixel tiles are RT_ERR_UNSUPPORTED.
  *   - any sphere count is accepted; above 65 535 spheres the uniform grid (u16 item lists) is not
@@ -251,6 +253,14 @@ int rt_hip_debug_timeline(RtHipScene*, uint64_t* out, uint32_t max_waves);
 int rt_hip_math_probe(const double* x, const double* y, double* out_sqrt, double* out_div, float* out_sqrtf, double* out_atan2,
                       uint32_t n, void* stream);
 int rt_hip_hit_probe(const double* rays, const double* spheres, double* out_t, uint32_t n, void* stream);
+/* The texel of a Texture hit on the device, both ways (materials.rs:236-254 through sphere.rs:35-43): the kernel's fast
+ * (u, v) — v_rsq_f64 / v_rcp_f64 + Newton steps, which only the device build takes — beside the exact path, for n hit
+ * points (device, 3 doubles each) on the sphere centre_radius (host, 4 doubles).  d_out = n x {fast_ok, fast col, fast
+ * row, exact col, exact row} (u64); d_uv (optional) = n x {fast u, fast v, exact u, exact v}, fast u = NaN where the fast
+ * path declined.  rt_hip_quot_probe: rt_fast_quot(x, y) and rt_fast_rsqrt(x) of n positive normal operands. */
+int rt_hip_texel_probe(const double* d_points, const double centre_radius[4], double h_offset, uint64_t tex_w, uint64_t tex_h,
+                       uint64_t* d_out, double* d_uv, uint32_t n, void* stream);
+int rt_hip_quot_probe(const double* d_x, const double* d_y, double* d_quot, double* d_rsqrt, uint32_t n, void* stream);
 /* Tunables / A-B arms.  Keys: "variant" 0 = grid walk (default), 1 = the
  * reference's brute force (exact test on every sphere);
  * "chunk_spp" samples of a pixel per work item (0 = automatic); "tile_log2" pixel tiles of
@@ -276,7 +286,26 @@ int rt_hip_render_to_host(RtHipScene*, uint8_t* out_rgb8, RtStats* stats);
  * a kernel puts the scanlines in order, ONE device-to-host copy delivers them.  Bit-identical for every G.
  * stats: counters summed over ranks, kernel_ms = slowest rank, frame_ms = the whole call, gather_ms. */
 typedef struct RtHipGroup RtHipGroup;
+/* What a group actually runs on (rt_hip_group_info): bench.py echoes it next to its numbers. */
+#define RT_GROUP_INFO_MAX_RANKS 64u
+enum { RT_GATHER_NONE = 0, RT_GATHER_RCCL = 1, RT_GATHER_PEER = 2 };
+typedef struct RtGroupInfo {
+  uint32_t n_ranks;    /* G */
+  uint32_t n_devices;  /* distinct HIP device ordinals among the ranks (== n_ranks unless RT_GPUS_EMULATE=1) */
+  uint32_t transport;  /* RT_GATHER_*: how the packed tiles reach the first device (NONE: one rank, nothing to gather) */
+  uint32_t rccl_comms; /* RCCL communicators created by ncclCommInitAll (n_ranks with RT_GATHER_RCCL, else 0) */
+  uint32_t tile_rows;  /* scanlines per interleaved tile (2) */
+  uint32_t pad_rows;   /* rows of one rank's slice of the gather buffer */
+  uint32_t emulated;   /* 1: ranks share devices (RT_GPUS_EMULATE=1, tests) */
+  uint32_t reserved;
+  int32_t device[RT_GROUP_INFO_MAX_RANKS]; /* device ordinal of rank r; -1 beyond n_ranks */
+} RtGroupInfo;
 int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipGroup** out);
+int rt_hip_group_info(const RtHipGroup*, RtGroupInfo* info);
+/* the same frame, left in HBM: scanline order, RGB8, on the group's first device (rt_hip_group_frame returns the device
+ * pointer, valid until the group is destroyed, and that device's ordinal) — no device-to-host copy.  Blocking. */
+int rt_hip_group_render(RtHipGroup*, RtStats* stats);
+const void* rt_hip_group_frame(const RtHipGroup*, int* device_out);
 void rt_hip_group_destroy(RtHipGroup*);
 uint32_t rt_hip_group_size(const RtHipGroup*);
 int rt_hip_group_set_camera(RtHipGroup*, const double origin[3], const double lower_left[3], const double horizontal[3],

@@ -47,6 +47,16 @@ class RtStats(C.Structure):
         return {k: (list(getattr(self, k)) if k in ("wave_iters", "prof_cycles") else getattr(self, k)) for k, _ in self._fields_}
 
 
+RT_GROUP_INFO_MAX_RANKS = 64
+RT_GATHER_NONE, RT_GATHER_RCCL, RT_GATHER_PEER = range(3)
+
+
+class RtGroupInfo(C.Structure):
+    _fields_ = [("n_ranks", C.c_uint32), ("n_devices", C.c_uint32), ("transport", C.c_uint32), ("rccl_comms", C.c_uint32),
+                ("tile_rows", C.c_uint32), ("pad_rows", C.c_uint32), ("emulated", C.c_uint32), ("reserved", C.c_uint32),
+                ("device", C.c_int32 * RT_GROUP_INFO_MAX_RANKS)]
+
+
 def tiles_local_rows(height, tiles):
     """rt_tiles_local_rows() of the header."""
     if tiles is None or tiles.tile_rows == 0 or tiles.tile_stride == 0:

@@ -737,6 +737,19 @@ RT_HD double rt_fast_quot(double x, double b) {  // x / b to ~1.5 ulp, b normal 
   return x / b;
 #endif
 }
+// 1 / sqrt(x) to a few ulp, x normal and positive (v_rsq_f64 + two Newton steps on the device; the device sequences of
+// this and of rt_fast_quot are probed ON THE GPU by rt_hip_texel_probe / tests/test_gpu_parity.py: the CPU build
+// takes the library's operations instead, so CPU tests of texel_fast do not exercise them)
+RT_HD double rt_fast_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double rs = __builtin_amdgcn_rsq(x);
+  rs = rs * __builtin_fma(__builtin_fma(-x * rs, rs, 1.0), 0.5, 1.0);
+  rs = rs * __builtin_fma(__builtin_fma(-x * rs, rs, 1.0), 0.5, 1.0);
+  return rs;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
 // (Three small real calls instead of one function: interprocedural register allocation lets the kernel keep its lane
 //  state in whatever registers its callees leave alone; sphere_uv takes 29, and a cold function that needs 52 costs
 //  the path loop 17 spilled registers — 4 % of the whole frame, textures or not.)
@@ -745,13 +758,7 @@ RT_HD UV fast_uv_core(V3 point, const SphereGeom& g) {  // (u, v) of sphere_uv t
   V3 pc = sub(point, v3(g.cx, g.cy, g.cz));
   const double l2 = length_squared(pc);
   if (!(l2 > 1e-280 && l2 < 1e280)) return out;
-#if defined(__HIP_DEVICE_COMPILE__)
-  double rs = __builtin_amdgcn_rsq(l2);
-  rs = rs * __builtin_fma(__builtin_fma(-l2 * rs, rs, 1.0), 0.5, 1.0);
-  rs = rs * __builtin_fma(__builtin_fma(-l2 * rs, rs, 1.0), 0.5, 1.0);
-#else
-  const double rs = 1.0 / sqrt(l2);
-#endif
+  const double rs = rt_fast_rsqrt(l2);
   const double nx = pc.x * rs, nz = pc.z * rs;
   out.v = __builtin_fma(pc.y * rs, 0.5, 0.5);
   // angle = atan2(nx, nz) in [-pi, pi]

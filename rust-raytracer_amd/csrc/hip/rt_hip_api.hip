@@ -13,7 +13,7 @@
 
 #include "rt_kernel.hip"
 #ifdef RT_WITH_SCAN_KERNEL  // A/B builds only (tools/ab_bench.py): the round-1 cull-scan kernel as "variant" 2
-#include "rt_kernel_scan.hip"
+#include "../../../tools/legacy/rt_kernel_scan.hip"
 #endif
 #include "rt_tables.h"
 
@@ -50,7 +50,13 @@ struct RtHipScene {
   void* d_frame = nullptr; size_t frame_bytes = 0;           // framebuffer of rt_hip_render_to_host
   // queue order feedback (rt_kernel.hip KArgs::tile_order): depths measured by the last frame of this tile geometry
   uint32_t* d_tile_depth = nullptr; uint32_t* d_tile_order = nullptr; size_t order_cap = 0;
-  uint64_t order_key = 0;   // geometry (+ row tiles) the order buffers belong to; 0 = none yet
+  struct OrderKey {         // tile geometry (+ row tiles) an order belongs to: compared field by field
+    uint32_t n_tiles = 0, tile_log2 = 0, tile_shape = 0, aff_group_log2 = 0, tile_rows = 0, first_tile = 0, tile_stride = 0, local_rows = 0;
+    bool operator==(const OrderKey& o) const {
+      return n_tiles == o.n_tiles && tile_log2 == o.tile_log2 && tile_shape == o.tile_shape && aff_group_log2 == o.aff_group_log2 &&
+             tile_rows == o.tile_rows && first_tile == o.first_tile && tile_stride == o.tile_stride && local_rows == o.local_rows;
+    }
+  } order_key;              // n_tiles == 0: none yet
   bool order_ready = false; // d_tile_order holds an order for order_key
   int order_age = 0;        // frames since the order was last invalidated (geometry / camera / option change)
   int tile_affinity = 1;    // "tile_affinity" option: runs of tiles belong to one XCD's queue (framebuffer lines complete in one L2)
@@ -67,7 +73,6 @@ struct RtHipScene {
   uint32_t last_rows = 0;
   uint64_t last_waves = 0;
   int variant = 0;
-  int pool = 1;            // 1: pooled samples + exact fixed-point pixel sums; 0: reference f32 order
   std::chrono::steady_clock::time_point t_launch;
 };
 
@@ -81,6 +86,7 @@ extern "C" size_t rt_abi_sizeof(const char* name) {
   if (!std::strcmp(name, "RtScene")) return sizeof(RtScene);
   if (!std::strcmp(name, "RtRowTiles")) return sizeof(RtRowTiles);
   if (!std::strcmp(name, "RtStats")) return sizeof(RtStats);
+  if (!std::strcmp(name, "RtGroupInfo")) return sizeof(RtGroupInfo);
   return 0;
 }
 
@@ -200,7 +206,6 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
   constexpr int64_t max_variant = 1;
 #endif
   if (!std::strcmp(key, "variant")) { if (value < 0 || value > max_variant) return fail(RT_ERR_INVALID, "variant must be 0 (grid walk) or 1 (brute force)"); s->variant = (int)value; return RT_OK; }
-  if (!std::strcmp(key, "pool")) { s->pool = value != 0; return RT_OK; }
   if (!std::strcmp(key, "tile_log2")) { if (value < -1 || value > 3) return fail(RT_ERR_INVALID, "tile_log2 must be -1..3"); s->tile_log2 = (int)value; return RT_OK; }
   if (!std::strcmp(key, "tile_shape")) { if (value < 0 || value > 3) return fail(RT_ERR_INVALID, "tile_shape must be 0 (square), 1 (scanline runs), 2 (4:1) or 3 (16:1)"); s->tile_shape = (int)value; return RT_OK; }
   if (!std::strcmp(key, "tile_affinity")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_affinity must be 0 (off), 1 (large frames) or 2 (any frame of 8+ runs: tests)"); s->tile_affinity = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
@@ -233,7 +238,7 @@ int launch_scan(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb8, void* d_li
   const bool geom_lds = s->host.n_spheres <= rtk_scan::LDS_GEOM_MAX_SPHERES;
   const size_t lds_bytes = rtk_scan::LDS_GEOM_OFF + (geom_lds ? (size_t)s->host.n_spheres * sizeof(rtc::SphereGeom) : 0);
 #define RT_LAUNCH(HL, G, P) hipLaunchKernelGGL((rtk_scan::rt_megakernel<HL, 0, G, P>), grid, block, lds_bytes, stream, ka)
-#define RT_LAUNCH_P(HL, G) do { if (s->pool) RT_LAUNCH(HL, G, true); else RT_LAUNCH(HL, G, false); } while (0)
+#define RT_LAUNCH_P(HL, G) RT_LAUNCH(HL, G, true)
   if (s->has_lights) { if (geom_lds) RT_LAUNCH_P(true, true); else RT_LAUNCH_P(true, false); }
   else { if (geom_lds) RT_LAUNCH_P(false, true); else RT_LAUNCH_P(false, false); }
 #undef RT_LAUNCH_P
@@ -271,6 +276,9 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   if (!d_rgb8 && local_rows != 0) return fail(RT_ERR_INVALID, "null framebuffer");
   hipStream_t stream = (hipStream_t)stream_;
   // one tile-queue cursor / counter block / event pair per scene: launches of a scene are ordered on ONE stream
+  // (a caller that drained the first stream itself — hipStreamSynchronize, an event — need not call rt_hip_wait first)
+  if (s->in_flight && stream != s->last_stream && hipStreamQuery(s->last_stream) == hipSuccess) s->in_flight = false;
+  (void)hipGetLastError();  // (hipErrorNotReady of the query is not an error of this call)
   if (s->in_flight && stream != s->last_stream)
     return fail(RT_ERR_INVALID, "rt_hip_render: this scene has a launch in flight on another stream (call rt_hip_wait first, "
                                 "or use one RtHipScene per concurrent stream)");
@@ -314,7 +322,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   // 2x2 or 1x1 tiles, so that the heaviest tile (glass: 10x the mean) is a small part of a
   // workgroup's share and the long-path regions spread over many workgroups.
   const uint64_t want_tiles = (uint64_t)s->num_cus * 100u;
-  // tile geometry: 4^tl pixels, as a run of one scanline (default) or a square
+  // tile geometry: 4^tl pixels, as a square (default) or a run of one scanline
   // (shape 0: 2^t x 2^t; 1: 4^t x 1; 2 and 3: the square widened / flattened once or twice, 16x4 and 32x2 at t = 3)
   auto widen = [&](uint32_t t) { const uint32_t k = s->tile_shape == 0 ? 0u : (s->tile_shape == 1 ? t : (uint32_t)s->tile_shape - 1u); return k < t ? k : t; };
   auto tiles_xy = [&](uint32_t t, uint32_t& tx, uint32_t& ty) {
@@ -371,7 +379,11 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   ka.aff_group_log2 = 0xFFFFFFFFu;
   for (int x = 0; x < 8; ++x) { ka.xcd_cnt[x] = 0; ka.xcd_off[x] = 0; }
   {
-    static const uint32_t run_px_log2 = [] { const char* e = std::getenv("RT_AFF_RUN_LOG2"); const int v = e ? std::atoi(e) : 9; return (uint32_t)(v < 3 ? 3 : (v > 14 ? 14 : v)); }();  // (development knob)
+#ifdef RT_DEV_KNOBS  // (A/B builds only: tools/affinity_sweep.sh)
+    static const uint32_t run_px_log2 = [] { const char* e = std::getenv("RT_AFF_RUN_LOG2"); const int v = e ? std::atoi(e) : 9; return (uint32_t)(v < 3 ? 3 : (v > 14 ? 14 : v)); }();
+#else
+    constexpr uint32_t run_px_log2 = 9;  // runs of 512 pixels of a tile row (profiles/r02_run29_affinity.log)
+#endif
     const uint32_t gl = ka.tile_wl >= run_px_log2 ? 0u : run_px_log2 - ka.tile_wl;
     const uint32_t n_groups = (ka.n_tiles + (1u << gl) - 1u) >> gl;
     if ((s->tile_affinity == 1 && n_groups >= 256u) || (s->tile_affinity == 2 && n_groups >= 8u)) {
@@ -386,7 +398,9 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
     }
   }
   if (s->order_mode == 2) {
-    const uint64_t key = ((uint64_t)ka.n_tiles << 32) ^ ((uint64_t)tl << 28) ^ ((uint64_t)s->tile_shape << 26) ^ ((uint64_t)(ka.aff_group_log2 & 31u) << 50) ^ ((uint64_t)ka.first_tile << 14) ^ ka.tile_stride ^ ((uint64_t)ka.tile_rows << 40) ^ ((uint64_t)local_rows << 8);
+    RtHipScene::OrderKey key;
+    key.n_tiles = ka.n_tiles; key.tile_log2 = tl; key.tile_shape = (uint32_t)s->tile_shape; key.aff_group_log2 = ka.aff_group_log2;
+    key.tile_rows = ka.tile_rows; key.first_tile = ka.first_tile; key.tile_stride = ka.tile_stride; key.local_rows = local_rows;
     if (ka.n_tiles > s->order_cap) {
       if (s->d_tile_depth) (void)hipFree(s->d_tile_depth);
       if (s->d_tile_order) (void)hipFree(s->d_tile_order);
@@ -395,7 +409,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
       RT_HIP_TRY(hipMalloc((void**)&s->d_tile_order, (size_t)ka.n_tiles * 4));
       s->order_cap = ka.n_tiles;
     }
-    if (key != s->order_key) { s->order_key = key; s->order_ready = false; s->order_age = 0; }
+    if (!(key == s->order_key)) { s->order_key = key; s->order_ready = false; s->order_age = 0; }
     if (s->order_age < 2) ka.tile_depth = s->d_tile_depth;  // (measured only while the order is still being built)
     if (s->order_ready) ka.tile_order = s->d_tile_order;
   }
@@ -509,6 +523,24 @@ extern "C" int rt_hip_math_probe(const double* x, const double* y, double* out_s
                                  double* out_atan2, uint32_t n, void* stream) {
   hipLaunchKernelGGL(rtk::rt_math_probe, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, out_sqrt, out_div,
                      out_sqrtf, out_atan2, n);
+  RT_HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
+// device probe of the Texture hit's fast texel path beside the exact one (see rtk::rt_texel_probe); d_* are DEVICE pointers
+extern "C" int rt_hip_texel_probe(const double* d_points, const double centre_radius[4], double h_offset, uint64_t tex_w, uint64_t tex_h,
+                                  uint64_t* d_out, double* d_uv, uint32_t n, void* stream) {
+  if (!d_points || !centre_radius || !d_out) return fail(RT_ERR_INVALID, "null argument");
+  hipLaunchKernelGGL(rtk::rt_texel_probe, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_points, centre_radius[0], centre_radius[1],
+                     centre_radius[2], centre_radius[3], h_offset, (unsigned long long)tex_w, (unsigned long long)tex_h,
+                     (unsigned long long*)d_out, d_uv, n);
+  RT_HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
+extern "C" int rt_hip_quot_probe(const double* d_x, const double* d_y, double* d_quot, double* d_rsqrt, uint32_t n, void* stream) {
+  if (!d_x || !d_y || !d_quot || !d_rsqrt) return fail(RT_ERR_INVALID, "null argument");
+  hipLaunchKernelGGL(rtk::rt_quot_probe, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_x, d_y, d_quot, d_rsqrt, n);
   RT_HIP_TRY(hipGetLastError());
   return RT_OK;
 }

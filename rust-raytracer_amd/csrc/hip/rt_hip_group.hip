@@ -80,6 +80,7 @@ struct RtHipGroup {
   uint32_t G = 1, width = 0, height = 0, pad_rows = 0;
   size_t row_bytes = 0, pad_bytes = 0;
   bool rccl = false;
+  bool shared_device = false;        // RT_GPUS_EMULATE: some ranks share a device
   bool gather = false;               // G > 1 (or the one-rank self-test): gather + de-interleave after the kernels
   std::vector<int> device;
   std::vector<RtHipScene*> scene;
@@ -200,7 +201,7 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
   g->row_bytes = (size_t)scene->width * 3;
   g->device.resize(G); g->scene.assign(G, nullptr); g->stream.assign(G, nullptr); g->ev_done.assign(G, nullptr);
   g->d_tiles.assign(G, nullptr); g->tiles.resize(G); g->rc.assign(G, RT_OK); g->err.resize(G);
-  bool shared_device = false;
+  bool& shared_device = g->shared_device;
   for (uint32_t r = 0; r < G; ++r) {
     g->device[r] = (int)(r % (uint32_t)ndev);
     if (r >= (uint32_t)ndev) shared_device = true;
@@ -276,9 +277,34 @@ extern "C" int rt_hip_group_set_option(RtHipGroup* g, const char* key, int64_t v
   return RT_OK;
 }
 
-// One frame: G parallel launches, ONE gather, de-interleave, ONE device-to-host copy.  Blocking.
-extern "C" int rt_hip_group_render_to_host(RtHipGroup* g, uint8_t* out_rgb8, RtStats* stats) {
-  if (!g || !out_rgb8) return fail(RT_ERR_INVALID, "null argument");
+extern "C" int rt_hip_group_info(const RtHipGroup* g, RtGroupInfo* info) {
+  if (!g || !info) return fail(RT_ERR_INVALID, "null argument");
+  std::memset(info, 0, sizeof *info);
+  info->n_ranks = g->G;
+  info->transport = !g->gather ? RT_GATHER_NONE : (g->rccl ? RT_GATHER_RCCL : RT_GATHER_PEER);
+  info->rccl_comms = (uint32_t)g->comm.size();
+  info->tile_rows = RT_GROUP_TILE_ROWS; info->pad_rows = g->pad_rows;
+  info->emulated = g->shared_device ? 1u : 0u;
+  uint64_t seen[16] = {0};  // device ordinals < 1024
+  for (uint32_t r = 0; r < RT_GROUP_INFO_MAX_RANKS; ++r) info->device[r] = -1;
+  for (uint32_t r = 0; r < g->G; ++r) {
+    const int d = g->device[r];
+    if (r < RT_GROUP_INFO_MAX_RANKS) info->device[r] = d;
+    if (d >= 0 && d < 1024 && !((seen[d >> 6] >> (d & 63)) & 1ull)) { seen[d >> 6] |= 1ull << (d & 63); info->n_devices++; }
+  }
+  return RT_OK;
+}
+
+extern "C" const void* rt_hip_group_frame(const RtHipGroup* g, int* device_out) {
+  if (!g) return nullptr;
+  if (device_out) *device_out = g->device.empty() ? 0 : g->device[0];
+  return g->d_frame;
+}
+
+namespace rtg {
+// One frame: G parallel launches, ONE gather, de-interleave; the frame is left in scanline order on the group's first
+// device (rt_hip_group_frame) and, when out_rgb8 is given, leaves in ONE device-to-host copy.  Blocking.
+int group_frame(RtHipGroup* g, uint8_t* out_rgb8, RtStats* stats) {
   const auto t0 = std::chrono::steady_clock::now();
   const uint32_t G = g->G;
   {
@@ -326,7 +352,7 @@ extern "C" int rt_hip_group_render_to_host(RtHipGroup* g, uint8_t* out_rgb8, RtS
       RT_HIP_TRY(hipGetLastError());
     }
     RT_HIP_TRY(hipEventRecord(g->ev_assembled, s0));
-    RT_HIP_TRY(hipMemcpyAsync(out_rgb8, g->d_frame, (size_t)g->height * g->row_bytes, hipMemcpyDeviceToHost, s0));
+    if (out_rgb8) RT_HIP_TRY(hipMemcpyAsync(out_rgb8, g->d_frame, (size_t)g->height * g->row_bytes, hipMemcpyDeviceToHost, s0));
     RT_HIP_TRY(hipStreamSynchronize(s0));
     frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (uint32_t r = 0; r < G; ++r) {  // (also drains the other ranks' streams: with RCCL their gather kernels)
@@ -355,6 +381,16 @@ extern "C" int rt_hip_group_render_to_host(RtHipGroup* g, uint8_t* out_rgb8, RtS
   if (rc != RT_OK) drain();
   return rc;
 }
+}  // namespace rtg
+
+extern "C" int rt_hip_group_render_to_host(RtHipGroup* g, uint8_t* out_rgb8, RtStats* stats) {
+  if (!g || !out_rgb8) return fail(RT_ERR_INVALID, "null argument");
+  return rtg::group_frame(g, out_rgb8, stats);
+}
+extern "C" int rt_hip_group_render(RtHipGroup* g, RtStats* stats) {
+  if (!g) return fail(RT_ERR_INVALID, "null argument");
+  return rtg::group_frame(g, nullptr, stats);
+}
 
 // drop-in for the parallel loop of render() (raytracer.rs:254-263): host scene in, host RGB8 out
 extern "C" int rt_render_rgb8(const RtScene* scene, uint8_t* out_rgb8, RtStats* stats) {
@@ -363,6 +399,9 @@ extern "C" int rt_render_rgb8(const RtScene* scene, uint8_t* out_rgb8, RtStats* 
   RtHipGroup* g = nullptr;
   int rc = rt_hip_group_create(scene, 0, &g);
   if (rc != RT_OK) return rc;
+  // one frame per scene: no later frame could use a queue order learned from this one (tile_order 2 would measure
+  // the tile depths and run rt_order_tiles inside frame_ms for nothing) — bottom row first
+  (void)rt_hip_group_set_option(g, "tile_order", 1);
   const double setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   RtStats st;
   rc = rt_hip_group_render_to_host(g, out_rgb8, &st);

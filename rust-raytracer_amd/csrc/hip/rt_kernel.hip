@@ -931,4 +931,33 @@ __global__ void rt_hit_probe(const double* rays, const double* spheres, double* 
   out_t[i] = hit ? closest : -1.0;
 }
 
+
+// The Texture hit's texel ON THE DEVICE, both ways (materials.rs:236-254 through sphere.rs:35-43): texel_fast — the
+// plain-f64 (u, v) through v_rsq_f64 / v_rcp_f64 + Newton steps that only the device build takes — beside the exact path
+// (three correctly rounded divisions + the shared double-double atan2).  out = n x {fast_ok, fast col, fast row, exact
+// col, exact row}; uv = n x {fast u, fast v, exact u, exact v} (fast u = NaN: the fast path declined).
+__global__ void rt_texel_probe(const double* points, double cx, double cy, double cz, double r, double h_offset, unsigned long long tex_w,
+                               unsigned long long tex_h, unsigned long long* out, double* uv, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 p = v3(points[3 * i], points[3 * i + 1], points[3 * i + 2]);
+  SphereGeom g; g.cx = cx; g.cy = cy; g.cz = cz; g.r = r;
+  uint64_t col = 0, row = 0;
+  const bool ok = texel_fast(p, g, h_offset, tex_w, tex_h, col, row);
+  const UV fa = fast_uv_core(p, g);
+  const UV ex = sphere_uv(p, g);
+  double rot = ex.u + h_offset;
+  if (rot > 1.0) rot = rot - 1.0;
+  out[5 * i] = ok ? 1ull : 0ull; out[5 * i + 1] = col; out[5 * i + 2] = row;
+  out[5 * i + 3] = sat_u64(floor(rot * (double)tex_w)); out[5 * i + 4] = sat_u64(floor((1.0 - ex.v) * (double)(tex_h - 1)));
+  if (uv) { uv[4 * i] = fa.u; uv[4 * i + 1] = fa.v; uv[4 * i + 2] = ex.u; uv[4 * i + 3] = ex.v; }
+}
+// rt_fast_quot(x, y) and rt_fast_rsqrt(x) as the device evaluates them (x, y normal and positive)
+__global__ void rt_quot_probe(const double* x, const double* y, double* out_quot, double* out_rsqrt, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out_quot[i] = rt_fast_quot(x[i], y[i]);
+  out_rsqrt[i] = rt_fast_rsqrt(x[i]);
+}
+
 }  // namespace rtk

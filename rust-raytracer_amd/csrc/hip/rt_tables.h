@@ -3,6 +3,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -40,13 +41,19 @@ struct GridParams {
   uint32_t max_large_by_radius = 8;
   uint32_t large_cell_limit = 512; // a sphere covering more cells than this -> `large` list
   uint32_t min_spheres = 24;       // fewer spheres than this: no grid, test them all
+  uint32_t force_n[3] = {0, 0, 0}; // != 0: cells along that axis (development: anisotropic grids)
 };
+// The shipped library takes the defaults above and reads NOTHING from the environment.  A/B builds and the analysis
+// tools (tools/ab_bench.py, tools/analysis/) compile with -DRT_DEV_KNOBS to sweep the grid's shape.
 inline GridParams grid_params_from_env() {
   GridParams p;
+#ifdef RT_DEV_KNOBS
   if (const char* e = std::getenv("RT_GRID_CELLS_PER_SPHERE")) p.cells_per_sphere = std::atof(e);
   if (const char* e = std::getenv("RT_GRID_MIN_SPHERES")) p.min_spheres = (uint32_t)std::atoi(e);
   if (const char* e = std::getenv("RT_GRID_LARGE_RATIO")) p.large_radius_ratio = std::atof(e);
   if (const char* e = std::getenv("RT_GRID_LARGE_CELLS")) p.large_cell_limit = (uint32_t)std::atoi(e);
+  if (const char* e = std::getenv("RT_GRID_N")) std::sscanf(e, "%u,%u,%u", &p.force_n[0], &p.force_n[1], &p.force_n[2]);
+#endif
   return p;
 }
 
@@ -110,6 +117,7 @@ inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
   for (int k = 0; k < 3; ++k) {
     double c = std::ceil(ext[k] / cell);
     if (!(c >= 1.0)) c = 1.0;
+    if (gp.force_n[k]) c = (double)gp.force_n[k];
     if (c > (double)GRID_MAX_AXIS) c = (double)GRID_MAX_AXIS;
     G.n[k] = (uint32_t)c;
   }

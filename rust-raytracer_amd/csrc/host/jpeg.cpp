@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <new>
 #include <vector>
 
 #include "../../../include/rt_abi.h"
@@ -151,7 +152,10 @@ struct Decoder {
 
   bool fail(const std::string& m) { err = m; return false; }
 
-  static inline int16_t sat16(int v) { return int16_t(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+  static inline int16_t sat16(long long v) { return int16_t(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+  // DC predictor of a crafted stream: saturate far outside anything a real frame reaches (|DC| < 2^15) instead of
+  // running into signed overflow after millions of maximal differences
+  static inline int add_pred(int pred, int diff) { const int v = pred + diff; return v < -(1 << 24) ? -(1 << 24) : (v > (1 << 24) ? (1 << 24) : v); }
 
   // ---- one block of one scan.  Sequential frames: DC + all AC (ss = 0, se = 63, ah = al = 0).  Progressive frames
   // (ITU T.81 annex G): DC first / refinement, AC first / refinement with end-of-band runs shared across blocks.
@@ -159,7 +163,7 @@ struct Decoder {
     const Huff& hd = dc[cp.td]; const Huff& ha = ac[cp.ta];
     int t = decode_sym(br, hd);
     if (t < 0 || t > 11) return fail("bad DC huffman code");
-    cp.pred += t ? extend(br.get(t), t) : 0;
+    cp.pred = add_pred(cp.pred, t ? extend(br.get(t), t) : 0);
     blk[0] = sat16(cp.pred);
     for (int k = 1; k < 64;) {
       int rs = decode_sym(br, ha);
@@ -176,8 +180,8 @@ struct Decoder {
   bool block_dc_first(BitReader& br, Comp& cp, int16_t* blk, int al) {
     int t = decode_sym(br, dc[cp.td]);
     if (t < 0 || t > 11) return fail("bad DC huffman code");
-    cp.pred += t ? extend(br.get(t), t) : 0;
-    blk[0] = sat16(cp.pred * (1 << al));
+    cp.pred = add_pred(cp.pred, t ? extend(br.get(t), t) : 0);
+    blk[0] = sat16((long long)cp.pred * (1ll << al));
     return true;
   }
   static void block_dc_refine(BitReader& br, int16_t* blk, int al) {
@@ -360,8 +364,13 @@ struct Decoder {
           comp[c].bw = mcux * comp[c].h; comp[c].bh = mcuy * comp[c].v;
           const int cw = (width * comp[c].h + hmax - 1) / hmax, ch = (height * comp[c].v + vmax - 1) / vmax;
           comp[c].nbx = (cw + 7) / 8; comp[c].nby = (ch + 7) / 8;
-          if (size_t(comp[c].bw) * comp[c].bh > (size_t(1) << 26)) return fail("image too large");
-          comp[c].coef.assign(size_t(comp[c].bw) * comp[c].bh * 64, 0);
+          // The coefficient store is 128 B per block.  A Huffman-coded block takes at least one bit, so a frame header
+          // that claims more than 8 blocks per byte of the file cannot be backed by data: refuse it before allocating
+          // (a 30-byte header claiming 65535 x 65535 would otherwise zero-fill 8 GiB per component).
+          const size_t blocks = size_t(comp[c].bw) * comp[c].bh;
+          if (blocks > (size_t(1) << 22)) return fail("image too large (more than 2^22 blocks per component)");
+          if (blocks > 8 * len + 64) return fail("frame header claims more blocks than the file could hold");
+          comp[c].coef.assign(blocks * 64, 0);
         }
         sof_seen = true;
       } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
@@ -496,13 +505,25 @@ extern "C" const char* rt_jpeg_last_error(void) { return g_jpeg_err.c_str(); }
 
 extern "C" int rt_jpeg_decode_mem(const uint8_t* data, size_t len, uint8_t** rgb8, uint32_t* w, uint32_t* h) {
   if (!data || !rgb8 || !w || !h) return RT_ERR_INVALID;
-  Decoder d; d.data = data; d.len = len;
-  if (!d.parse()) { g_jpeg_err = d.err; return RT_ERR_TEXTURE; }
-  uint8_t* out = static_cast<uint8_t*>(std::malloc(size_t(d.width) * d.height * 3));
-  if (!out) { g_jpeg_err = "out of memory"; return RT_ERR_TEXTURE; }
-  d.to_rgb(out);
-  *rgb8 = out; *w = uint32_t(d.width); *h = uint32_t(d.height);
-  return RT_OK;
+  // nothing may leave an extern "C" function by exception: an allocation failure inside the decoder is a texture error
+  uint8_t* out = nullptr;
+  try {
+    Decoder d; d.data = data; d.len = len;
+    if (!d.parse()) { g_jpeg_err = d.err; return RT_ERR_TEXTURE; }
+    out = static_cast<uint8_t*>(std::malloc(size_t(d.width) * d.height * 3));
+    if (!out) { g_jpeg_err = "out of memory"; return RT_ERR_TEXTURE; }
+    d.to_rgb(out);
+    *rgb8 = out; *w = uint32_t(d.width); *h = uint32_t(d.height);
+    return RT_OK;
+  } catch (const std::bad_alloc&) {
+    std::free(out);
+    g_jpeg_err = "out of memory while decoding";
+    return RT_ERR_TEXTURE;
+  } catch (...) {
+    std::free(out);
+    g_jpeg_err = "internal decoder error";
+    return RT_ERR_TEXTURE;
+  }
 }
 
 extern "C" int rt_jpeg_decode_file(const char* path, uint8_t** rgb8, uint32_t* w, uint32_t* h) {
@@ -510,8 +531,14 @@ extern "C" int rt_jpeg_decode_file(const char* path, uint8_t** rgb8, uint32_t* w
   FILE* f = std::fopen(path, "rb");
   if (!f) { g_jpeg_err = std::string("cannot open ") + path; return RT_ERR_TEXTURE; }
   std::vector<uint8_t> buf;
-  uint8_t tmp[65536]; size_t n;
-  while ((n = std::fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+  try {
+    uint8_t tmp[65536]; size_t n;
+    while ((n = std::fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+  } catch (const std::bad_alloc&) {
+    std::fclose(f);
+    g_jpeg_err = std::string("out of memory reading ") + path;
+    return RT_ERR_TEXTURE;
+  }
   std::fclose(f);
   return rt_jpeg_decode_mem(buf.data(), buf.size(), rgb8, w, h);
 }

@@ -50,9 +50,15 @@ def lib():
         L.rt_hip_group_set_camera.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 4
         L.rt_hip_group_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.rt_hip_group_render_to_host.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.RtStats)]
+        L.rt_hip_group_render.argtypes = [C.c_void_p, C.POINTER(abi.RtStats)]
+        L.rt_hip_group_info.argtypes = [C.c_void_p, C.POINTER(abi.RtGroupInfo)]
+        L.rt_hip_group_frame.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.rt_hip_group_frame.restype = C.c_void_p
+        L.rt_hip_texel_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.rt_hip_quot_probe.argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_void_p]
         L.rt_hip_group_stacked_row.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
         L.rt_hip_group_stacked_row.restype = C.c_uint32
-        for name in ("RtSphere", "RtTexture", "RtScene", "RtRowTiles", "RtStats"):   # the binding's own layout check
+        for name in ("RtSphere", "RtTexture", "RtScene", "RtRowTiles", "RtStats", "RtGroupInfo"):   # the binding's own layout check
             if L.rt_abi_sizeof(name.encode()) != C.sizeof(getattr(abi, name)):
                 raise ImportError(f"{LIB_PATH}: sizeof({name}) = {L.rt_abi_sizeof(name.encode())} but abi.py has "
                                   f"{C.sizeof(getattr(abi, name))} — rebuild with __graft_entry__.build()")
@@ -154,6 +160,25 @@ class HipGroup:
         st = abi.RtStats()
         _check(lib().rt_hip_group_render_to_host(self._h, out.ctypes.data, C.byref(st)))
         return out, st.as_dict()
+
+    def render(self):
+        """one frame, left in HBM of the group's first device (frame_ptr()); blocking; returns the stats"""
+        st = abi.RtStats()
+        _check(lib().rt_hip_group_render(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def frame_ptr(self):
+        """(device pointer of the assembled RGB8 frame, device ordinal)"""
+        dev = C.c_int(0)
+        return lib().rt_hip_group_frame(self._h, C.byref(dev)), dev.value
+
+    def info(self):
+        """what the group runs on: ranks, distinct devices, gather transport, RCCL communicators (rt_hip_group_info)"""
+        gi = abi.RtGroupInfo()
+        _check(lib().rt_hip_group_info(self._h, C.byref(gi)))
+        return {"n_ranks": gi.n_ranks, "n_devices": gi.n_devices, "transport": ("none", "rccl", "peer")[gi.transport],
+                "rccl_comms": gi.rccl_comms, "tile_rows": gi.tile_rows, "pad_rows": gi.pad_rows, "emulated": bool(gi.emulated),
+                "rank_devices": [gi.device[r] for r in range(min(gi.n_ranks, abi.RT_GROUP_INFO_MAX_RANKS))]}
 
     def close(self):
         if self._h:

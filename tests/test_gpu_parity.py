@@ -39,7 +39,7 @@ def torch_cuda():
 def gpu_render(pkg, abi, torch_cuda):
     torch = torch_cuda
 
-    def _render(scene, tiles=None, variant=0, want_linear=True, pool=None, chunk_spp=None, tile_log2=None, tile_order=None, frames=1, tile_shape=None,
+    def _render(scene, tiles=None, variant=0, want_linear=True, chunk_spp=None, tile_log2=None, tile_order=None, frames=1, tile_shape=None,
                 tile_affinity=None):
         """variant 0: the product kernel (grid walk, tile queue, exact fixed-point pixel sums);
         variant 1: same kernel, the reference's brute force over all spheres.  chunk_spp: samples of a
@@ -49,8 +49,6 @@ def gpu_render(pkg, abi, torch_cuda):
         gs = pkg.hip.HipScene(scene.ptr, 0)
         if variant:
             gs.set_option("variant", variant)
-        if pool is not None:
-            gs.set_option("pool", pool)
         if chunk_spp is not None:
             gs.set_option("chunk_spp", chunk_spp)
         if tile_log2 is not None:

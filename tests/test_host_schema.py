@@ -196,6 +196,14 @@ def test_malformed_jpeg_is_rejected_not_overrun(host, abi):
     # a DRI segment with no payload, placed before SOS
     m, p, L = next(s for s in segs if s[0] == 0xDA)
     expect_fail(good[:p] + bytes([0xFF, 0xDD, 0, 2]) + good[p:], "empty DRI")
+    # (2b) ADVICE r2 (medium): a frame header that claims 65535 x 65535 pixels in a tiny file must be refused BEFORE the
+    # coefficient store is allocated (8 GiB per component, std::bad_alloc across the extern "C" boundary), and so must
+    # any size the file could not possibly back with entropy-coded data
+    m, p, L = next(s for s in segs if s[0] == 0xC0)
+    for hh, ww in ((0xFFFF, 0xFFFF), (0x4000, 0x4000), (2048, 2048)):
+        bad = bytearray(good)
+        bad[p + 5:p + 9] = bytes([hh >> 8, hh & 255, ww >> 8, ww & 255])
+        expect_fail(bad, f"claimed {ww}x{hh}")
     # (3) truncations: any prefix either fails cleanly or (entropy data cut short) decodes with zero-filled bits
     for cut in list(range(0, 64)) + list(range(64, len(good), 37)):
         try:

@@ -19,7 +19,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 AB = os.path.join(ROOT, "build", "ab")
 SRC = os.path.join(ROOT, "rust-raytracer_amd", "csrc", "hip", "rt_hip_api.hip")
-BASE = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+BASE = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DRT_DEV_KNOBS"]  # A/B builds read the RT_GRID_* / RT_AFF_RUN_LOG2 knobs; the product does not
 # name -> (extra compile flags, runtime options, environment at scene creation)
 W4 = ["-DRT_WAVES_PER_EU=4"]
 SCAN = ["-DRT_WITH_SCAN_KERNEL"]   # the round-1 cull-scan kernel is compiled into A/B builds only ("variant" 2)
@@ -94,22 +94,22 @@ def run(rounds, scene_path, only):
             del os.environ[k]
         for k, v in opts.items():
             assert L.rt_hip_set_option(hs, k.encode(), v) == 0
-        libs[name] = (L, hs, [], opts.get("pool", 1))
+        libs[name] = (L, hs, [])
     st = abi.RtStats()
     stats = {}
     for r in range(rounds + 1):  # round 0 = warm-up + image check
-        for name, (L, hs, times, pool) in libs.items():
+        for name, (L, hs, times) in libs.items():
             assert L.rt_hip_render(hs, None, rgb.data_ptr(), None, stream) == 0, L.rt_hip_last_error()
             assert L.rt_hip_wait(hs, C.byref(st)) == 0
             if r == 0:
                 img = rgb.cpu().numpy()
-                ref.setdefault(pool, img)  # pooled and per-pixel accumulation each have their own bits
-                assert np.array_equal(img, ref[pool]), f"{name}: image differs from the first variant of its accumulation mode"
+                ref.setdefault(0, img)
+                assert np.array_equal(img, ref[0]), f"{name}: image differs from the first variant"
             else:
                 times.append(st.kernel_ms)
             stats[name] = (st.exact_tests, st.grid_steps, st.segments)
     samples = w * h * sc.c.samples_per_pixel
-    for name, (L, hs, times, pool) in libs.items():
+    for name, (L, hs, times) in libs.items():
         med = statistics.median(times)
         print(json.dumps({"variant": name, "kernel_ms_median": round(med, 3), "kernel_ms_min": round(min(times), 3),
                           "msamples_per_s": round(samples / med / 1e3, 1), "rounds": rounds,

@@ -18,7 +18,7 @@
 //   * RGB8 framebuffer written once per pixel.
 #include <hip/hip_runtime.h>
 
-#include "rt_core.h"
+#include "../../rust-raytracer_amd/csrc/hip/rt_core.h"
 
 namespace rtk_scan {
 using namespace rtc;
