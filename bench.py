@@ -10,7 +10,18 @@ A "step" is one frame of BASELINE configs[1] — cover_scene at 1200x800, spp 12
 scene tables already resident in HBM.  With N > 1 the frame is sharded by interleaved
 2-scanline tiles (rank r renders tiles r, r+N, ...) and assembled on rank 0 by ONE gather
 over RCCL; total work is fixed, so scaling is "strong" (the north-star target is a >=6x
-speed-up of this frame at 8 GPUs).  In the timed region the tile buffers are double-buffered:
+speed-up of this frame at 8 GPUs).
+
+Two hosts for N > 1, the line's config.parallelism says which ran:
+  * `python bench.py --gpus N` (no torchrun): ONE process drives the PRODUCT path — the in-library group
+    (rt_hip_group_*: host thread + stream per device, ncclCommInitAll, one ncclGather per frame, de-interleave
+    kernel), K blocking frames, each complete in HBM of the first device before the next starts; `value` from
+    wall time.  RT_GPUS_EMULATE=1 lets the ranks share devices (a 1-GPU box can run the whole path).
+  * under torch.distributed.run (WORLD_SIZE set): one process per GPU, the same shards gathered by
+    torch.distributed (RCCL), described next.
+Any failure prints ONE JSON line with an "error" key and exits non-zero — never a bare traceback.
+
+Process-per-GPU branch: in the timed region the tile buffers are double-buffered:
 frame i's gather runs (asynchronously, on the collective's stream) while frame i+1 is being
 rendered, and all K frames are assembled on rank 0 before the closing barrier — `value` is that
 pipelined throughput.  The latency of ONE frame with nothing overlapped (render, gather, row
@@ -79,7 +90,7 @@ def _latest_pmc():
     return (best[1], best[2]) if best else (None, None)
 
 
-def main():
+def _args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -93,8 +104,158 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-row-stride", type=int, default=16,
                     help="cpu_baseline renders every k-th scanline (default: chosen for ~10 s of CPU wall time)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+class BenchError(RuntimeError):
+    pass
+
+
+def _pmc_head(pmc):
+    return (pmc or {}).get("git_head")
+
+
+def _git_head():
+    """the commit librt_hip.so was built from (BUILD_INFO.json, written by build(): the GPU box has no .git)"""
+    try:
+        return json.load(open(os.path.join(ROOT, "rust-raytracer_amd", "BUILD_INFO.json"))).get("git_head")
+    except Exception:
+        return None
+
+
+def _scene_pmc(key):
+    """newest profiles/rNN_*pmc_<key>.json (counters of another BASELINE config, tools/pmc_scene.sh)"""
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*pmc_{key}.json")))
+    if not c:
+        return None
+    try:
+        return c[-1], json.load(open(c[-1]))
+    except Exception:
+        return None
+
+
+def main():
+    args = _args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    try:
+        if world == 1 and args.gpus > 1:
+            line = run_group(args)          # ONE process, the in-library group (the product's multi-GPU path)
+        else:
+            line = run_ranks(args)          # N = 1, or one process per GPU under torch.distributed.run
+    except BaseException as e:              # noqa: BLE001 — the driver must get a JSON line whatever happens
+        if isinstance(e, KeyboardInterrupt):
+            raise
+        if rank == 0:
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            _flush_c_stdio()
+            print(json.dumps({"metric": "Msamples/sec (pixels x spp / s) on cover_scene 1200x800", "value": None, "unit": "Msamples/s",
+                              "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "error": f"{type(e).__name__}: {e}"}), flush=True)
+        sys.exit(2)
+    _flush_c_stdio()
+    if rank == 0 and line is not None:
+        print(line, flush=True)   # the ONE JSON line, and the last thing this process writes to stdout
+
+
+def run_group(args):
+    """--gpus N without torchrun: the in-library group (rt_hip_group_*), one process, blocking frames."""
+    import numpy as np
+    import torch
+
+    os.chdir(ROOT)
+    if not torch.cuda.is_available():
+        raise BenchError("bench.py needs a GPU: the hot path has no CPU fallback")
+    pkg = graft.load_package()
+    abi, host, hip = pkg.abi, pkg.host, pkg.hip
+    visible = hip.device_count()
+    emulate = os.environ.get("RT_GPUS_EMULATE") == "1"
+    if args.gpus > visible and not emulate:
+        raise BenchError(f"--gpus {args.gpus} but only {visible} device(s) visible (RT_GPUS_EMULATE=1 lets ranks share devices: tests only)")
+    sc = host.Scene.load(args.scene)
+    if args.spp:
+        sc.c.samples_per_pixel = args.spp
+    if args.width:
+        sc.c.width = args.width
+    if args.height:
+        sc.c.height = args.height
+    W, H, SPP, N_SPH = sc.c.width, sc.c.height, sc.c.samples_per_pixel, sc.c.n_spheres
+    headline = args.scene == HEADLINE and not (args.spp or args.width or args.height or args.variant)
+    # RCCL prints its banner through C stdio when the communicators come up: keep stdout for the ONE line
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        t_setup = time.perf_counter()
+        grp = hip.HipGroup(sc.ptr, args.gpus)    # scene replicas + streams + threads + ncclCommInitAll: outside the timed region
+        setup_s = time.perf_counter() - t_setup
+    finally:
+        _flush_c_stdio()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+    if args.variant:
+        grp.set_option("variant", args.variant)
+    info = grp.info()
+    devs = sorted(set(info["rank_devices"]))
+
+    def sync_all():
+        for d in devs:
+            torch.cuda.synchronize(d)
+
+    for _ in range(max(args.warmup, 2)):      # (two frames build the queue order, like the N = 1 path's warm-up)
+        grp.render()
+    sync_all()
+    lat, kern, gath = [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = grp.render()                     # blocking: G launches -> ONE gather -> de-interleave; frame in HBM of the first device
+        lat.append(st["frame_ms"]); kern.append(st["kernel_ms"]); gath.append(st["gather_ms"])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    # the assembled frame against ONE launch of the whole frame on the first device (same process): must be byte-identical
+    frame, _ = grp.render_to_host()
+    one = hip.HipScene(sc.ptr, devs[0])
+    if args.variant:
+        one.set_option("variant", args.variant)
+    ks = []
+    ref = None
+    for _ in range(4):
+        ref, st1 = one.render_to_host()
+        ks.append(st1["kernel_ms"])
+    one.close()
+    n1_kernel_ms = sorted(ks[1:])[1]
+    identical = bool(np.array_equal(frame, ref))
+    grp.close()
+    if not identical:
+        raise BenchError(f"the {args.gpus}-rank frame differs from the single launch in {int((frame != ref).sum())} bytes")
+    samples = W * H * SPP
+    med = lambda v: sorted(v)[len(v) // 2]    # noqa: E731
+    ms_per_step = elapsed * 1e3 / args.steps
+    out = {
+        "metric": "Msamples/sec (pixels x spp / s) on cover_scene 1200x800",
+        "value": round(samples * args.steps / elapsed / 1e6, 3), "unit": "Msamples/s", "n_gpus": args.gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "scene derived from the reference's data/cover_scene.json (committed under scenes/); Philox seed 0",
+        "config": {"workload": f"{os.path.basename(args.scene)}: {W}x{H} spp {SPP} depth {sc.c.max_depth}, {N_SPH} spheres"
+                               + (" (BASELINE configs[1])" if headline else " (NON-HEADLINE run)"),
+                   "parallelism": f"single process, in-library group (rt_hip_group_*): {info['n_ranks']} ranks x interleaved {info['tile_rows']}-scanline tiles, "
+                                  f"one host thread + stream per rank, ONE {info['transport']} gather per frame, blocking frames (no overlap)"
+                                  + (" — RANKS SHARE DEVICES (RT_GPUS_EMULATE=1: a functional check, not a scaling number)" if info["emulated"] else ""),
+                   "inputs": "scene tables resident in HBM of every device before the timed region; each timed frame ends assembled in HBM of the first device"},
+        "kernel_ms": round(med(kern), 4),                 # slowest rank's shard, median over the timed frames
+        "gather_ms": round(med(gath), 4),                 # rank 0's kernel end -> frame in scanline order (waiting for slower ranks + gather + de-interleave)
+        "frame_latency_ms": round(med(lat), 4),           # ONE frame, nothing overlapped (== a step here)
+        "n1_kernel_ms": round(n1_kernel_ms, 4),           # the whole frame in one launch on the first device, same process
+        "speedup_vs_n1_latency": round(n1_kernel_ms / med(lat), 3),
+        "frame_identical_to_n1": identical,
+        "rccl_ranks": info["rccl_comms"], "transport": info["transport"], "rank_devices": info["rank_devices"],
+        "distinct_devices": info["n_devices"], "visible_gpus": visible, "setup_ms": round(setup_s * 1e3, 1),
+        "git_head": _git_head(),
+    }
+    return json.dumps(out)
+
+
+def run_ranks(args):
     import torch
     import torch.distributed as dist
 
@@ -103,11 +264,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+        raise BenchError("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # RT_BENCH_FORCE_COLLECTIVE=1: a one-rank RCCL group still goes through init / gather / barrier — the N > 1
@@ -255,7 +414,8 @@ def main():
             roof["valu_issue_busy"] = round(act / (N_SIMD * kernel_s * ENGINE_HZ / 4.0), 4)
             roof["lane_utilisation"] = round(thr / (64.0 * act), 4)
             roof["counters"] = {"SQ_THREAD_CYCLES_VALU": thr, "SQ_ACTIVE_INST_VALU": act, "SQ_INSTS_VALU": m.get("SQ_INSTS_VALU"),
-                                "source": os.path.relpath(pmc_path, ROOT), "kernel_ms_of_that_run": pmc.get("kernel_ms")}
+                                "source": os.path.relpath(pmc_path, ROOT), "kernel_ms_of_that_run": pmc.get("kernel_ms"),
+                                "git_head_of_that_build": pmc.get("git_head"), "git_head_of_this_build": _git_head()}
             if pmc.get("hbm_bytes_per_launch") is not None:
                 alg_bytes = 3 * W * H + 32 * N_SPH * 2 + 8 * 4800   # framebuffer + one pass over geometry/material/cell tables
                 roof["traffic"] = pmc["hbm_bytes_per_launch"]
@@ -277,7 +437,7 @@ def main():
             "dtype": "f64", "data": "scene derived from the reference's data/cover_scene.json (committed under scenes/); Philox seed 0",
             "config": {"workload": f"{os.path.basename(args.scene)}: {W}x{H} spp {SPP} depth {sc.c.max_depth}, {N_SPH} spheres"
                                    + (" (BASELINE configs[1])" if headline else " (NON-HEADLINE run)"),
-                       "parallelism": f"{world} x interleaved {rdist.TILE_ROWS}-scanline tiles, one RCCL gather per frame (overlapping the next frame's render)" if world > 1 else ("single GPU (one-rank RCCL group forced: self-check)" if force_coll else "single GPU"),
+                       "parallelism": f"one process per GPU (torch.distributed.run): {world} x interleaved {rdist.TILE_ROWS}-scanline tiles, one RCCL gather per frame through torch.distributed (overlapping the next frame's render)" if world > 1 else ("single GPU (one-rank RCCL group forced: self-check)" if force_coll else "single GPU"),
                        "inputs": "scene tables resident in HBM before the timed region"},
             "kernel_ms": round(kernel_ms, 4), "segments_per_sample": round(segments / samples, 4),
             "exact_tests_per_segment": round(exact / max(1.0, segments), 3),
@@ -302,36 +462,68 @@ def main():
             for _ in range(3):
                 gs.render_to_host()
             out["frame_ms_to_host_buffer"] = round((time.perf_counter() - h0) * 1e3 / 3, 3)
+            # `value` is the steady state of repeated frames of one view (the queue order learned from the previous frame,
+            # DESIGN.md §4.1); a one-shot render (rt_render_rgb8, the reference's one frame per process) has no previous
+            # frame: the same kernel with the fixed bottom-row-first order, best of 3
+            g1 = hip.HipScene(sc.ptr, local_rank)
+            g1.set_option("tile_order", 1)
+            if args.variant:
+                g1.set_option("variant", args.variant)
+            fb1 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+            k1 = []
+            for _ in range(4):
+                g1.render(fb1.data_ptr(), 0, None, stream.cuda_stream)
+                k1.append(g1.wait()["kernel_ms"])
+            g1.close()
+            out["first_frame_kernel_ms"] = round(min(k1[1:]), 4)
+            out["value_note"] = "steady state: frame i uses the tile-queue order learned from frame i-1 of the same view; first_frame_kernel_ms = no learned order (a one-shot render)"
+            out["git_head"] = _git_head()
         if world == 1 and headline and not args.no_other_configs:
             out["other_configs"] = other_configs(pkg, torch, dev, stream)
         if world == 1 and not args.no_cpu_baseline:
             oracle = graft.load_oracle()
             cores = oracle.lib(abi).rt_oracle_threads()
 
-            def cpu_run(stride):
+            def cpu_run(stride, want_linear=False):
                 ct = abi.RtRowTiles(1, 0, stride)
                 c0 = time.perf_counter()
-                _, _, ost = oracle.render(abi, sc.ptr, ct, 0, want_linear=False)
-                return time.perf_counter() - c0, ost, abi.tiles_local_rows(H, ct)
+                o_rgb, o_lin, ost = oracle.render(abi, sc.ptr, ct, 0, want_linear=want_linear)
+                return time.perf_counter() - c0, ost, abi.tiles_local_rows(H, ct), o_rgb, o_lin
 
             stride = max(1, args.cpu_row_stride)
-            if stride == 0 or args.cpu_row_stride == 16:   # default: size the sample for ~10 s of wall time on this box
-                probe_s, _, _ = cpu_run(64)
-                stride = int(min(64, max(1, round(64 * probe_s / 10.0))))
-            csec, ost, rows = cpu_run(stride)
+            if stride == 0 or args.cpu_row_stride == 16:   # default: size the sample for <= ~25 s of wall time on this box
+                probe_s, _, _, _, _ = cpu_run(64)          # (the GPU box's 128 host threads take the WHOLE frame in ~21 s)
+                stride = int(min(64, max(1, round(64 * probe_s / 25.0))))
+            csec, ost, rows, o_rgb, o_lin = cpu_run(stride, want_linear=True)
             out["cpu_baseline"] = {"value": round(ost["samples"] / csec / 1e6, 4), "unit": "Msamples/s",
                                    "cores": cores, "kind": "port",
                                    "sample": f"{'every scanline' if stride == 1 else ('every 2nd scanline' if stride == 2 else ('every 3rd scanline' if stride == 3 else f'every {stride}th scanline'))} of the same frame ({rows} rows, {ost['samples'] / 1e6:.2f} Msamples, "
                                              f"{csec:.1f} s); C oracle, OpenMP over 32-pixel blocks of a scanline, -O3 -march=native -ffp-contract=off",
                                    "gpu_over_cpu": round(value / (ost["samples"] / csec / 1e6), 1)}
+            # the image the oracle just produced is the parity check of THIS run's frame (the oracle as checker, after the
+            # timed region): same bar as tests/parity.py
+            import numpy as np
+            fb = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+            fl = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+            gs.render(fb.data_ptr(), fl.data_ptr(), None, stream.cuda_stream)
+            gst = gs.wait()
+            g_rgb, g_lin = fb.cpu().numpy()[::stride], fl.cpu().numpy()[::stride]
+            atol = 2e-6 + 3e-8 * SPP
+            dlin = float(np.abs(g_lin.astype(np.float64) - o_lin.astype(np.float64)).max())
+            d8 = np.abs(g_rgb.astype(np.int16) - o_rgb.astype(np.int16))
+            flips = int((d8 != 0).sum())
+            ok = bool(dlin <= atol and int(d8.max()) <= 1 and flips <= max(2, int(5e-4 * d8.size)))
+            out["parity_vs_oracle"] = {"rows": rows, "of": H, "whole_frame": stride == 1, "max_dlin": dlin, "atol": atol, "rgb8_flips": flips,
+                                       "rgb8_values": int(d8.size), "max_rgb8_diff": int(d8.max()), "ok": ok,
+                                       "segments_equal": (gst["segments"] == ost["segments"] - ost["segments_discarded"]) if stride == 1 else None}
+            if not ok:
+                raise BenchError(f"frame differs from the oracle: {out['parity_vs_oracle']}")
         line = json.dumps(out)
     gs.close()
     if collective:
         dist.barrier()
         dist.destroy_process_group()
-    _flush_c_stdio()
-    if rank == 0:
-        print(line, flush=True)   # the ONE JSON line, and the last thing this process writes to stdout
+    return line if rank == 0 else None
 
 
 def other_configs(pkg, torch, dev, stream):
@@ -340,11 +532,11 @@ def other_configs(pkg, torch, dev, stream):
     sys.path.insert(0, os.path.join(ROOT, "scenes"))
     import procedural
     res = []
-    cases = [("configs[0] test_scene 800x600 spp16 depth8 (lights, textures, hollow glass)", "scenes/cfg1_test_800x600_spp16.json", None),
-             ("configs[2] cover 3840x2160 spp1024, earth/moon + sky textures", "scenes/cfg3_cover_4k_textured.json", None),
-             ("configs[3] cover 3840x2160 spp512 textured, on ONE GPU (the 8-GPU config)", "scenes/cfg4_cover_4k_textured_spp512.json", None),
-             ("configs[4] procedural 10 001 spheres 3840x2160 spp2048 (tables in L2)", None, dict(width=3840, height=2160, spp=2048, half=50, seed=0))]
-    for name, path, proc in cases:
+    cases = [("configs[0] test_scene 800x600 spp16 depth8 (lights, textures, hollow glass)", "scenes/cfg1_test_800x600_spp16.json", None, "cfg1"),
+             ("configs[2] cover 3840x2160 spp1024, earth/moon + sky textures", "scenes/cfg3_cover_4k_textured.json", None, "cfg3"),
+             ("configs[3] cover 3840x2160 spp512 textured, on ONE GPU (the 8-GPU config)", "scenes/cfg4_cover_4k_textured_spp512.json", None, "cfg4"),
+             ("configs[4] procedural 10 001 spheres 3840x2160 spp2048", None, dict(width=3840, height=2160, spp=2048, half=50, seed=0), "cfg5")]
+    for name, path, proc, key in cases:
         s = pkg.host.Scene.load(path) if path else pkg.host.Scene.loads(procedural.make_json(**proc))
         g = pkg.hip.HipScene(s.ptr, dev.index or 0)
         fb = torch.zeros((s.c.height, s.c.width, 3), dtype=torch.uint8, device=dev)
@@ -355,8 +547,20 @@ def other_configs(pkg, torch, dev, stream):
             ks.append(stt["kernel_ms"])
         k = sum(ks[1:]) / 2.0
         n = s.c.width * s.c.height * s.c.samples_per_pixel
-        res.append({"config": name, "kernel_ms": round(k, 3), "msamples_per_s": round(n / k / 1e3, 1), "n_spheres": s.c.n_spheres,
-                    "segments_per_sample": round(stt["segments"] / n, 3), "exact_tests_per_segment": round(stt["exact_tests"] / max(1, stt["segments"]), 2)})
+        rec = {"config": name, "kernel_ms": round(k, 3), "msamples_per_s": round(n / k / 1e3, 1), "n_spheres": s.c.n_spheres,
+               "segments_per_sample": round(stt["segments"] / n, 3), "exact_tests_per_segment": round(stt["exact_tests"] / max(1, stt["segments"]), 2)}
+        # counters of this config (rocprofv3 --pmc passes, tools/pmc_scene.sh -> profiles/rNN_pmc_<key>.json), per launch
+        pm = _scene_pmc(key)
+        if pm is not None:
+            m = pm[1].get("mean_per_launch", {})
+            if "SQ_THREAD_CYCLES_VALU" in m:
+                rec["lane_slot_frac"] = round(m["SQ_THREAD_CYCLES_VALU"] / (k * 1e-3) / 1e12 / PEAK_LANE_SLOTS_T, 4)
+            if pm[1].get("hbm_bytes_per_launch") is not None:
+                rec["traffic"] = pm[1]["hbm_bytes_per_launch"]
+            if pm[1].get("l2_hit_rate") is not None:
+                rec["l2_hit_rate"] = pm[1]["l2_hit_rate"]
+            rec["counters_source"] = os.path.relpath(pm[0], ROOT)
+        res.append(rec)
         g.close()
         del fb
     return res

@@ -55,10 +55,31 @@ def build_cli(force=False):
     return out
 
 
+def write_build_info():
+    """BUILD_INFO.json next to the libraries: the commit they were built from.  The GPU box gets a snapshot without .git,
+    so bench.py and the PMC tools read the head from here (git-ignored, travels with the .so files)."""
+    import json
+    import time
+
+    def git(*a):
+        try:
+            return subprocess.run(["git", *a], cwd=ROOT, capture_output=True, text=True, timeout=10).stdout.strip()
+        except Exception:
+            return ""
+    head = git("rev-parse", "--short", "HEAD")
+    if not head:
+        return  # (not a git checkout: keep whatever file travelled with the snapshot)
+    dirty = bool(git("status", "--porcelain", "--untracked-files=no"))
+    info = {"git_head": head + ("+dirty" if dirty else ""), "built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())}
+    with open(os.path.join(HERE, "BUILD_INFO.json"), "w") as f:
+        json.dump(info, f)
+
+
 def build_all(force=False):
     build_host(force)
     build_hip(force)
     build_cli(force)
+    write_build_info()
 
 
 if __name__ == "__main__":

@@ -80,37 +80,18 @@ def test_fast_texel_path_agrees_with_the_exact_one(hostsim):
     """texel_fast (plain-f64 unit vector and atan, rt_core.h) names a texel only when the exact path (correctly-rounded
     divisions and atan2, then floor) names the same one; hit points aimed at texel boundaries, at the u wrap (rot = 1),
     at the poles and at the octant seams of the atan reduction either agree or are handed to the exact path."""
+    import texel_points
     rng = np.random.default_rng(11)
     total = wrong = refused = 0
-    for (w, h, h_off, radius, centre) in ((2048, 1024, 0.75, 0.5, (0.0, 0.0, -1.0)), (2048, 1024, 0.75, 1.0, (4.0, 1.0, 0.0)),
-                                          (4096, 2048, 0.0, -0.45, (-1.2, 0.0, -1.0)), (7, 3, 0.3, 100.0, (0.0, -100.5, -1.0)),
-                                          (1, 1, 0.999, 1e-3, (1e3, 2e3, -5e2)), (100003, 50021, 0.5, 2.0, (0.0, 0.0, 0.0))):
+    for (w, h, h_off, radius, centre) in texel_points.CASES:
         n = int(os.environ.get("RT_TEXEL_POINTS", "400000"))
-        d = rng.normal(size=(n, 3))
-        d /= np.linalg.norm(d, axis=1)[:, None]
-        # aimed points: u on (or within a few ulps .. 1e-9 of) a column boundary, incl. the wrap; v on a row boundary
-        k = rng.integers(0, w + 1, n // 4)
-        u_t = (k / w - h_off) % 1.0 + rng.choice([0.0, 1e-16, -1e-16, 1e-13, -1e-13, 1e-11, -1e-11, 1e-9, -1e-9], n // 4)
-        ang = (u_t - 0.5) * 2.0 * np.pi
-        yy = rng.uniform(-0.999, 0.999, n // 4)
-        j = rng.integers(0, max(1, h), n // 8)
-        yy[: n // 8] = np.clip(1.0 - 2.0 * j / max(1, h - 1) + rng.choice([0.0, 1e-16, -1e-15, 1e-12, -1e-10], n // 8), -1, 1)
-        rr = np.sqrt(np.maximum(0.0, 1.0 - yy * yy))
-        d[: n // 4] = np.stack([rr * np.sin(ang), yy, rr * np.cos(ang)], axis=1)
-        # poles and the seams |x| = |z|, x = 0, z = 0
-        m = n // 4
-        d[m:m + 1000] = [0.0, 1.0, 0.0]
-        d[m:m + 1000, 0] = rng.normal(size=1000) * 1e-9
-        d[m + 1000:m + 2000, 0] = d[m + 1000:m + 2000, 2] * rng.choice([1.0, -1.0], 1000)
-        d[m + 2000:m + 3000, 0] = 0.0
-        d[m + 3000:m + 4000, 2] = 0.0
-        pts = np.ascontiguousarray(np.asarray(centre)[None, :] + abs(radius) * d * (1.0 + rng.normal(size=(n, 1)) * 1e-9))
+        pts, m4 = texel_points.points(rng, n, w, h, h_off, radius, centre)
         out = np.zeros((n, 5), np.uint64)
         hostsim.hostsim_texels(pts.ctypes.data, n, dvec(*centre, radius), h_off, w, h, out.ctypes.data)
         ok = out[:, 0] == 1
         wrong += int((ok & ((out[:, 1] != out[:, 3]) | (out[:, 2] != out[:, 4]))).sum())
-        refused += int((~ok[m + 4000:]).sum())   # of the un-aimed, uniformly distributed directions
-        total += n - (m + 4000)
+        refused += int((~ok[m4:]).sum())   # of the un-aimed, uniformly distributed directions
+        total += n - m4
     assert wrong == 0, f"{wrong} of {total} fast texels differ from the exact path"
     # ... and it takes practically every ordinary hit point (a boundary band is 4e-12 of a texel wide)
     assert refused < 1e-4 * total, (refused, total)
