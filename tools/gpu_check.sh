@@ -29,6 +29,20 @@ if [[ " $* " == *" pmc "* ]]; then
   python tools/pmc_summary.py $OUT > $OUT/pmc_summary.json 2>$OUT/pmc_summary.err; stamp pmc_summary $?
   cat $OUT/pmc_summary.json
 fi
+if [[ " $* " == *" pmcs "* ]]; then
+  # counters of the configs where the memory system takes part: textures (cfg3), tables in L2 (cfg5), the lit test scene (cfg1)
+  timeout 1500 bash tools/pmc_scene.sh "${RT_TAG:-rXX}" cfg1=scenes/cfg1_test_800x600_spp16.json cfg3=scenes/cfg3_cover_4k_textured.json cfg5=procedural:50:2048 > $OUT/pmcs.log 2>&1; stamp pmcs $?
+  grep -E "^cfg[0-9] (\{|pass)" $OUT/pmcs.log | cut -c1-400
+fi
+if [[ " $* " == *" group "* ]]; then
+  # the product's multi-GPU path in ONE process (bench.py --gpus N without torchrun), ranks sharing this box's GPU
+  RT_GPUS_EMULATE=1 timeout 300 python bench.py --gpus 4 --steps 5 --warmup 2 > $OUT/bench_group4.log 2>$OUT/bench_group4.err; stamp bench_group4 $?
+  tail -1 $OUT/bench_group4.log | cut -c1-1500
+  RT_GPUS_EMULATE=1 timeout 300 python bench.py --gpus 8 --steps 5 --warmup 2 > $OUT/bench_group8.log 2>$OUT/bench_group8.err; stamp bench_group8 $?
+  tail -1 $OUT/bench_group8.log | cut -c1-1500
+  timeout 120 python bench.py --gpus 8 --steps 2 --warmup 1 > $OUT/bench_group8_refused.log 2>/dev/null; stamp bench_group8_refused $?
+  tail -1 $OUT/bench_group8_refused.log | cut -c1-400
+fi
 if [[ " $* " == *" configs "* ]]; then
   {
     echo "# full-size runs of every BASELINE config, current kernel"
