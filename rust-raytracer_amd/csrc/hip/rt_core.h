@@ -129,7 +129,8 @@ struct DevScene {
   uint32_t width, height, spp, max_depth;
   uint32_t sky_mode, n_spheres, n_lights, n_pairs;
   uint32_t seed_lo, seed_hi;
-  uint32_t pad0, pad1;
+  uint32_t light_pool_slots;  // lit scenes, pooled kernels: records in the workgroup's pool of light frames (LightState<true, true>)
+  uint32_t pad1;
   double cam_origin[3], cam_ll[3], cam_h[3], cam_v[3];
   double wm1, hm1, inv_wm1, inv_hm1, height_d;  // (width-1), (height-1), their RN reciprocals (0: slow divide), height
   const SphereGeom* geom;
@@ -921,30 +922,96 @@ struct LightParked {
   V3 saved_d;
 };
 static_assert(sizeof(LightParked) == 80, "parked light state is 80 B per lane");
-template <bool HAS_LIGHTS>
+// Where a lane's active frame lives:
+//   direct (POOLED = false): `pk`, one record per lane — the host simulator's local; the kernel's per-lane LDS record
+//     when the workgroup's LDS has room for 1024 of them beside the scene tables (small scenes: the reference's test_scene);
+//   pooled: 80 KB of per-lane records would push a cover-sized scene's tables out of LDS (gathers from L2 instead: 5.9
+//     instead of 8.9 Gsamples/s) although only the ~6 % of lanes that are summing over the lights at any moment use
+//     theirs.  So the workgroup shares a POOL of records in LDS (as many as fit beside the tables): a record is taken
+//     (bitmap, one LDS atomic) when a camera-path hit starts sampling the lights and given back when that activation
+//     returns to the camera path.  A lane that finds the pool exhausted does NOT shade its hit: it leaves its ray as it
+//     is and traces the same segment again in the next iteration (every draw is addressed by counter, so the repeat
+//     decides the same; the holders of records never wait, so records keep coming back).  The host only picks this form
+//     when the pool is 1.5 x the expected demand (rt_hip_api.hip), so a repeat is rare.
+//     The pool sits at a FIXED offset of the kernel's dynamic LDS ([128-byte bitmap][records]; rt_kernel.hip's layout
+//     asserts it) and its size travels in DevScene.light_pool_slots, so a lane carries one dword for it: the LDS byte
+//     offset of its record, 0 while it holds none.
+constexpr uint32_t LIGHT_POOL_LDS_OFF = 65824u;      // = rt_kernel.hip lds_layout().park_off
+constexpr uint32_t LIGHT_POOL_BITMAP_BYTES = 128u;   // 1024 slots at most
+constexpr uint32_t LIGHT_POOL_MAX_SLOTS = 1024u;
+#if defined(__HIP_DEVICE_COMPILE__)
+extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds_dyn[];  // the kernel's dynamic LDS (aliases its own declaration)
+#endif
+template <bool HAS_LIGHTS, bool POOLED = false>
 struct LightState {};
 template <>
-struct LightState<true> {
+struct LightState<true, false> {
   LightParked* pk;
   LightStack<true>* stack; // levels 0..top-1: touched only when a light ray's own hit starts sampling the lights again
                            // (probability 0.1 n_lights) and when that nested activation returns
   int top;
 };
+template <>
+struct LightState<true, true> {
+  LightStack<true>* stack;
+  uint32_t where;          // LDS byte offset of the lane's pool record while it is summing over the lights, else 0
+  uint32_t repeats;        // segments traced again because the pool was exhausted (subtracted from the segment count)
+  int top;
+};
+RT_HD LightParked& light_frame(LightState<true, false>& ls) { return *ls.pk; }
+RT_HD bool light_frame_acquire(LightState<true, false>&, uint32_t, uint32_t) { return true; }
+RT_HD void light_frame_release(LightState<true, false>&) {}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ LightParked& light_frame(LightState<true, true>& ls) { return *reinterpret_cast<LightParked*>(rt_lds_dyn + ls.where); }
+// a camera-path hit starts summing over the lights: take a pool record (n_slots of them, a multiple of 32); false: none free
+__device__ __forceinline__ bool light_frame_acquire(LightState<true, true>& ls, uint32_t n_slots, uint32_t seed) {
+  uint32_t* const bitmap = reinterpret_cast<uint32_t*>(rt_lds_dyn + LIGHT_POOL_LDS_OFF);
+  const uint32_t words = n_slots >> 5;
+  uint32_t w = ((seed * 2654435761u) >> 16) % words;
+  for (uint32_t tries = 0; tries < words; ++tries) {
+    uint32_t cur = __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (cur != 0xFFFFFFFFu) {
+      const uint32_t b = (uint32_t)__builtin_ctz(~cur);
+      const uint32_t old = __hip_atomic_fetch_or(&bitmap[w], 1u << b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (!((old >> b) & 1u)) { ls.where = LIGHT_POOL_LDS_OFF + LIGHT_POOL_BITMAP_BYTES + ((w << 5) + b) * (uint32_t)sizeof(LightParked); return true; }
+      cur = old | (1u << b);
+    }
+    w = w + 1u == words ? 0u : w + 1u;
+  }
+  ls.repeats++;
+  return false;
+}
+// ... and that activation is back on the camera path: give the record back (after the last read of it)
+__device__ __forceinline__ void light_frame_release(LightState<true, true>& ls) {
+  const uint32_t slot = (ls.where - LIGHT_POOL_LDS_OFF - LIGHT_POOL_BITMAP_BYTES) / (uint32_t)sizeof(LightParked);
+  uint32_t* const bitmap = reinterpret_cast<uint32_t*>(rt_lds_dyn + LIGHT_POOL_LDS_OFF);
+  __hip_atomic_fetch_and(&bitmap[slot >> 5], ~(1u << (slot & 31u)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  ls.where = 0u;
+}
+#else  // (host passes: the pooled kernel exists on the device only; the host simulator runs the direct form)
+inline LightParked& light_frame(LightState<true, true>&) { static LightParked never; return never; }
+inline bool light_frame_acquire(LightState<true, true>&, uint32_t, uint32_t) { return true; }
+inline void light_frame_release(LightState<true, true>&) {}
+#endif
+template <bool HL, bool P> RT_HD uint32_t light_repeats(const LightState<HL, P>&) { return 0u; }
+RT_HD uint32_t light_repeats(const LightState<true, true>& ls) { return ls.repeats; }
 
-RT_HD void light_frame_push(LightState<true>& ls) {  // stack[top] <- cur; ++top
+template <bool P>
+RT_HD void light_frame_push(LightState<true, P>& ls) {  // stack[top] <- cur; ++top
   const int t = ls.top;
   LightStack<true>& k = *ls.stack;
-  const LightFrame& c = ls.pk->cur;
+  const LightFrame& c = light_frame(ls).cur;
   k.P[t][0] = c.P.x; k.P[t][1] = c.P.y; k.P[t][2] = c.P.z;
   k.a[t][0] = c.a[0]; k.a[t][1] = c.a[1]; k.a[t][2] = c.a[2];
   k.a[t][3] = c.acc[0]; k.a[t][4] = c.acc[1]; k.a[t][5] = c.acc[2];
   k.j[t][0] = c.j; k.j[t][1] = c.node;
   ls.top = t + 1;
 }
-RT_HD void light_frame_pop(LightState<true>& ls) {  // --top; cur <- stack[top]
+template <bool P>
+RT_HD void light_frame_pop(LightState<true, P>& ls) {  // --top; cur <- stack[top]
   const int t = ls.top - 1;
   const LightStack<true>& k = *ls.stack;
-  LightFrame& c = ls.pk->cur;
+  LightFrame& c = light_frame(ls).cur;
   c.P.x = k.P[t][0]; c.P.y = k.P[t][1]; c.P.z = k.P[t][2];
   c.a[0] = k.a[t][0]; c.a[1] = k.a[t][1]; c.a[2] = k.a[t][2];
   c.acc[0] = k.a[t][3]; c.acc[1] = k.a[t][4]; c.acc[2] = k.a[t][5];
@@ -954,8 +1021,11 @@ RT_HD void light_frame_pop(LightState<true>& ls) {  // --top; cur <- stack[top]
 // Lane setup: `stk` and `*pk` must outlive the lane.
 template <class LaneT> RT_HD void lane_attach_light_state(LaneT&, LightStack<false>&, LightParked*) {}
 template <class LaneT> RT_HD void lane_attach_light_state(LaneT& L, LightStack<true>& stk, LightParked* pk) { L.ls.stack = &stk; L.ls.pk = pk; L.ls.top = 0; }
+template <class LaneT> RT_HD void lane_attach_light_pool(LaneT& L, LightStack<true>& stk) {
+  L.ls.stack = &stk; L.ls.where = 0u; L.ls.repeats = 0u; L.ls.top = 0;
+}
 
-template <bool HAS_LIGHTS, bool SIMPLE = false>
+template <bool HAS_LIGHTS, bool SIMPLE = false, bool POOLED = false>
 struct Lane {
   static constexpr bool kLights = HAS_LIGHTS;
   V3 o, d;        // current ray
@@ -966,7 +1036,7 @@ struct Lane {
   FwdT<SIMPLE> fwd;
   float val[3];   // radiance of the sample that just finished (valid when lane_shade returned true)
   RngAddr ra;
-  LightState<HAS_LIGHTS> ls;
+  LightState<HAS_LIGHTS, POOLED> ls;
   // counters
   uint32_t n_segments, n_exact, n_tex_oob;
 };
@@ -1049,9 +1119,9 @@ RT_HD bool lane_continue_main(const DevScene& sc, LaneT& L, V3 point, V3 out_dir
 }
 
 // aim the current ray at light j of frame `top` (raytracer.rs:104-106)
-template <class Tables>
-RT_HD void lane_aim_light(const DevScene& sc, const Tables& tb, Lane<true>& L) {
-  LightFrame& f = L.ls.pk->cur;
+template <class Tables, class LaneT>
+RT_HD void lane_aim_light(const DevScene& sc, const Tables& tb, LaneT& L) {
+  LightFrame& f = light_frame(L.ls).cur;
   const SphereGeom lg = tb.geom(sc.lights[f.j]);
   L.o = f.P;
   L.d = sub(v3(lg.cx, lg.cy, lg.cz), f.P);
@@ -1059,17 +1129,20 @@ RT_HD void lane_aim_light(const DevScene& sc, const Tables& tb, Lane<true>& L) {
   L.in_light = 1;
 }
 // a nested light ray produced colour tc: hand it to its parent activation(s) (:107-113)
-template <class Tables>
-RT_HD bool lane_light_return(const DevScene& sc, const Tables& tb, Lane<true>& L, Rgb tc) {
+template <class Tables, class LaneT>
+RT_HD bool lane_light_return(const DevScene& sc, const Tables& tb, LaneT& L, Rgb tc) {
   for (;;) {
-    LightFrame& f = L.ls.pk->cur;
+    LightFrame& f = light_frame(L.ls).cur;
     f.acc[0] += f.a[0] * tc.r; f.acc[1] += f.a[1] * tc.g; f.acc[2] += f.a[2] * tc.b;
     f.j += 1;
     if (f.j < sc.n_lights) { lane_aim_light(sc, tb, L); return false; }
     float nl = (float)sc.n_lights;
     float light[3] = {f.acc[0] / nl, f.acc[1] / nl, f.acc[2] / nl};
-    if (L.ls.top == 0)  // back on the camera path: clamp(light + albedo*child), child = scattered ray
-      return lane_continue_main(sc, L, f.P, L.ls.pk->saved_d, light, f.a);
+    if (L.ls.top == 0) {  // back on the camera path: clamp(light + albedo*child), child = scattered ray
+      const bool fin = lane_continue_main(sc, L, f.P, light_frame(L.ls).saved_d, light, f.a);
+      light_frame_release(L.ls);  // (after the last read of the frame)
+      return fin;
+    }
     // a nested activation (max_depth 2, depth 1): its own child is depth 0 = black (:117-122)
     tc = rgb(clamp01(light[0] + f.a[0] * 0.0f), clamp01(light[1] + f.a[1] * 0.0f), clamp01(light[2] + f.a[2] * 0.0f));
     light_frame_pop(L.ls);  // the activation that shot the light ray goes on
@@ -1109,7 +1182,7 @@ RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, d
         U4 w = rng(L.ra, L.node, 0);
         if (u01_53(w.z, w.w) > (1.0 - (double)sc.n_lights * prob)) {
           light_frame_push(L.ls);  // suspend the activation whose light ray this is
-          LightFrame& f = L.ls.pk->cur;
+          LightFrame& f = light_frame(L.ls).cur;
           f.P = h.point; f.a[0] = att[0]; f.a[1] = att[1]; f.a[2] = att[2];
           f.acc[0] = f.acc[1] = f.acc[2] = 0.0f; f.j = 0; f.node = L.node;
           lane_aim_light(sc, tb, L);
@@ -1129,11 +1202,14 @@ RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, d
       double prob = m.kind == RT_MAT_GLASS ? 0.05 : 0.1;
       U4 w = rng(L.ra, L.node, 0);
       if (u01_53(w.z, w.w) > (1.0 - (double)sc.n_lights * prob)) {
+        // (pooled kernels: no record free -> nothing has changed yet, the same segment is traced again)
+        if (!light_frame_acquire(L.ls, sc.light_pool_slots, L.ra.pixel + L.ra.sample)) return false;
         L.ls.top = 0;
-        LightFrame& f = L.ls.pk->cur;
+        LightParked& pk = light_frame(L.ls);
+        LightFrame& f = pk.cur;
         f.P = h.point; f.a[0] = att[0]; f.a[1] = att[1]; f.a[2] = att[2];
         f.acc[0] = f.acc[1] = f.acc[2] = 0.0f; f.j = 0; f.node = L.node;
-        L.ls.pk->saved_d = out_dir;
+        pk.saved_d = out_dir;
         lane_aim_light(sc, tb, L);
         return false;
       }

@@ -61,6 +61,7 @@ struct RtHipScene {
   int order_age = 0;        // frames since the order was last invalidated (geometry / camera / option change)
   int tile_affinity = 1;    // "tile_affinity" option: runs of tiles belong to one XCD's queue (framebuffer lines complete in one L2)
   int order_mode = 2;       // "tile_order" option: 0 top row first, 1 bottom row first, 2 deepest tiles of the previous frame first
+  int light_pool_cap = 0;  // "light_pool" option: cap on the light-frame pool of lit scenes (0 = as many as fit; tests shrink it to force the fall-back)
   int chunk_spp = 0;       // 0 = automatic
   int tile_log2 = -1;      // -1 = automatic; else tiles of 4^k pixels, k = 0..3
   int tile_shape = 0;      // 0: 2^k x 2^k squares (default: 0.9 % faster); 1: runs of 4^k pixels of one scanline (contiguous
@@ -210,6 +211,7 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
   if (!std::strcmp(key, "tile_shape")) { if (value < 0 || value > 3) return fail(RT_ERR_INVALID, "tile_shape must be 0 (square), 1 (scanline runs), 2 (4:1) or 3 (16:1)"); s->tile_shape = (int)value; return RT_OK; }
   if (!std::strcmp(key, "tile_affinity")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_affinity must be 0 (off), 1 (large frames) or 2 (any frame of 8+ runs: tests)"); s->tile_affinity = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
   if (!std::strcmp(key, "tile_order")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_order must be 0, 1 or 2"); s->order_mode = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
+  if (!std::strcmp(key, "light_pool")) { if (value < 0 || value > 1024 || (value != 0 && value < 32)) return fail(RT_ERR_INVALID, "light_pool must be 0 (automatic) or 32..1024"); s->light_pool_cap = (int)value; return RT_OK; }
   if (!std::strcmp(key, "chunk_spp")) { if (value < 0) return fail(RT_ERR_INVALID, "chunk_spp must be >= 0"); s->chunk_spp = (int)value; return RT_OK; }
   if (!std::strcmp(key, "samples_per_pixel") || !std::strcmp(key, "max_depth")) {
     if (value < 0 || value > (int64_t)0xFFFFFFFFll) return fail(RT_ERR_INVALID, std::string(key) + " must be in 0 .. 2^32-1");
@@ -247,11 +249,11 @@ int launch_scan(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb8, void* d_li
 }
 #endif  // RT_WITH_SCAN_KERNEL
 
-template <bool HL, bool SIMPLE, bool LDS>
+template <bool HL, bool SIMPLE, bool LDS, bool POOLED = false>
 int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka, size_t lds_bytes, uint32_t n_items, hipStream_t stream) {
-  auto kern = rtk::rt_megakernel<HL, SIMPLE, LDS>;
+  auto kern = rtk::rt_megakernel<HL, SIMPLE, LDS, POOLED>;
   // the launch configuration of this scene's kernel is worked out once (it costs two runtime calls a frame otherwise)
-  const int key = (HL ? 4 : 0) | (SIMPLE ? 2 : 0) | (LDS ? 1 : 0);
+  const int key = (POOLED ? 8 : 0) | (HL ? 4 : 0) | (SIMPLE ? 2 : 0) | (LDS ? 1 : 0);
   if (s->cfg_key != key || s->cfg_lds != lds_bytes) {
     if (lds_bytes > 48 * 1024) RT_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     int per_cu_q = 0;
@@ -364,10 +366,29 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   ka.chunk_spp = chunk_spp;
   ka.n_chunks = spp ? (spp + chunk_spp - 1) / chunk_spp : 1;
   const uint32_t n_items = ka.n_tiles * ka.n_chunks;
+  // LDS budget.  Tables + tile slots + (lit scenes) one light frame per lane: everything in LDS.  A lit scene whose tables do
+  // not fit beside 1024 light frames (80 KB) keeps its TABLES in LDS and shares a pool of as many frames as still fit —
+  // if that covers 1.5 x the expected demand: a camera path starts summing over the n lights with probability ~0.1 n at
+  // each of its first two hits (raytracer.rs:92-102) and then shoots n light rays, so about f = 0.2 n^2 / (2.9 + 0.2 n^2)
+  // of the lanes hold a frame at any moment (n = 1: 6.5 % = 66 of 1024 lanes; n = 2: 22 %; n = 3: 38 %).  A lane that
+  // finds the pool exhausted repeats its segment (rt_core.h), so an undersized pool is slow, never wrong.  Scenes whose
+  // tables do not fit at all, or with too many lights for the pool, gather the tables from L2 (one frame per lane).
   const rtc::GridDesc& G = ka.sc.grid;
   const rtk::LdsLayout with_tables = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, s->has_lights);
-  const bool lds_tables = with_tables.total <= rtk::LDS_TABLES_MAX_BYTES;
-  const size_t lds_bytes = lds_tables ? with_tables.total : rtk::lds_layout(0, 0, 0, false, s->has_lights).total;
+  bool lds_tables = with_tables.total <= rtk::LDS_TABLES_MAX_BYTES;
+  uint32_t pool_slots = 0;
+  if (!lds_tables && s->has_lights) {
+    const uint32_t bare = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, false).total;
+    uint32_t fit = 0;
+    while (fit + 32u <= rtc::LIGHT_POOL_MAX_SLOTS && bare + rtk::park_bytes(fit + 32u) <= rtk::LDS_TABLES_MAX_BYTES) fit += 32u;
+    const double n = (double)s->dev.n_lights, f = 0.2 * n * n / (2.9 + 0.2 * n * n);
+    const bool forced = s->light_pool_cap > 0;  // ("light_pool" option, tests: any pool of >= 32 records that fits)
+    if (forced && fit > (uint32_t)s->light_pool_cap) fit = (uint32_t)s->light_pool_cap & ~31u;
+    if (fit >= 32u && (forced || (double)fit >= 1.5 * f * (double)rtk::BLOCK)) { pool_slots = fit; lds_tables = true; }
+  }
+  ka.sc.light_pool_slots = pool_slots;
+  const size_t lds_bytes = lds_tables ? rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, s->has_lights, pool_slots).total
+                                      : rtk::lds_layout(0, 0, 0, false, s->has_lights).total;
 
   // queue order: bottom of the image first; from the second frame of a tile geometry on, the tiles whose samples ran
   // deepest in the previous frame first (their paths are what a frame ends on)
@@ -416,7 +437,8 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
 
   RT_HIP_TRY(hipEventRecord(s->ev_start, stream));
   int rc;
-  if (s->has_lights) rc = lds_tables ? launch_grid_t<true, false, true>(s, ka, lds_bytes, n_items, stream) : launch_grid_t<true, false, false>(s, ka, lds_bytes, n_items, stream);
+  if (s->has_lights) rc = pool_slots ? launch_grid_t<true, false, true, true>(s, ka, lds_bytes, n_items, stream)
+                                     : (lds_tables ? launch_grid_t<true, false, true>(s, ka, lds_bytes, n_items, stream) : launch_grid_t<true, false, false>(s, ka, lds_bytes, n_items, stream));
   else if (s->simple_colour) rc = lds_tables ? launch_grid_t<false, true, true>(s, ka, lds_bytes, n_items, stream) : launch_grid_t<false, true, false>(s, ka, lds_bytes, n_items, stream);
   else rc = lds_tables ? launch_grid_t<false, false, true>(s, ka, lds_bytes, n_items, stream) : launch_grid_t<false, false, false>(s, ka, lds_bytes, n_items, stream);
   if (rc != RT_OK) return rc;

@@ -124,12 +124,17 @@ __host__ __device__ inline uint32_t tile_slots(uint32_t tile_log2) {
 struct LdsLayout {
   uint32_t hdr_off, coop_off, park_off, geom_off, matc_off, cell_off, item_off, total;
 };
-__host__ __device__ inline LdsLayout lds_layout(uint32_t n_spheres, uint32_t n_cells, uint32_t n_items, bool tables, bool lights) {
+// light frames (lit scenes): one LightParked per lane (pool_slots == 0), or [bitmap][pool of pool_slots records] (rt_core.h)
+__host__ __device__ constexpr uint32_t park_bytes(uint32_t pool_slots) {
+  return pool_slots ? LIGHT_POOL_BITMAP_BYTES + pool_slots * (uint32_t)sizeof(LightParked) : (uint32_t)BLOCK * (uint32_t)sizeof(LightParked);
+}
+static_assert(LDS_FLAGS_BYTES + LDS_SLOT_BUDGET + WAVES * 64u * 16u == LIGHT_POOL_LDS_OFF || BLOCK != 1024, "rt_core.h LIGHT_POOL_LDS_OFF = park_off of the layout below");
+__host__ __device__ inline LdsLayout lds_layout(uint32_t n_spheres, uint32_t n_cells, uint32_t n_items, bool tables, bool lights, uint32_t pool_slots = 0) {
   LdsLayout l;
   uint32_t o = LDS_FLAGS_BYTES;
   l.hdr_off = o; o += LDS_SLOT_BUDGET;  // [t_slots headers][t_slots x npx x 3 u64 sums], sized by tile_slots()
   l.coop_off = o; o += WAVES * 64u * 16u;  // per wave: 64 x 16 B exchange slots of coop_random_in_unit_sphere
-  l.park_off = o; if (lights) o += (uint32_t)BLOCK * (uint32_t)sizeof(LightParked);  // per lane: rt_core.h LightParked
+  l.park_off = o; if (lights) o += park_bytes(pool_slots);  // rt_core.h LightParked: [records][pool bitmap]
   l.geom_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(SphereGeom);
   l.matc_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(MatCore);
   l.cell_off = o; if (tables) o += n_cells * 8u;
@@ -248,14 +253,15 @@ struct LdsTables {  // per-lane gathers from the workgroup's LDS copies
   __device__ __forceinline__ MatCore mat(uint32_t i) const { return m[i]; }
 };
 
-template <bool HL, bool SIMPLE, bool LDS_TABLES>
+template <bool HL, bool SIMPLE, bool LDS_TABLES, bool POOLED = false>
 __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs ka) {
+  static_assert(!POOLED || (HL && LDS_TABLES), "the light-frame pool exists to keep a lit scene's tables in LDS");
   const DevScene& sc = ka.sc;
   const GridDesc& G = sc.grid;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   RT_PROF_DECL
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const LdsLayout lay = lds_layout(sc.n_spheres, G.n_cells, G.n_items, LDS_TABLES, HL);
+  const LdsLayout lay = lds_layout(sc.n_spheres, G.n_cells, G.n_items, LDS_TABLES, HL, POOLED ? sc.light_pool_slots : 0u);
   uint32_t* const wg_flags = reinterpret_cast<uint32_t*>(lds_raw);  // [0] the frame's tile queue is empty, [1] slot opened last
   SlotHdr* const hdr = reinterpret_cast<SlotHdr*>(lds_raw + lay.hdr_off);
   const uint32_t T = ka.t_slots, acc_stride = 3u << (2u * ka.tile_log2);  // u64 words of pixel sums per slot
@@ -271,6 +277,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   const uint32_t my_xcd = (uint32_t)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;
   unsigned long long* const wg_counters = reinterpret_cast<unsigned long long*>(lds_raw + 32);
   if (threadIdx.x < 32u) wg_counters[threadIdx.x] = 0ull;
+  if constexpr (POOLED) {  // every slot of the light-frame pool is free
+    if (threadIdx.x < LIGHT_POOL_BITMAP_BYTES / 4u) reinterpret_cast<uint32_t*>(lds_raw + LIGHT_POOL_LDS_OFF)[threadIdx.x] = 0u;
+  }
   if constexpr (!LDS_TABLES) __syncthreads();
 
   if constexpr (LDS_TABLES) {  // stage the tables once per (persistent) workgroup
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     cell_word = reinterpret_cast<const uint2*>(sc.cell_word); cell_items = sc.cell_items;
   }
 
-  typedef Lane<HL, SIMPLE> LaneT;
+  typedef Lane<HL, SIMPLE, POOLED> LaneT;
   LaneT L;
   L.s = 0; L.k = 0; L.node = 0; L.in_light = 0;
   L.val[0] = L.val[1] = L.val[2] = 0.0f;
@@ -317,7 +326,11 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   L.o = v3(0, 0, 0); L.d = v3(0, 0, 1);
   fwd_init(L.fwd);
   LightStack<HL> light_stack;
-  lane_attach_light_state(L, light_stack, reinterpret_cast<LightParked*>(lds_raw + lay.park_off) + threadIdx.x);
+  if constexpr (POOLED) {
+    lane_attach_light_pool(L, light_stack);
+  } else {
+    lane_attach_light_state(L, light_stack, reinterpret_cast<LightParked*>(lds_raw + lay.park_off) + threadIdx.x);
+  }
   uint32_t n_segments = 0, n_exact = 0, n_steps = 0;  // per-lane counters (one exec-masked add each)
   uint32_t cnt_w_iter = 0, cnt_w_step = 0, cnt_w_test = 0, cnt_items = 0;  // wave trip counts (RT_PROFILE builds)
 
@@ -819,7 +832,8 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 #endif
 
   // counters: wave reduction, one atomic per wave
-  unsigned long long c0 = n_segments, c1 = n_exact, c2 = L.n_tex_oob, c3 = n_steps;
+  // (a segment repeated because the light-frame pool was exhausted is one segment of the path)
+  unsigned long long c0 = n_segments - light_repeats(L.ls), c1 = n_exact, c2 = L.n_tex_oob, c3 = n_steps;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     c0 += __shfl_down(c0, off); c1 += __shfl_down(c1, off); c2 += __shfl_down(c2, off); c3 += __shfl_down(c3, off);

@@ -40,7 +40,7 @@ def gpu_render(pkg, abi, torch_cuda):
     torch = torch_cuda
 
     def _render(scene, tiles=None, variant=0, want_linear=True, chunk_spp=None, tile_log2=None, tile_order=None, frames=1, tile_shape=None,
-                tile_affinity=None):
+                tile_affinity=None, opts=None):
         """variant 0: the product kernel (grid walk, tile queue, exact fixed-point pixel sums);
         variant 1: same kernel, the reference's brute force over all spheres.  chunk_spp: samples of a
         pixel per work item; tile_log2: pixel tiles of 2^k x 2^k."""
@@ -59,6 +59,8 @@ def gpu_render(pkg, abi, torch_cuda):
             gs.set_option("tile_shape", tile_shape)
         if tile_affinity is not None:
             gs.set_option("tile_affinity", tile_affinity)
+        for k, v in (opts or {}).items():
+            gs.set_option(k, v)
         rgb = torch.zeros((rows, sc.width, 3), dtype=torch.uint8, device="cuda:0")
         lin = torch.zeros((rows, sc.width, 3), dtype=torch.float32, device="cuda:0") if want_linear else None
         for _ in range(frames):   # (frames > 1: the later frames use the queue order learnt from the one before)
@@ -282,10 +284,34 @@ def test_many_lights_nested_sampling(gpu_render, oracle, abi, host):
         assert o_st["segments_discarded"] > 0 and st["segments"] == o_st["segments"] - o_st["segments_discarded"]
 
 
+def test_lit_cover_scene_light_frame_pool(gpu_render, oracle, abi, host):
+    """A lit scene of cover size: 1024 per-lane light frames (80 KB) would push the tables out of LDS, so the workgroup
+    shares a POOL of frames (rt_core.h LightState<true, true>; one light: ~150 records for ~66 in use).  A lane that
+    finds the pool exhausted repeats its segment.  The frame must not depend on any of it: the automatic pool, a pool of
+    32 records (most light-sampling hits repeat, some many times) and — two lights, forced — pools of 64 and 32 all give
+    the oracle's image and exactly the oracle's path count (a repeated segment is counted once)."""
+    cfg = json.load(open(os.path.join(ROOT, "scenes", "cfg2_cover_1200x800_spp128.json")))
+    cfg.update(width=240, height=160, samples_per_pixel=16)
+    cfg["objects"].append({"center": {"x": 0.0, "y": 30.0, "z": 10.0}, "radius": 8.0, "material": {"Light": {}}})
+    one = host.Scene.loads(json.dumps(cfg))
+    cfg["objects"].append({"center": {"x": 3.0, "y": 2.5, "z": 2.0}, "radius": 0.4, "material": {"Light": {}}})
+    two = host.Scene.loads(json.dumps(cfg))
+    for sc, pools in ((one, (0, 32, 96)), (two, (0, 64, 32))):
+        o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+        first = None
+        for pool in pools:
+            rgb, lin, st = gpu_render(sc, opts={"light_pool": pool})
+            assert_parity(rgb, lin, o_rgb, o_lin, f"lit cover, {len(sc.lights())} light(s), pool {pool}", atol=pooled_atol(16))
+            assert st["segments"] == o_st["segments"] - o_st["segments_discarded"], (pool, st["segments"])
+            first = first if first is not None else (rgb, lin)
+            assert np.array_equal(rgb, first[0]) and np.array_equal(lin, first[1]), pool   # and bit-identical to one another
+            print(f"lit cover {len(sc.lights())} light(s) pool {pool}: kernel {st['kernel_ms']:.3f} ms")
+
+
 def test_lit_cover_scene_tables_beside_the_parked_light_state(gpu_render, oracle, abi, host):
-    """lights in a gridded scene: the lit kernel keeps each lane's active light frame in LDS (80 B x 1024 lanes), so the
-    cover scene's tables no longer fit beside it and are read through L2 — and with two lights every fifth hit of depth
-    0/1 samples them.  Same frame as the oracle's, grid or brute force."""
+    """lights in a gridded scene, two of them: every fifth hit of depth 0/1 samples them (with two lights the pool of
+    light frames would be too small: one frame per lane, tables through L2).  Same frame as the oracle's, grid or brute
+    force."""
     cfg = json.load(open(os.path.join(ROOT, "scenes", "cfg2_cover_1200x800_spp128.json")))
     cfg.update(width=96, height=64, samples_per_pixel=8)
     cfg["objects"].append({"center": {"x": 0.0, "y": 30.0, "z": 10.0}, "radius": 8.0, "material": {"Light": {}}})
