@@ -911,6 +911,7 @@ struct LightStack<true> {
   double P[RT_MAX_LIGHT_NEST - 1][3];
   float a[RT_MAX_LIGHT_NEST - 1][6];  // a[0..2], acc[0..2]
   uint32_t j[RT_MAX_LIGHT_NEST - 1][2];  // j, node
+  float base[6];  // lit scenes with every albedo in [0, 1]: p[3], h[3] of the sample's colour map once a light contributed (lane_compose)
 };
 // The activation summing over the lights right now (nesting level `top`; 0 = the camera-path hit), and the camera
 // path's scattered direction to resume with.  Touched a few times per light-sampling hit (about 4 % of the segments of
@@ -955,7 +956,6 @@ template <>
 struct LightState<true, true> {
   LightStack<true>* stack;
   uint32_t where;          // LDS byte offset of the lane's pool record while it is summing over the lights, else 0
-  uint32_t repeats;        // segments traced again because the pool was exhausted (subtracted from the segment count)
   int top;
 };
 RT_HD LightParked& light_frame(LightState<true, false>& ls) { return *ls.pk; }
@@ -978,7 +978,6 @@ __device__ __forceinline__ bool light_frame_acquire(LightState<true, true>& ls, 
     }
     w = w + 1u == words ? 0u : w + 1u;
   }
-  ls.repeats++;
   return false;
 }
 // ... and that activation is back on the camera path: give the record back (after the last read of it)
@@ -993,8 +992,6 @@ inline LightParked& light_frame(LightState<true, true>&) { static LightParked ne
 inline bool light_frame_acquire(LightState<true, true>&, uint32_t, uint32_t) { return true; }
 inline void light_frame_release(LightState<true, true>&) {}
 #endif
-template <bool HL, bool P> RT_HD uint32_t light_repeats(const LightState<HL, P>&) { return 0u; }
-RT_HD uint32_t light_repeats(const LightState<true, true>& ls) { return ls.repeats; }
 
 template <bool P>
 RT_HD void light_frame_push(LightState<true, P>& ls) {  // stack[top] <- cur; ++top
@@ -1022,17 +1019,18 @@ RT_HD void light_frame_pop(LightState<true, P>& ls) {  // --top; cur <- stack[to
 template <class LaneT> RT_HD void lane_attach_light_state(LaneT&, LightStack<false>&, LightParked*) {}
 template <class LaneT> RT_HD void lane_attach_light_state(LaneT& L, LightStack<true>& stk, LightParked* pk) { L.ls.stack = &stk; L.ls.pk = pk; L.ls.top = 0; }
 template <class LaneT> RT_HD void lane_attach_light_pool(LaneT& L, LightStack<true>& stk) {
-  L.ls.stack = &stk; L.ls.where = 0u; L.ls.repeats = 0u; L.ls.top = 0;
+  L.ls.stack = &stk; L.ls.where = 0u; L.ls.top = 0;
 }
 
 template <bool HAS_LIGHTS, bool SIMPLE = false, bool POOLED = false>
 struct Lane {
   static constexpr bool kLights = HAS_LIGHTS;
+  static constexpr bool kSimple = SIMPLE;
   V3 o, d;        // current ray
   uint32_t node;  // RNG node of the current ray
   uint32_t k;     // camera-path segment index of the current (or suspended) camera ray
   uint32_t s;     // current sample
-  uint32_t in_light;  // 1 while the current ray is a nested light ray
+  uint32_t in_light;  // bit 0: the current ray is a nested light ray; bit 1 (LANE_HAS_BASE): the sample's colour map has a base (lane_compose)
   FwdT<SIMPLE> fwd;
   float val[3];   // radiance of the sample that just finished (valid when lane_shade returned true)
   RngAddr ra;
@@ -1066,13 +1064,63 @@ RT_HD void lane_begin_sample(const DevScene& sc, LaneT& L, uint32_t px, uint32_t
   lane_begin_sample_w(sc, L, px, py, rng(L.ra, NODE_CAMERA, 0));
 }
 
+// ---- the colour map of LIT scenes whose albedos all lie in [0, 1] (Lane<true, true, *>) ------------------------------
+// With a, L >= 0 every level is f(x) = min(1, L + a x), and the composition is G(x) = min(h, p + q x) — FwdT<false>'s
+// (p, q, hi); its `lo` never binds (lo <= p by induction, and fl(p + q x) >= p).  Only the first two levels of a sample can
+// carry light (raytracer.rs:99-102), so:
+//   * a sample that never sampled the lights has p = 0 and h >= q: G(x) = q x — the three floats of the unlit map;
+//   * once a light contributed, (p, h) — the BASE — are final after level 1: later levels only multiply q (p + q*0 = p,
+//     and their h-terms fl(p + q_j) >= fl(p + fl(q x)) cannot bind).
+// So the lane keeps q[3] in registers like an unlit lane, and the base — written at most twice per sample and read once
+// when the sample ends, for ~20 % of the samples of a one-light scene — lives in memory (LightStack::base), not in nine
+// registers the 128-register kernel does not have (the general map cost the lit kernels 30 spilled registers, some
+// reloaded inside the walk loop).  Bit-identical to FwdT<false> (tests/test_core_cpu.py).
+constexpr uint32_t LANE_HAS_BASE = 2u;
+template <class LaneT>
+RT_HD void lane_compose(LaneT& L, const float light[3], const float att[3], bool has_light) {
+  if constexpr (LaneT::kLights && LaneT::kSimple) {
+    if (has_light) {  // level L.k (0 or 1) contributes `light`: create / update the base
+      float* b = L.ls.stack->base;
+      float p[3], h[3];
+      if (L.in_light & LANE_HAS_BASE) { p[0] = b[0]; p[1] = b[1]; p[2] = b[2]; h[0] = b[3]; h[1] = b[4]; h[2] = b[5]; }
+      else { p[0] = p[1] = p[2] = 0.0f; h[0] = h[1] = h[2] = 3.4028234663852886e38f; }  // (a level 0 without light before this one: its h-term 0 + 1 >= q)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float g1 = p[i] + L.fwd.q[i] * 1.0f;
+        h[i] = g1 < h[i] ? g1 : h[i];
+        p[i] = p[i] + L.fwd.q[i] * light[i];
+        L.fwd.q[i] = L.fwd.q[i] * att[i];
+      }
+      b[0] = p[0]; b[1] = p[1]; b[2] = p[2]; b[3] = h[0]; b[4] = h[1]; b[5] = h[2];
+      L.in_light |= LANE_HAS_BASE;
+    } else {
+      fwd_compose(L.fwd, light, att);
+    }
+  } else {
+    (void)has_light;
+    fwd_compose(L.fwd, light, att);
+  }
+}
 // the sample's radiance is known: fold the leaf colour through the forward map.  The caller
 // adds L.val to the pixel (raytracer.rs:203-205) and picks the lane's next sample.
 template <class LaneT>
 RT_HD void lane_finish_sample(LaneT& L, Rgb leaf) {
-  L.val[0] = fwd_eval1(L.fwd, 0, leaf.r);
-  L.val[1] = fwd_eval1(L.fwd, 1, leaf.g);
-  L.val[2] = fwd_eval1(L.fwd, 2, leaf.b);
+  const float x[3] = {leaf.r, leaf.g, leaf.b};
+  if constexpr (LaneT::kLights && LaneT::kSimple) {
+    if (L.in_light & LANE_HAS_BASE) {
+      const float* b = L.ls.stack->base;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float y = b[i] + L.fwd.q[i] * x[i];
+        y = y > b[3 + i] ? b[3 + i] : y;
+        L.val[i] = y;
+      }
+      return;
+    }
+  }
+  L.val[0] = fwd_eval1(L.fwd, 0, x[0]);
+  L.val[1] = fwd_eval1(L.fwd, 1, x[1]);
+  L.val[2] = fwd_eval1(L.fwd, 2, x[2]);
 }
 
 // Pooled-sample mode: lanes of a wave take (pixel, sample) items from a shared counter, so
@@ -1110,11 +1158,11 @@ RT_HD float rt_nanf() {
 // compose clamp(light + albedo*child) and step to the scattered ray.  Returns true when the
 // sample finished (depth exhausted: the child is ray_color(.., depth 0) = black, :80-82).
 template <class LaneT>
-RT_HD bool lane_continue_main(const DevScene& sc, LaneT& L, V3 point, V3 out_dir, const float light[3], const float att[3]) {
-  fwd_compose(L.fwd, light, att);
+RT_HD bool lane_continue_main(const DevScene& sc, LaneT& L, V3 point, V3 out_dir, const float light[3], const float att[3], bool has_light = false) {
+  lane_compose(L, light, att, has_light);
   L.k += 1;
   if (L.k >= sc.max_depth) { lane_finish_sample(L, rgb(0.0f, 0.0f, 0.0f)); return true; }
-  L.o = point; L.d = out_dir; L.node = L.k; L.in_light = 0;
+  L.o = point; L.d = out_dir; L.node = L.k; L.in_light &= ~1u;
   return false;
 }
 
@@ -1126,7 +1174,7 @@ RT_HD void lane_aim_light(const DevScene& sc, const Tables& tb, LaneT& L) {
   L.o = f.P;
   L.d = sub(v3(lg.cx, lg.cy, lg.cz), f.P);
   L.node = child_node(f.node, f.j);
-  L.in_light = 1;
+  L.in_light |= 1u;
 }
 // a nested light ray produced colour tc: hand it to its parent activation(s) (:107-113)
 template <class Tables, class LaneT>
@@ -1139,7 +1187,7 @@ RT_HD bool lane_light_return(const DevScene& sc, const Tables& tb, LaneT& L, Rgb
     float nl = (float)sc.n_lights;
     float light[3] = {f.acc[0] / nl, f.acc[1] / nl, f.acc[2] / nl};
     if (L.ls.top == 0) {  // back on the camera path: clamp(light + albedo*child), child = scattered ray
-      const bool fin = lane_continue_main(sc, L, f.P, light_frame(L.ls).saved_d, light, f.a);
+      const bool fin = lane_continue_main(sc, L, f.P, light_frame(L.ls).saved_d, light, f.a, true);
       light_frame_release(L.ls);  // (after the last read of the frame)
       return fin;
     }
@@ -1158,7 +1206,7 @@ RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, d
   if (idx < 0) {  // raytracer.rs:133-163
     Rgb sky = sky_color(sc, L.d, L.n_tex_oob);
     if constexpr (HL) {
-      if (L.in_light) return lane_light_return(sc, tb, L, sky);
+      if (L.in_light & 1u) return lane_light_return(sc, tb, L, sky);
     }
     lane_finish_sample(L, sky);
     return true;
@@ -1172,7 +1220,7 @@ RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, d
   const float zero3[3] = {0.0f, 0.0f, 0.0f};
 
   if constexpr (HL) {
-    if (L.in_light) {
+    if (L.in_light & 1u) {
       // nested activation ray_color(light_ray, 2, 1) at nesting level top+1
       if (st == SCATTER_EMIT) return lane_light_return(sc, tb, L, rgb(att[0], att[1], att[2]));  // :124
       if (st == SCATTER_ABSORBED) return lane_light_return(sc, tb, L, rgb(0.f, 0.f, 0.f));        // :127-131
@@ -1202,8 +1250,8 @@ RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, d
       double prob = m.kind == RT_MAT_GLASS ? 0.05 : 0.1;
       U4 w = rng(L.ra, L.node, 0);
       if (u01_53(w.z, w.w) > (1.0 - (double)sc.n_lights * prob)) {
-        // (pooled kernels: no record free -> nothing has changed yet, the same segment is traced again)
-        if (!light_frame_acquire(L.ls, sc.light_pool_slots, L.ra.pixel + L.ra.sample)) return false;
+        // (pooled kernels: no record free -> nothing has changed yet: the same segment is traced again, and counted once)
+        if (!light_frame_acquire(L.ls, sc.light_pool_slots, L.ra.pixel + L.ra.sample)) { L.n_segments--; return false; }
         L.ls.top = 0;
         LightParked& pk = light_frame(L.ls);
         LightFrame& f = pk.cur;

@@ -437,10 +437,16 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
 
   RT_HIP_TRY(hipEventRecord(s->ev_start, stream));
   int rc;
-  if (s->has_lights) rc = pool_slots ? launch_grid_t<true, false, true, true>(s, ka, lds_bytes, n_items, stream)
-                                     : (lds_tables ? launch_grid_t<true, false, true>(s, ka, lds_bytes, n_items, stream) : launch_grid_t<true, false, false>(s, ka, lds_bytes, n_items, stream));
-  else if (s->simple_colour) rc = lds_tables ? launch_grid_t<false, true, true>(s, ka, lds_bytes, n_items, stream) : launch_grid_t<false, true, false>(s, ka, lds_bytes, n_items, stream);
-  else rc = lds_tables ? launch_grid_t<false, false, true>(s, ka, lds_bytes, n_items, stream) : launch_grid_t<false, false, false>(s, ka, lds_bytes, n_items, stream);
+  // instantiation = (lights, every albedo in [0, 1], tables in LDS, light-frame pool)
+#define RT_GO(HL, SIMPLE, LDS, POOLED) rc = launch_grid_t<HL, SIMPLE, LDS, POOLED>(s, ka, lds_bytes, n_items, stream)
+  const bool simple = s->simple_colour;
+  if (s->has_lights) {
+    if (pool_slots) { if (simple) RT_GO(true, true, true, true); else RT_GO(true, false, true, true); }
+    else if (lds_tables) { if (simple) RT_GO(true, true, true, false); else RT_GO(true, false, true, false); }
+    else { if (simple) RT_GO(true, true, false, false); else RT_GO(true, false, false, false); }
+  } else if (lds_tables) { if (simple) RT_GO(false, true, true, false); else RT_GO(false, false, true, false); }
+  else { if (simple) RT_GO(false, true, false, false); else RT_GO(false, false, false, false); }
+#undef RT_GO
   if (rc != RT_OK) return rc;
   RT_HIP_TRY(hipGetLastError());
   RT_HIP_TRY(hipEventRecord(s->ev_stop, stream));

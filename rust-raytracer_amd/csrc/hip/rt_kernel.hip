@@ -331,7 +331,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   } else {
     lane_attach_light_state(L, light_stack, reinterpret_cast<LightParked*>(lds_raw + lay.park_off) + threadIdx.x);
   }
-  uint32_t n_segments = 0, n_exact = 0, n_steps = 0;  // per-lane counters (one exec-masked add each)
+  uint32_t n_exact = 0, n_steps = 0;  // per-lane counters (one exec-masked add each; the segments are counted in L.n_segments)
   uint32_t cnt_w_iter = 0, cnt_w_step = 0, cnt_w_test = 0, cnt_items = 0;  // wave trip counts (RT_PROFILE builds)
 
   RT_PROF(5);  // staging of the tables into LDS (+ item bookkeeping later)
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     const RayK rk = ray_consts(L.d);
     closest = T_MAX;
     best = -1;
-    if (has_ray) n_segments++;
+    if (has_ray) L.n_segments++;
     // (1) spheres outside the grid: every lane tests them.  The records are wave-uniform, so they
     // arrive by scalar loads as SGPR operands; the next record is fetched while this one is tested.
     if (n_large != 0u) {
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     RT_PROF(3);
     // (a) a ray that left the scene ends its sample here (raytracer.rs:133-163); light rays return to their parent in (d)
     bool miss = has_ray && best < 0;
-    if constexpr (HL) miss = miss && !L.in_light;
+    if constexpr (HL) miss = miss && !(L.in_light & 1u);
     const uint32_t k_miss = my_k;
     if (wave_any(miss)) {
       if (miss) {
@@ -832,8 +832,8 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 #endif
 
   // counters: wave reduction, one atomic per wave
-  // (a segment repeated because the light-frame pool was exhausted is one segment of the path)
-  unsigned long long c0 = n_segments - light_repeats(L.ls), c1 = n_exact, c2 = L.n_tex_oob, c3 = n_steps;
+  // (L.n_segments: a segment repeated because the light-frame pool was exhausted is one segment of the path, rt_core.h)
+  unsigned long long c0 = L.n_segments, c1 = n_exact, c2 = L.n_tex_oob, c3 = n_steps;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     c0 += __shfl_down(c0, off); c1 += __shfl_down(c1, off); c2 += __shfl_down(c2, off); c3 += __shfl_down(c3, off);

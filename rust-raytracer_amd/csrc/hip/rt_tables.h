@@ -21,7 +21,7 @@ struct HostTables {
   std::vector<uint64_t> tex_off;  // per RtTexture, byte offset in the blob
   uint64_t tex_bytes = 0;
   uint32_t n_pairs = 0;           // real pairs (cull.size() includes chunk padding)
-  bool simple_colour = true;  // no lights and every albedo in [0,1]
+  bool simple_colour = true;  // every albedo in [0,1] (textures always are): the short colour maps of rt_core.h apply
   // hit_world acceleration (GridDesc, rt_core.h)
   std::vector<MatCore> matc;
   GridDesc grid{};
@@ -276,7 +276,6 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
     CullPair& cp = t.cull[n / 2];
     cp.cx[1] = cp.cx[0]; cp.cy[1] = cp.cy[0]; cp.cz[1] = cp.cz[0]; cp.R[1] = -INFINITY;
   }
-  if (!t.lights.empty()) t.simple_colour = false;
   auto pack_large = [&]() {
     t.large_geom.resize(t.large.size());
     for (size_t i = 0; i < t.large.size(); ++i) t.large_geom[i] = t.geom[t.large[i]];

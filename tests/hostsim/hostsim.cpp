@@ -16,7 +16,7 @@ using namespace rtc;
 
 namespace {
 unsigned long long* g_hist = nullptr;  // [0..63] steps per segment, [64..127] exact tests per segment, [128..] path lengths (diagnostics; 512 entries)
-template <bool HL>
+template <bool HL, bool SHORT_MAP = false>
 void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, const RtRowTiles* tiles, uint8_t* rgb8,
                  float* linear, RtStats* stats, int use_cull_flags) {
   const int use_cull = use_cull_flags & 15;
@@ -27,7 +27,7 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
   for (uint32_t lr = 0; lr < rows; ++lr) {
     const uint32_t y = rt_tiles_global_row(tiles, lr);
     for (uint32_t x = 0; x < sc.width; ++x) {
-      Lane<HL> L;
+      Lane<HL, SHORT_MAP> L;
       std::memset(&L, 0, sizeof L);
       LightStack<HL> light_stack;
       LightParked light_parked;
@@ -133,6 +133,7 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
 //           3 = grid walk (the default kernel's hit_world); stats->grid_steps = DDA steps
 //           4 = grid walk audited against brute force per segment (stats->kernel_ms = mismatches)
 //           +16 = accumulate pixels in exact fixed point (the pooled-sample kernels' rule)
+//           +32 = the short colour maps (scenes whose albedos all lie in [0, 1]; ignored otherwise)
 extern "C" int hostsim_render(const RtScene* scene, const RtRowTiles* tiles, uint8_t* rgb8, float* linear,
                               RtStats* stats, int use_cull) {
   HostTables t;
@@ -145,8 +146,12 @@ extern "C" int hostsim_render(const RtScene* scene, const RtRowTiles* tiles, uin
   ds.geom = t.geom.data(); ds.mat = t.mat.data(); ds.cull = t.cull.data(); ds.lights = t.lights.data();
   ds.tex = blob.data(); ds.sky = scene->sky_rgb8;
   ds.matc = t.matc.data(); ds.cell_word = t.cell_word.data(); ds.cell_items = t.cell_items.data(); ds.large = t.large.data(); ds.large_geom = t.large_geom.data();
-  if (t.lights.empty()) render_rows<false>(*scene, t, ds, tiles, rgb8, linear, stats, use_cull);
-  else render_rows<true>(*scene, t, ds, tiles, rgb8, linear, stats, use_cull);
+  // +32: the SHORT colour maps the product kernel takes when every albedo lies in [0, 1] (rt_core.h FwdT<true>; lit scenes:
+  // q in registers + the memory-resident base of lane_compose) instead of the general clamped-affine map — bit-identical
+  const bool short_map = (use_cull & 32) != 0 && t.simple_colour;
+  use_cull &= ~32;
+  if (t.lights.empty()) { if (short_map) render_rows<false, true>(*scene, t, ds, tiles, rgb8, linear, stats, use_cull); else render_rows<false>(*scene, t, ds, tiles, rgb8, linear, stats, use_cull); }
+  else { if (short_map) render_rows<true, true>(*scene, t, ds, tiles, rgb8, linear, stats, use_cull); else render_rows<true>(*scene, t, ds, tiles, rgb8, linear, stats, use_cull); }
   return RT_OK;
 }
 

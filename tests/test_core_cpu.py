@@ -76,6 +76,37 @@ def test_adversarial_sphere_records(hostsim, oracle, abi, host, seed):
     assert st["kernel_ms"] == 0.0 and st["grid_steps"] > 0
 
 
+def _many_lights_scene(host, n_lights=3, w=64, h=40, spp=16, depth=6):
+    objs = ['{"center":{"x":0.0,"y":-100.5,"z":-1.0},"radius":100.0,"material":{"Lambertian":{"albedo":[0.7,0.7,0.7]}}}']
+    for i, x in enumerate((-2.0, 0.0, 2.0)[:n_lights]):
+        objs.append('{"center":{"x":%f,"y":2.5,"z":-2.0},"radius":0.5,"material":{"Light":{}}}' % x)
+        objs.append('{"center":{"x":%f,"y":0.0,"z":-1.5},"radius":0.5,"material":{"%s}}' %
+                    (x, ['Lambertian":{"albedo":[0.9,0.2,0.2]}', 'Glass":{"index_of_refraction":1.5}', 'Metal":{"albedo":[0.8,0.8,0.9],"fuzz":0.2}'][i]))
+        objs.append('{"center":{"x":%f,"y":1.2,"z":-1.8},"radius":0.3,"material":{"Lambertian":{"albedo":[1.0,0.9,0.4]}}}' % x)
+    text = ('{"width":%d,"height":%d,"samples_per_pixel":%d,"max_depth":%d,"sky":{"texture":""},"camera":{"look_from":{"x":0.0,"y":1.0,"z":3.0},'
+            '"look_at":{"x":0.0,"y":0.5,"z":-1.0},"vup":{"x":0.0,"y":1.0,"z":0.0},"vfov":60.0,"aspect":1.6},"objects":[' % (w, h, spp, depth) + ",".join(objs) + "]}")
+    return host.Scene.loads(text)
+
+
+def test_short_colour_maps_are_bit_identical_to_the_general_one(hostsim, oracle, abi, host, load_scene):
+    """Scenes whose albedos all lie in [0, 1] run the kernel's SHORT colour maps (rt_core.h): unlit G(x) = q x; lit
+    G(x) = min(h, p + q x) with q in registers and (p, h) in memory once a light contributed.  Same bits as the general
+    clamped-affine map FwdT<false> — on the reference's lit test_scene, on a gradient-sky world with three lights whose
+    sums hit the clamp (levels 0 AND 1 sampling the lights, nested light rays), on the unlit cover scene — and the
+    oracle's image within the parity bar."""
+    cases = [load_scene("test", 96, 72, 8, 8), load_scene("test", 64, 48, 8, 50, 5), _many_lights_scene(host), _many_lights_scene(host, 2, 48, 30, 32, 3),
+             _many_lights_scene(host, 1, 48, 30, 16, 2), load_scene("cover", 96, 64, 4, 50)]
+    for i, sc in enumerate(cases):
+        g_rgb, g_lin, g_st = hostsim.render(sc.ptr, None, 3 + 16)        # general map
+        s_rgb, s_lin, s_st = hostsim.render(sc.ptr, None, 3 + 16 + 32)   # short maps
+        assert np.array_equal(g_lin, s_lin) and np.array_equal(g_rgb, s_rgb), f"case {i}: {int((g_lin != s_lin).sum())} values differ"
+        assert g_st["segments"] == s_st["segments"]
+        o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+        assert_parity(s_rgb, s_lin, o_rgb, o_lin, f"short map case {i}", atol=2e-6 + 3e-8 * sc.c.samples_per_pixel, flip_frac=2e-3)
+        if len(sc.lights()):
+            assert o_st["segments_discarded"] > 0 and s_lin.max() > 0.5
+
+
 def test_fast_texel_path_agrees_with_the_exact_one(hostsim):
     """texel_fast (plain-f64 unit vector and atan, rt_core.h) names a texel only when the exact path (correctly-rounded
     divisions and atan2, then floor) names the same one; hit points aimed at texel boundaries, at the u wrap (rot = 1),
