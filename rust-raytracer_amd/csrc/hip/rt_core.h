@@ -1197,73 +1197,101 @@ RT_HD bool lane_light_return(const DevScene& sc, const Tables& tb, LaneT& L, Rgb
   }
 }
 
+// The light-sampling draw of the current node (raytracer.rs:100: slot 0, words z w), and whether a hit of this lane's
+// current ray could need it at all: a camera-path hit of the first two levels, or a light ray's hit below the nesting cap.
+// The kernel draws it for all such lanes in ONE instruction stream before lane_shade (light_u_pre) — two Philox streams
+// inlined in two branches that a few lanes take cost every wave iteration ~160 instructions.
+template <class LaneT>
+RT_HD double lane_light_draw(const LaneT& L) {
+  const U4 w = rng(L.ra, L.node, 0);
+  return u01_53(w.z, w.w);
+}
+template <class LaneT>
+RT_HD bool lane_may_sample_lights(const DevScene& sc, const LaneT& L) {
+  if constexpr (LaneT::kLights) {
+    return (L.in_light & 1u) ? (uint32_t)L.ls.top + 1u < RT_MAX_LIGHT_NEST : (sc.max_depth >= 2 && L.k < 2);
+  }
+  return false;
+}
+
 // Consume the closest hit (idx < 0: miss) of the lane's current ray.  Returns true when the
 // lane's current sample finished (its radiance is in L.val; the caller starts the next one).
 template <class LaneT, class Tables>
 RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, double t, const V3* rnd_pre = nullptr,
-                      const double* glass_u_pre = nullptr) {
+                      const double* glass_u_pre = nullptr, const double* light_u_pre = nullptr) {
   constexpr bool HL = LaneT::kLights;
-  if (idx < 0) {  // raytracer.rs:133-163
-    Rgb sky = sky_color(sc, L.d, L.n_tex_oob);
-    if constexpr (HL) {
-      if (L.in_light & 1u) return lane_light_return(sc, tb, L, sky);
-    }
-    lane_finish_sample(L, sky);
-    return true;
-  }
-  const SphereGeom g = tb.geom((uint32_t)idx);
-  const MatCore m = tb.mat((uint32_t)idx);
-  Surface h = surface_at(L.o, L.d, t, g, m.inv_r);
-  V3 out_dir = v3(0, 0, 0);
-  float att[3];
-  int st = scatter(sc, L.ra, L.node, L.d, h, g, m, (uint32_t)idx, out_dir, att, L.n_tex_oob, rnd_pre, glass_u_pre);
   const float zero3[3] = {0.0f, 0.0f, 0.0f};
-
-  if constexpr (HL) {
-    if (L.in_light & 1u) {
-      // nested activation ray_color(light_ray, 2, 1) at nesting level top+1
-      if (st == SCATTER_EMIT) return lane_light_return(sc, tb, L, rgb(att[0], att[1], att[2]));  // :124
-      if (st == SCATTER_ABSORBED) return lane_light_return(sc, tb, L, rgb(0.f, 0.f, 0.f));        // :127-131
-      const uint32_t level = (uint32_t)L.ls.top + 1u;
-      if (level < RT_MAX_LIGHT_NEST) {
-        double prob = m.kind == RT_MAT_GLASS ? 0.05 : 0.1;
-        U4 w = rng(L.ra, L.node, 0);
-        if (u01_53(w.z, w.w) > (1.0 - (double)sc.n_lights * prob)) {
-          light_frame_push(L.ls);  // suspend the activation whose light ray this is
-          LightFrame& f = light_frame(L.ls).cur;
-          f.P = h.point; f.a[0] = att[0]; f.a[1] = att[1]; f.a[2] = att[2];
-          f.acc[0] = f.acc[1] = f.acc[2] = 0.0f; f.j = 0; f.node = L.node;
-          lane_aim_light(sc, tb, L);
-          return false;
-        }
-      }
-      // no light sampling: clamp(0 + albedo * black)
-      return lane_light_return(sc, tb, L, rgb(clamp01(0.0f + att[0] * 0.0f), clamp01(0.0f + att[1] * 0.0f), clamp01(0.0f + att[2] * 0.0f)));
+  if constexpr (!HL) {
+    (void)light_u_pre;
+    if (idx < 0) {  // raytracer.rs:133-163
+      lane_finish_sample(L, sky_color(sc, L.d, L.n_tex_oob));
+      return true;
     }
-  }
-
-  if (st == SCATTER_ABSORBED) { lane_finish_sample(L, rgb(0.f, 0.f, 0.f)); return true; }       // :127-131
-  if (st == SCATTER_EMIT) { lane_finish_sample(L, rgb(att[0], att[1], att[2])); return true; }  // :124
-  if constexpr (HL) {
-    // raytracer.rs:99-102: depth > max_depth-2  <=>  k < 2 (and max_depth >= 2, usize wrap)
-    if (sc.max_depth >= 2 && L.k < 2) {
-      double prob = m.kind == RT_MAT_GLASS ? 0.05 : 0.1;
-      U4 w = rng(L.ra, L.node, 0);
-      if (u01_53(w.z, w.w) > (1.0 - (double)sc.n_lights * prob)) {
+    const SphereGeom g = tb.geom((uint32_t)idx);
+    const MatCore m = tb.mat((uint32_t)idx);
+    Surface h = surface_at(L.o, L.d, t, g, m.inv_r);
+    V3 out_dir = v3(0, 0, 0);
+    float att[3];
+    int st = scatter(sc, L.ra, L.node, L.d, h, g, m, (uint32_t)idx, out_dir, att, L.n_tex_oob, rnd_pre, glass_u_pre);
+    if (st == SCATTER_ABSORBED) { lane_finish_sample(L, rgb(0.f, 0.f, 0.f)); return true; }       // :127-131
+    if (st == SCATTER_EMIT) { lane_finish_sample(L, rgb(att[0], att[1], att[2])); return true; }  // :124
+    return lane_continue_main(sc, L, h.point, out_dir, zero3, att);
+  } else {
+    // Lit scenes.  First decide what the hit MEANS for the lane; the heavy continuations — hand a colour back to the
+    // activation that shot this light ray, start summing over the lights — then exist once each: in a wave some lane
+    // takes nearly every branch, and every inlined copy of lane_light_return a different lane reaches is paid by all 64.
+    enum { ACT_FINISH = 0, ACT_CONTINUE = 1, ACT_RETURN = 2, ACT_SAMPLE = 3 };
+    const bool light_ray = (L.in_light & 1u) != 0u;   // a nested activation ray_color(light_ray, 2, 1) at nesting level top+1
+    Rgb col = rgb(0.f, 0.f, 0.f);  // the sample's leaf colour (ACT_FINISH) / the colour of the light ray (ACT_RETURN)
+    V3 point = v3(0, 0, 0), out_dir = v3(0, 0, 0);
+    float att[3] = {0.f, 0.f, 0.f};
+    int act;
+    if (idx < 0) {  // raytracer.rs:133-163
+      col = sky_color(sc, L.d, L.n_tex_oob);
+      act = light_ray ? ACT_RETURN : ACT_FINISH;
+    } else {
+      const SphereGeom g = tb.geom((uint32_t)idx);
+      const MatCore m = tb.mat((uint32_t)idx);
+      Surface h = surface_at(L.o, L.d, t, g, m.inv_r);
+      point = h.point;
+      const int st = scatter(sc, L.ra, L.node, L.d, h, g, m, (uint32_t)idx, out_dir, att, L.n_tex_oob, rnd_pre, glass_u_pre);
+      if (st != SCATTER_RAY) {  // :124 Light: its colour; :127-131 absorbed: black
+        if (st == SCATTER_EMIT) col = rgb(att[0], att[1], att[2]);
+        act = light_ray ? ACT_RETURN : ACT_FINISH;
+      } else {
+        // raytracer.rs:92-102: sample the lights?  Camera path: depth > max_depth-2 <=> k < 2 (and max_depth >= 2, usize
+        // wrap); a light ray's own hit: the same test one level down, below the nesting cap
+        bool sample = false;
+        if (lane_may_sample_lights(sc, L)) {
+          const double prob = m.kind == RT_MAT_GLASS ? 0.05 : 0.1;
+          const double lu = light_u_pre ? *light_u_pre : lane_light_draw(L);
+          sample = lu > (1.0 - (double)sc.n_lights * prob);
+        }
+        if (sample) act = ACT_SAMPLE;
+        else if (light_ray) {  // no light sampling: clamp(0 + albedo * black) (:117-122, the child is depth 0)
+          col = rgb(clamp01(0.0f + att[0] * 0.0f), clamp01(0.0f + att[1] * 0.0f), clamp01(0.0f + att[2] * 0.0f));
+          act = ACT_RETURN;
+        } else act = ACT_CONTINUE;
+      }
+    }
+    if (act == ACT_SAMPLE) {
+      if (light_ray) light_frame_push(L.ls);  // suspend the activation whose light ray this is
+      else {
         // (pooled kernels: no record free -> nothing has changed yet: the same segment is traced again, and counted once)
         if (!light_frame_acquire(L.ls, sc.light_pool_slots, L.ra.pixel + L.ra.sample)) { L.n_segments--; return false; }
         L.ls.top = 0;
-        LightParked& pk = light_frame(L.ls);
-        LightFrame& f = pk.cur;
-        f.P = h.point; f.a[0] = att[0]; f.a[1] = att[1]; f.a[2] = att[2];
-        f.acc[0] = f.acc[1] = f.acc[2] = 0.0f; f.j = 0; f.node = L.node;
-        pk.saved_d = out_dir;
-        lane_aim_light(sc, tb, L);
-        return false;
+        light_frame(L.ls).saved_d = out_dir;
       }
+      LightFrame& f = light_frame(L.ls).cur;
+      f.P = point; f.a[0] = att[0]; f.a[1] = att[1]; f.a[2] = att[2];
+      f.acc[0] = f.acc[1] = f.acc[2] = 0.0f; f.j = 0; f.node = L.node;
+      lane_aim_light(sc, tb, L);
+      return false;
     }
+    if (act == ACT_RETURN) return lane_light_return(sc, tb, L, col);
+    if (act == ACT_FINISH) { lane_finish_sample(L, col); return true; }
+    return lane_continue_main(sc, L, point, out_dir, zero3, att);
   }
-  return lane_continue_main(sc, L, h.point, out_dir, zero3, att);
 }
 
 // raytracer.rs:207-213: mean, sqrt gamma, palette f32 -> u8: round-half-even of min(x*255, 255), negatives -> 0,

@@ -185,8 +185,9 @@ __device__ __forceinline__ const KArgs& fresh_args() {
 // attempt 0, and get its first two words back in `glass_u`.
 // Lanes that just took a new sample (`fresh`; they hold no hit) make the Philox call of its camera jitter (node
 // NODE_CAMERA, slot 0, raytracer.rs:199-200) in the same stream and get its four words back in `cam_w`.
+// Glass lanes also get the light-sampling draw of their node back (same Philox call, words z w: raytracer.rs:100) in `glass_lu`.
 __device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, bool glass, bool fresh, const RngAddr& ra, uint32_t node, uint32_t lane,
-                                                         uint4* xch, double& glass_u, U4& cam_w) {
+                                                         uint4* xch, double& glass_u, double& glass_lu, U4& cam_w) {
   auto point = [](uint32_t x, uint32_t y, uint32_t z) { return v3(range_m1_1(x), range_m1_1(y), range_m1_1(z)); };
   uint32_t wx = 0, wy = 0, wz = 0, ww = 0;
   bool pending = false;
@@ -197,6 +198,7 @@ __device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, bool glass, 
   }
   cam_w.x = wx; cam_w.y = wy; cam_w.z = wz; cam_w.w = ww;
   glass_u = u01_53(wx, wy);
+  glass_lu = u01_53(wz, ww);
   uint32_t base = 1;  // next attempt of every lane still pending (wave-uniform)
   for (;;) {
     const unsigned long long F = wave_ballot(pending);
@@ -762,13 +764,19 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     RT_PROF(0);
     // (c) the random numbers of this iteration, one instruction stream
     const uint32_t hit_kind = has_ray && best >= 0 ? tb.mat((uint32_t)best).kind : 0xFFFFFFFFu;
-    double glass_u;
+    double glass_u, light_u;
     U4 cam_w;
     const V3 rnd = coop_random_in_unit_sphere(hit_kind != 0xFFFFFFFFu && material_draws_unit_sphere(hit_kind), hit_kind == RT_MAT_GLASS, fresh,
-                                              L.ra, L.node, lane, coop_xch, glass_u, cam_w);
+                                              L.ra, L.node, lane, coop_xch, glass_u, light_u, cam_w);
+    if constexpr (HL) {  // the light-sampling draw (raytracer.rs:100) of every hit that may need it: one instruction stream
+      const bool want = hit_kind != 0xFFFFFFFFu && hit_kind != RT_MAT_GLASS && hit_kind != RT_MAT_LIGHT && lane_may_sample_lights(fresh_args().sc, L);
+      if (wave_any(want)) {
+        if (want) light_u = lane_light_draw(L);
+      }
+    }
     // (d) shade the hits
     bool finished = false;
-    if (has_ray) finished = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u);
+    if (has_ray) finished = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u, HL ? &light_u : nullptr);
     RT_PROF(2);
     if (wave_any(finished)) {
       if (finished) has_ray = false;
@@ -819,8 +827,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     const uint32_t hit_kind = has_ray && best >= 0 ? tb.mat((uint32_t)best).kind : 0xFFFFFFFFu;
     double glass_u;
     U4 cam_w;
+    double glass_lu;
     const V3 rnd = coop_random_in_unit_sphere(hit_kind != 0xFFFFFFFFu && material_draws_unit_sphere(hit_kind), hit_kind == RT_MAT_GLASS, false,
-                                              L.ra, L.node, lane, coop_xch, glass_u, cam_w);
+                                              L.ra, L.node, lane, coop_xch, glass_u, glass_lu, cam_w);
     bool finished = false;
     if (has_ray) finished = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u);
     RT_PROF(2);
