@@ -683,6 +683,9 @@ struct GlobalTables {
   const MatCore* m;
   RT_HD SphereGeom geom(uint32_t i) const { return g[i]; }
   RT_HD MatCore mat(uint32_t i) const { return m[i]; }
+  // centre of light j (raytracer.rs:104-105 aims at it): the kernel's table types answer from a small LDS copy instead of
+  // two dependent global loads (a light ray starts in nearly every wave iteration of a lit scene)
+  RT_HD V3 light_centre(const DevScene& sc, uint32_t j) const { const SphereGeom lg = g[sc.lights[j]]; return v3(lg.cx, lg.cy, lg.cz); }
 };
 
 // ------------------------------------------------------------------ scatter (materials.rs:44-54)
@@ -937,7 +940,8 @@ static_assert(sizeof(LightParked) == 80, "parked light state is 80 B per lane");
 //     The pool sits at a FIXED offset of the kernel's dynamic LDS ([128-byte bitmap][records]; rt_kernel.hip's layout
 //     asserts it) and its size travels in DevScene.light_pool_slots, so a lane carries one dword for it: the LDS byte
 //     offset of its record, 0 while it holds none.
-constexpr uint32_t LIGHT_POOL_LDS_OFF = 65824u;      // = rt_kernel.hip lds_layout().park_off
+constexpr uint32_t LIGHT_CENTRES_LDS_MAX = 32u;       // light centres staged in LDS (24 B each); further lights are read from HBM
+constexpr uint32_t LIGHT_POOL_LDS_OFF = 65824u + LIGHT_CENTRES_LDS_MAX * 24u;  // = rt_kernel.hip lds_layout().park_off of a lit scene
 constexpr uint32_t LIGHT_POOL_BITMAP_BYTES = 128u;   // 1024 slots at most
 constexpr uint32_t LIGHT_POOL_MAX_SLOTS = 1024u;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1078,6 +1082,9 @@ RT_HD void lane_begin_sample(const DevScene& sc, LaneT& L, uint32_t px, uint32_t
 constexpr uint32_t LANE_HAS_BASE = 2u;
 template <class LaneT>
 RT_HD void lane_compose(LaneT& L, const float light[3], const float att[3], bool has_light) {
+#ifdef RT_EXP_NO_BASE  // (timing experiment only — WRONG image: what the memory-resident base costs)
+  has_light = false;
+#endif
   if constexpr (LaneT::kLights && LaneT::kSimple) {
     if (has_light) {  // level L.k (0 or 1) contributes `light`: create / update the base
       float* b = L.ls.stack->base;
@@ -1170,9 +1177,8 @@ RT_HD bool lane_continue_main(const DevScene& sc, LaneT& L, V3 point, V3 out_dir
 template <class Tables, class LaneT>
 RT_HD void lane_aim_light(const DevScene& sc, const Tables& tb, LaneT& L) {
   LightFrame& f = light_frame(L.ls).cur;
-  const SphereGeom lg = tb.geom(sc.lights[f.j]);
   L.o = f.P;
-  L.d = sub(v3(lg.cx, lg.cy, lg.cz), f.P);
+  L.d = sub(tb.light_centre(sc, f.j), f.P);
   L.node = child_node(f.node, f.j);
   L.in_light |= 1u;
 }

@@ -378,7 +378,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   bool lds_tables = with_tables.total <= rtk::LDS_TABLES_MAX_BYTES;
   uint32_t pool_slots = 0;
   if (!lds_tables && s->has_lights) {
-    const uint32_t bare = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, false).total;
+    const uint32_t bare = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, false).total + rtc::LIGHT_CENTRES_LDS_MAX * 24u;
     uint32_t fit = 0;
     while (fit + 32u <= rtc::LIGHT_POOL_MAX_SLOTS && bare + rtk::park_bytes(fit + 32u) <= rtk::LDS_TABLES_MAX_BYTES) fit += 32u;
     const double n = (double)s->dev.n_lights, f = 0.2 * n * n / (2.9 + 0.2 * n * n);

@@ -122,19 +122,21 @@ __host__ __device__ inline uint32_t tile_slots(uint32_t tile_log2) {
   return t > T_SLOTS_MAX ? T_SLOTS_MAX : t;
 }
 struct LdsLayout {
-  uint32_t hdr_off, coop_off, park_off, geom_off, matc_off, cell_off, item_off, total;
+  uint32_t hdr_off, coop_off, light_off, park_off, geom_off, matc_off, cell_off, item_off, total;
 };
 // light frames (lit scenes): one LightParked per lane (pool_slots == 0), or [bitmap][pool of pool_slots records] (rt_core.h)
 __host__ __device__ constexpr uint32_t park_bytes(uint32_t pool_slots) {
   return pool_slots ? LIGHT_POOL_BITMAP_BYTES + pool_slots * (uint32_t)sizeof(LightParked) : (uint32_t)BLOCK * (uint32_t)sizeof(LightParked);
 }
-static_assert(LDS_FLAGS_BYTES + LDS_SLOT_BUDGET + WAVES * 64u * 16u == LIGHT_POOL_LDS_OFF || BLOCK != 1024, "rt_core.h LIGHT_POOL_LDS_OFF = park_off of the layout below");
+constexpr uint32_t LIGHT_CENTRES_LDS_OFF = LDS_FLAGS_BYTES + LDS_SLOT_BUDGET + WAVES * 64u * 16u;  // lit scenes: centres of the first 32 lights, 3 doubles each
+static_assert(LIGHT_CENTRES_LDS_OFF + LIGHT_CENTRES_LDS_MAX * 24u == LIGHT_POOL_LDS_OFF || BLOCK != 1024, "rt_core.h LIGHT_POOL_LDS_OFF = park_off of the layout below");
 __host__ __device__ inline LdsLayout lds_layout(uint32_t n_spheres, uint32_t n_cells, uint32_t n_items, bool tables, bool lights, uint32_t pool_slots = 0) {
   LdsLayout l;
   uint32_t o = LDS_FLAGS_BYTES;
   l.hdr_off = o; o += LDS_SLOT_BUDGET;  // [t_slots headers][t_slots x npx x 3 u64 sums], sized by tile_slots()
   l.coop_off = o; o += WAVES * 64u * 16u;  // per wave: 64 x 16 B exchange slots of coop_random_in_unit_sphere
-  l.park_off = o; if (lights) o += park_bytes(pool_slots);  // rt_core.h LightParked: [records][pool bitmap]
+  l.light_off = o; if (lights) o += LIGHT_CENTRES_LDS_MAX * 24u;
+  l.park_off = o; if (lights) o += park_bytes(pool_slots);  // rt_core.h LightParked: [bitmap][records] of a pool, or one record per lane
   l.geom_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(SphereGeom);
   l.matc_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(MatCore);
   l.cell_off = o; if (tables) o += n_cells * 8u;
@@ -244,9 +246,24 @@ __device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, bool glass, 
   return point(wx, wy, wz);
 }
 
+// centre of light j from the workgroup's LDS copy (the first LIGHT_CENTRES_LDS_MAX lights), else through HBM
+__device__ __forceinline__ V3 light_centre_lds(const unsigned char* lds, const DevScene& sc, uint32_t j) {
+  if (j < LIGHT_CENTRES_LDS_MAX) {
+    const double* c = reinterpret_cast<const double*>(lds + LIGHT_CENTRES_LDS_OFF) + 3u * j;
+    return v3(c[0], c[1], c[2]);
+  }
+  const SphereGeom lg = sc.geom[sc.lights[j]];
+  return v3(lg.cx, lg.cy, lg.cz);
+}
+struct GlobalTablesK : GlobalTables {  // scenes whose tables stay in HBM / L2: only the light centres come from LDS
+  const unsigned char* lds;
+  __device__ __forceinline__ V3 light_centre(const DevScene& sc, uint32_t j) const { return light_centre_lds(lds, sc, j); }
+};
 struct LdsTables {  // per-lane gathers from the workgroup's LDS copies
   const double* g;
   const MatCore* m;
+  const unsigned char* lds;
+  __device__ __forceinline__ V3 light_centre(const DevScene& sc, uint32_t j) const { return light_centre_lds(lds, sc, j); }
   __device__ __forceinline__ SphereGeom geom(uint32_t i) const {
     const double* p = g + 4u * i;
     SphereGeom r; r.cx = p[0]; r.cy = p[1]; r.cz = p[2]; r.r = p[3];
@@ -305,8 +322,15 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     }
     __syncthreads();
   }
-  using Tables = typename std::conditional<LDS_TABLES, LdsTables, GlobalTables>::type;
+  if constexpr (HL) {  // centres of the lights: read when a light ray is aimed (raytracer.rs:104-105)
+    double* lc = reinterpret_cast<double*>(lds_raw + LIGHT_CENTRES_LDS_OFF);
+    const uint32_t nl = sc.n_lights < LIGHT_CENTRES_LDS_MAX ? sc.n_lights : LIGHT_CENTRES_LDS_MAX;
+    for (uint32_t i = threadIdx.x; i < 3u * nl; i += BLOCK) lc[i] = reinterpret_cast<const double*>(sc.geom + sc.lights[i / 3u])[i % 3u];
+    __syncthreads();
+  }
+  using Tables = typename std::conditional<LDS_TABLES, LdsTables, GlobalTablesK>::type;
   Tables tb;
+  tb.lds = lds_raw;
   const uint2* cell_word;
   const uint16_t* cell_items;
   if constexpr (LDS_TABLES) {
@@ -768,12 +792,18 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     U4 cam_w;
     const V3 rnd = coop_random_in_unit_sphere(hit_kind != 0xFFFFFFFFu && material_draws_unit_sphere(hit_kind), hit_kind == RT_MAT_GLASS, fresh,
                                               L.ra, L.node, lane, coop_xch, glass_u, light_u, cam_w);
+#ifdef RT_PROF_SPLIT  // (experiment builds: the random draws are booked under "item", lane_shade proper stays under "lane_shade")
+    RT_PROF(5);
+#endif
     if constexpr (HL) {  // the light-sampling draw (raytracer.rs:100) of every hit that may need it: one instruction stream
       const bool want = hit_kind != 0xFFFFFFFFu && hit_kind != RT_MAT_GLASS && hit_kind != RT_MAT_LIGHT && lane_may_sample_lights(fresh_args().sc, L);
       if (wave_any(want)) {
         if (want) light_u = lane_light_draw(L);
       }
     }
+#ifdef RT_PROF_SPLIT
+    RT_PROF(0);  // (the light draw alone: booked under "refill")
+#endif
     // (d) shade the hits
     bool finished = false;
     if (has_ray) finished = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u, HL ? &light_u : nullptr);
