@@ -397,9 +397,9 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   // deepest in the previous frame first (their paths are what a frame ends on)
   ka.order_mode = s->order_mode != 0 ? 1u : 0u;
   ka.tile_order = nullptr; ka.tile_depth = nullptr;
-  // XCD affinity: runs of 1.5 KB of a scanline's tiles (512 pixels) per XCD, for frames of at least 32 runs per XCD
-  // (smaller ones — the 1/8 shards of the headline frame — lose more to the coarser balance than the write traffic is
-  // worth: 2.10 instead of 1.89 ms, profiles/r02_run29_affinity.log)
+  // XCD affinity: runs of 1.5 KB of a scanline's tiles (512 pixels) per XCD, for large frames (smaller ones — the shards
+  // of the headline frame — lose more to the coarser balance than the write traffic is worth: 2.10 instead of 1.89 ms,
+  // profiles/r02_run29_affinity.log)
   ka.aff_group_log2 = 0xFFFFFFFFu;
   for (int x = 0; x < 8; ++x) { ka.xcd_cnt[x] = 0; ka.xcd_off[x] = 0; }
   {
@@ -410,7 +410,10 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
 #endif
     const uint32_t gl = ka.tile_wl >= run_px_log2 ? 0u : run_px_log2 - ka.tile_wl;
     const uint32_t n_groups = (ka.n_tiles + (1u << gl) - 1u) >> gl;
-    if ((s->tile_affinity == 1 && n_groups >= 256u) || (s->tile_affinity == 2 && n_groups >= 8u)) {
+    // on for frames of at least 2^19 pixels (the headline frame: 0.96 M; its 1/2 ... 1/8 shards and the 800x600 test scene are
+    // below and lose 6 - 15 % to the coarser balance, profiles/r03_run8_shard_affinity_sweep.log) with at least 8 runs
+    const bool big = (uint64_t)local_rows * s->host.width >= (1ull << 19);
+    if ((s->tile_affinity == 1 && big && n_groups >= 8u) || (s->tile_affinity == 2 && n_groups >= 8u)) {
       ka.aff_group_log2 = gl;
       for (uint32_t g = 0; g < 8u && g < n_groups; ++g) {  // groups g, g + 8, ...: all full but possibly the frame's last
         const uint32_t mine = (n_groups - 1u - g) / 8u + 1u;
