@@ -279,8 +279,9 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   hipStream_t stream = (hipStream_t)stream_;
   // one tile-queue cursor / counter block / event pair per scene: launches of a scene are ordered on ONE stream
   // (a caller that drained the first stream itself — hipStreamSynchronize, an event — need not call rt_hip_wait first)
-  if (s->in_flight && stream != s->last_stream && hipStreamQuery(s->last_stream) == hipSuccess) s->in_flight = false;
-  (void)hipGetLastError();  // (hipErrorNotReady of the query is not an error of this call)
+  // (hipErrorNotReady = work pending; anything else — success, or a stream the caller has destroyed since — holds no work of ours)
+  if (s->in_flight && stream != s->last_stream && hipStreamQuery(s->last_stream) != hipErrorNotReady) s->in_flight = false;
+  (void)hipGetLastError();  // (the query's status is not an error of this call)
   if (s->in_flight && stream != s->last_stream)
     return fail(RT_ERR_INVALID, "rt_hip_render: this scene has a launch in flight on another stream (call rt_hip_wait first, "
                                 "or use one RtHipScene per concurrent stream)");
