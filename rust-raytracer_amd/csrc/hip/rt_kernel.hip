@@ -176,6 +176,9 @@ __device__ __forceinline__ const KArgs& fresh_args() {
 #ifndef RT_HANDOUT_DIRECT
 #define RT_HANDOUT_DIRECT 0
 #endif
+#ifndef RT_SINGLE_SETTLE
+#define RT_SINGLE_SETTLE 0  // 1: ONE add_sample / count_tiles block per iteration (samples that end in the shade block settle one iteration later): 13.76 -> 13.84 ms, not adopted (profiles/r03_run14_ab_single_settle.log)
+#endif
 #ifndef RT_DEEP_PATH
 #define RT_DEEP_PATH 2u  // camera paths at least this many segments long mark their tile (SlotHdr::max_depth); 2 / 3 / 4 / 6 / 8 / 16: 13.96 / 13.98 / 13.98 / 14.01 / 14.05 / 14.5 ms (profiles/r02_run10_ab.log)
 #endif
@@ -760,6 +763,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 
   RT_PROF(5);
   uint32_t idle_spins = 0;
+#if RT_SINGLE_SETTLE
+  bool pending = false;  // per lane: its sample finished in the shade block of the previous iteration (radiance in L.val)
+#endif
 #if RT_FUSED_REFILL
   // Loop order: trace -> rays that left the scene finish at once (sky) -> every lane without a path takes its next
   // sample -> ONE Philox instruction stream serves the hits (unit-sphere point / Glass draw) and the new samples (camera
@@ -779,6 +785,20 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     // (a) a ray that left the scene ends its sample here (raytracer.rs:133-163); light rays return to their parent in (d)
     bool miss = has_ray && best < 0;
     if constexpr (HL) miss = miss && !(L.in_light & 1u);
+#if RT_SINGLE_SETTLE
+    // ONE settle block per iteration: the samples that ended in the sky now, and those that ended in last iteration's shade
+    // block (`pending`: absorbed, a Light hit, depth exhausted — a few % of the lanes, which sit out this trace)
+    if (wave_any(miss)) {
+      if (miss) {
+        lane_finish_sample(L, sky_color(fresh_args().sc, L.d, L.n_tex_oob));
+        has_ray = false;
+      }
+    }
+    const bool settle = miss || pending;
+    if (wave_any(settle)) add_sample(settle);
+    count_tiles(settle, my_k);
+    pending = false;
+#else
     const uint32_t k_miss = my_k;
     if (wave_any(miss)) {
       if (miss) {
@@ -787,6 +807,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       }
       add_sample(miss);
     }
+#endif
     RT_PROF(4);
     // (b) every lane without a path takes its next sample
     uint32_t n_px = 0, n_py = 0;
@@ -814,16 +835,24 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     bool finished = false;
     if (has_ray) finished = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u, HL ? &light_u : nullptr);
     RT_PROF(2);
+#if RT_SINGLE_SETTLE
+    if (finished) { has_ray = false; pending = true; }
+#else
     if (wave_any(finished)) {
       if (finished) has_ray = false;
       add_sample(finished);
     }
     count_tiles(miss || finished, miss ? k_miss : my_k);
+#endif
     RT_PROF(4);
     // (e) the new samples start (raytracer.rs:199-201, camera.rs:79-84)
     if (fresh) { lane_begin_sample_w(fresh_args().sc, L, n_px, n_py, cam_w); has_ray = true; }
     RT_PROF(0);
+#if RT_SINGLE_SETTLE
+    if (!wave_any(has_ray || pending)) {
+#else
     if (!wave_any(has_ray)) {
+#endif
       // nothing in flight.  Done when the frame has nothing left; otherwise (all tile slots are busy with other waves'
       // long paths) wait a little and ask again — bounded, a wave may always retire: the samples it traced are already
       // counted in their tiles.
