@@ -296,7 +296,10 @@ def test_lit_cover_scene_light_frame_pool(gpu_render, oracle, abi, host):
     one = host.Scene.loads(json.dumps(cfg))
     cfg["objects"].append({"center": {"x": 3.0, "y": 2.5, "z": 2.0}, "radius": 0.4, "material": {"Light": {}}})
     two = host.Scene.loads(json.dumps(cfg))
-    for sc, pools in ((one, (0, 32, 96)), (two, (0, 64, 32))):
+    cfg["objects"].pop()
+    cfg["objects"][5]["material"] = {"Lambertian": {"albedo": [1.5, 0.9, 0.2]}}   # an albedo above 1: the GENERAL colour map beside the pool
+    hot = host.Scene.loads(json.dumps(cfg))
+    for sc, pools in ((one, (0, 32, 96)), (two, (0, 64, 32)), (hot, (0, 64))):
         o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
         first = None
         for pool in pools:
