@@ -286,7 +286,7 @@ def test_many_lights_nested_sampling(gpu_render, oracle, abi, host):
 
 def test_lit_cover_scene_light_frame_pool(gpu_render, oracle, abi, host):
     """A lit scene of cover size: 1024 per-lane light frames (80 KB) would push the tables out of LDS, so the workgroup
-    shares a POOL of frames (rt_core.h LightState<true, true>; one light: ~150 records for ~66 in use).  A lane that
+    shares a POOL of frames (rt_core.h LightState<true, true>; one light: 160 records for ~66 in use).  A lane that
     finds the pool exhausted repeats its segment.  The frame must not depend on any of it: the automatic pool, a pool of
     32 records (most light-sampling hits repeat, some many times) and — two lights, forced — pools of 64 and 32 all give
     the oracle's image and exactly the oracle's path count (a repeated segment is counted once)."""
