@@ -597,13 +597,21 @@ RT_HD uint64_t sat_u64_f32(float x) {  // Rust `f32 as usize`
   if (x >= 18446744073709551616.0f) return ~0ull;
   return (uint64_t)x;
 }
+// x / 255.0f (materials.rs:247-252, raytracer.rs:153-158), correctly rounded, through y = RN(1/255) and ONE Markstein
+// correction: 3 instructions instead of the ~10 of an IEEE f32 division, three times per texel.  Equal to the IEEE quotient
+// for EVERY float in [0, 256] (tools/analysis/div255_check.cpp: all 1.13e9 of them) — the kernel divides bytes and 0.7f * bytes.
+RT_HD float rt_div255f(float x) {
+  const float y = 0.003921568859368563f;  // RN(1 / 255) = 0x1.010102p-8
+  const float q = x * y;
+  return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), y, q);
+}
 // materials.rs:236-254 (out-of-range index: clamp + count; the reference panics)
 RT_HD Rgb texel_fetch(const DevScene& sc, const SphereMat& m, uint64_t col, uint64_t row, uint32_t& tex_oob) {
   uint64_t base_pixel = 3 * (row * m.tex_w + col);
   if (m.tex_nbytes < 3) { tex_oob++; return rgb(0.f, 0.f, 0.f); }
   if (base_pixel > m.tex_nbytes - 3) { tex_oob++; base_pixel = (m.tex_nbytes / 3 - 1) * 3; }
   const uint8_t* px = sc.tex + m.tex_off + base_pixel;
-  return rgb((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+  return rgb(rt_div255f((float)px[0]), rt_div255f((float)px[1]), rt_div255f((float)px[2]));
 }
 RT_HD Rgb texture_albedo(const DevScene& sc, const SphereMat& m, double u, double v, uint32_t& tex_oob) {
   double rot = u + m.h_offset;
@@ -672,7 +680,7 @@ RT_HD Rgb sky_color(const DevScene& sc, V3 d, uint32_t& tex_oob) {
   uint64_t base = (y * sc.sky_w + x) * 3;
   if (base + 2 >= sc.sky_w * sc.sky_h * 3) { tex_oob++; base = (sc.sky_w * sc.sky_h - 1) * 3; }
   const uint8_t* px = sc.sky + base;
-  return rgb(0.7f * (float)px[0] / 255.0f, 0.7f * (float)px[1] / 255.0f, 0.7f * (float)px[2] / 255.0f);
+  return rgb(rt_div255f(0.7f * (float)px[0]), rt_div255f(0.7f * (float)px[1]), rt_div255f(0.7f * (float)px[2]));
 }
 
 // ------------------------------------------------------------------ table access

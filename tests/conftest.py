@@ -70,6 +70,7 @@ def hostsim(abi):
     L.hostsim_texels.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.c_double, C.c_uint64, C.c_uint64, C.c_void_p]
     L.hostsim_texels.restype = None
     L.hostsim_div_by_recip.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.hostsim_div255.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.hostsim_grid_info.argtypes = [C.POINTER(abi.RtScene), C.POINTER(C.c_uint32)]
     L.hostsim_hit_world.argtypes = [C.POINTER(abi.RtScene), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]
 

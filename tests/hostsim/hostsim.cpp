@@ -220,6 +220,12 @@ extern "C" void hostsim_texels(const double* points, uint64_t n, const double ce
   }
 }
 
+// rt_core.h rt_div255f over an array (property test against the IEEE quotient x / 255.0f)
+extern "C" void hostsim_div255(const float* x, float* out, uint64_t n) {
+#pragma omp parallel for
+  for (int64_t i = 0; i < (int64_t)n; ++i) out[i] = rt_div255f(x[i]);
+}
+
 extern "C" void hostsim_div_by_recip(const double* x, const double* b, double* out, uint64_t n) {
 #pragma omp parallel for
   for (int64_t i = 0; i < (int64_t)n; ++i) out[i] = div_by_recip(x[i], b[i], 1.0 / b[i]);

@@ -107,6 +107,20 @@ def test_short_colour_maps_are_bit_identical_to_the_general_one(hostsim, oracle,
             assert o_st["segments_discarded"] > 0 and s_lin.max() > 0.5
 
 
+def test_division_by_255_through_the_reciprocal_is_the_ieee_quotient(hostsim):
+    """rt_div255f (texel / sky-texel colours, materials.rs:247-252, raytracer.rs:153-158): one Markstein correction on
+    x * RN(1/255) equals x / 255.0f — on every value the kernel divides (bytes, 0.7f * bytes) and on 2e7 floats spread over
+    [0, 256] incl. denormals (tools/analysis/div255_check.cpp runs all 1.13e9)."""
+    rng = np.random.default_rng(3)
+    b = np.arange(256, dtype=np.float32)
+    bits = rng.integers(0, np.float32(256.0).view(np.uint32) + 1, 20_000_000, dtype=np.uint32)
+    x = np.concatenate([b, np.float32(0.7) * b, bits.view(np.float32), np.array([0.0, 1e-45, 1e-40, 255.0, 256.0], np.float32)]).astype(np.float32)
+    out = np.zeros_like(x)
+    hostsim.hostsim_div255(x.ctypes.data, out.ctypes.data, len(x))
+    want = x / np.float32(255.0)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), int((out != want).sum())
+
+
 def test_fast_texel_path_agrees_with_the_exact_one(hostsim):
     """texel_fast (plain-f64 unit vector and atan, rt_core.h) names a texel only when the exact path (correctly-rounded
     divisions and atan2, then floor) names the same one; hit points aimed at texel boundaries, at the u wrap (rot = 1),
