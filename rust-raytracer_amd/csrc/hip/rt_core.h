@@ -244,12 +244,17 @@ RT_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
 //   node n, slot 1+a         : attempt a of random_in_unit_sphere  (point3d.rs:31-38)
 constexpr uint32_t NODE_CAMERA = 0xFFFFFFFFu;
 RT_HD double u01_53(uint32_t lo, uint32_t hi) {  // rand 0.8 Standard f64: (u64 >> 11) * 2^-53
-  uint64_t u = ((uint64_t)hi << 32) | lo;
-  return (double)(u >> 11) * (1.0 / 9007199254740992.0);
+  // u >> 11 = h * 2^32 + l with h = hi >> 11 (21 bits), l = the 32 bits below: the value h * 2^-21 + l * 2^-53 is a 53-bit
+  // number < 1, so both products and their sum are exact — the same bits as converting the 64-bit integer and scaling it,
+  // without the emulated u64 -> f64 conversion (the GPU has none)
+  const uint32_t h = hi >> 11, l = (hi << 21) | (lo >> 11);
+  return __builtin_fma((double)h, 1.0 / 2097152.0, (double)l * (1.0 / 9007199254740992.0));
 }
-RT_HD double range_m1_1(uint32_t w) {  // gen_range(-1.0..1.0) on a 2^-32 grid: v*(hi-lo)+lo
-  double value0_1 = (double)w * (1.0 / 4294967296.0);
-  return value0_1 * 2.0 + (-1.0);
+RT_HD double range_m1_1(uint32_t w) {  // gen_range(-1.0..1.0) on a 2^-32 grid: v*(hi-lo)+lo with v = w * 2^-32
+  // = (w * 2^-32) * 2.0 + (-1.0).  Every intermediate is exact in f64 (w < 2^32; the sum has at most 33 significant
+  // bits), so ONE fused w * 2^-31 - 1 returns the same bits as the three rounded operations (the oracle's form): two
+  // instructions fewer per coordinate, three coordinates per attempt of random_in_unit_sphere.
+  return __builtin_fma((double)w, 1.0 / 2147483648.0, -1.0);
 }
 RT_HD uint32_t child_node(uint32_t node, uint32_t light_j) {
   uint32_t x = node * 0x9E3779B1u + (light_j + 1u) * 0x85EBCA77u;
@@ -1151,7 +1156,7 @@ RT_HD unsigned long long sample_to_fixed(float v) {
   // (unsigned long long)(x * 2^40 + 0.5), written so that the GPU needs no 64-bit float->int
   // conversion (it has none: 10 instructions per channel): the truncated value is an integer
   // below 2^41, so adding 2^52 is exact and leaves it in the low mantissa bits.
-  const double y = __builtin_trunc(x * FIX_SCALE + 0.5) + 4503599627370496.0;
+  const double y = __builtin_trunc(__builtin_fma(x, FIX_SCALE, 0.5)) + 4503599627370496.0;  // (x * 2^40 is exact: the fused form rounds once, to the same value)
   unsigned long long bits;
   __builtin_memcpy(&bits, &y, sizeof bits);
   return bits & 0x000FFFFFFFFFFFFFull;

@@ -220,6 +220,20 @@ extern "C" void hostsim_texels(const double* points, uint64_t n, const double ce
   }
 }
 
+// rt_core.h range_m1_1 (fused) and sample_to_fixed over arrays (property tests against the oracle's rounded forms)
+extern "C" void hostsim_range_m1_1(const uint32_t* w, double* out, uint64_t n) {
+#pragma omp parallel for
+  for (int64_t i = 0; i < (int64_t)n; ++i) out[i] = range_m1_1(w[i]);
+}
+extern "C" void hostsim_u01_53(const uint32_t* lo, const uint32_t* hi, double* out, uint64_t n) {
+#pragma omp parallel for
+  for (int64_t i = 0; i < (int64_t)n; ++i) out[i] = u01_53(lo[i], hi[i]);
+}
+extern "C" void hostsim_sample_to_fixed(const float* v, uint64_t* out, uint64_t n) {
+#pragma omp parallel for
+  for (int64_t i = 0; i < (int64_t)n; ++i) out[i] = sample_to_fixed(v[i]);
+}
+
 // rt_core.h rt_div255f over an array (property test against the IEEE quotient x / 255.0f)
 extern "C" void hostsim_div255(const float* x, float* out, uint64_t n) {
 #pragma omp parallel for

@@ -121,6 +121,32 @@ def test_division_by_255_through_the_reciprocal_is_the_ieee_quotient(hostsim):
     assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), int((out != want).sum())
 
 
+def test_fused_exact_conversions_equal_the_rounded_forms(hostsim):
+    """range_m1_1 as ONE fma (w * 2^-31 - 1) against the oracle's three rounded operations ((w * 2^-32) * 2 + (-1): every
+    intermediate is exact), u01_53 from two exact 32-bit conversions against the 64-bit integer conversion, and
+    sample_to_fixed's fused x * 2^40 + 0.5 against multiply-then-add (the product is exact)."""
+    rng = np.random.default_rng(5)
+    w = np.concatenate([rng.integers(0, 1 << 32, 8_000_000, dtype=np.uint64).astype(np.uint32),
+                        np.array([0, 1, 2, 0x7FFFFFFF, 0x80000000, 0x80000001, 0xFFFFFFFE, 0xFFFFFFFF], np.uint32)])
+    got = np.zeros(len(w), np.float64)
+    hostsim.hostsim_range_m1_1(w.ctypes.data, got.ctypes.data, len(w))
+    want = (w.astype(np.float64) * (1.0 / 4294967296.0)) * 2.0 + (-1.0)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    lo = np.concatenate([rng.integers(0, 1 << 32, 4_000_000, dtype=np.uint64).astype(np.uint32), np.array([0, 0xFFFFFFFF, 0x7FF, 0x800, 0xFFFFFFFF, 0], np.uint32)])
+    hi = np.concatenate([rng.integers(0, 1 << 32, 4_000_000, dtype=np.uint64).astype(np.uint32), np.array([0, 0xFFFFFFFF, 0, 0, 0x7FF, 0x800], np.uint32)])
+    got = np.zeros(len(lo), np.float64)
+    hostsim.hostsim_u01_53(lo.ctypes.data, hi.ctypes.data, got.ctypes.data, len(lo))
+    u = (hi.astype(np.uint64) << np.uint64(32)) | lo.astype(np.uint64)
+    want = (u >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)      # rand 0.8's form (u64 -> f64 is exact below 2^53)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64)) and got.max() < 1.0
+    v = np.concatenate([rng.random(4_000_000).astype(np.float32), rng.integers(0, 0x3F800001, 4_000_000, dtype=np.uint32).view(np.float32),
+                        np.array([0.0, 1.0, 1e-45, 9.09e-13, 4.5e-13, 0.5, np.nextafter(np.float32(1), np.float32(0))], np.float32)]).astype(np.float32)
+    got = np.zeros(len(v), np.uint64)
+    hostsim.hostsim_sample_to_fixed(v.ctypes.data, got.ctypes.data, len(v))
+    want = np.trunc(v.astype(np.float64) * 1099511627776.0 + 0.5).astype(np.uint64)
+    assert np.array_equal(got, want)
+
+
 def test_fast_texel_path_agrees_with_the_exact_one(hostsim):
     """texel_fast (plain-f64 unit vector and atan, rt_core.h) names a texel only when the exact path (correctly-rounded
     divisions and atan2, then floor) names the same one; hit points aimed at texel boundaries, at the u wrap (rot = 1),
