@@ -104,6 +104,8 @@ struct GridDesc {
   uint32_t n_items;
   float pull;         // 8 * grid_walk_eps(max n): how far the crossing planes are pulled back
   float pad;
+  double goff[3];     // -gmin * inv_cell: x_cell = fma(x, inv_cell, goff)
+  double nd[3];       // n[] as doubles (the slab test's far planes)
 };
 constexpr uint32_t GRID_MAX_AXIS = 256;        // cells per axis (bounds the f32 error of the walk)
 constexpr uint32_t CELL_COUNT_SHIFT = 20;      // cell word = first item | (item count << 20)
@@ -467,6 +469,19 @@ RT_HD float rt_rcpf(float x) {
 RT_HD float rt_clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }  // NaN stays NaN
 RT_HD double rt_mind(double a, double b) { return a < b ? a : b; }
 RT_HD double rt_maxd(double a, double b) { return a > b ? a : b; }
+// The slab test of grid_begin on the device: one v_min_f64 / v_max_f64 / v_med3_f32 each instead of compare + selects (12 +
+// 3 of them per ray).  They differ from the forms above only when an operand is NaN (minNum drops it; med3 returns a finite
+// bound): a ray with a non-finite origin or direction — whose entry point is then NaN, fails the `sane` test and takes the
+// full scan, or whose other axes already miss the grid's slab while no sphere can be hit through a NaN anyway.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double rt_slab_min(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double rt_slab_max(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float rt_slab_clamp(float x) { return __builtin_amdgcn_fmed3f(x, -1e30f, 1e30f); }
+#else
+inline double rt_slab_min(double a, double b) { return rt_mind(a, b); }
+inline double rt_slab_max(double a, double b) { return rt_maxd(a, b); }
+inline float rt_slab_clamp(float x) { return rt_clampf(x, -1e30f, 1e30f); }
+#endif
 RT_HD float rt_min3f(float a, float b, float c) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_fminf(__builtin_fminf(a, b), c);  // v_min3_f32
@@ -479,28 +494,30 @@ RT_HD float rt_min3f(float a, float b, float c) {
 // GRID_FALLBACK: numerically unsafe (non-finite input, or entry too far away for f32): the
 // caller tests every sphere exactly instead.
 RT_HD int grid_begin(const GridDesc& G, V3 o, V3 d, GridWalk& w) {
+  // (This function only SELECTS candidates — the margins below absorb its roundings — so it may fuse freely: the slab
+  //  test and the entry point are 12 fused operations shorter than their literal form, every ray pays for them.)
   const double ol[3] = {(o.x - G.gmin[0]) * G.inv_cell[0], (o.y - G.gmin[1]) * G.inv_cell[1], (o.z - G.gmin[2]) * G.inv_cell[2]};
   const double dl[3] = {d.x * G.inv_cell[0], d.y * G.inv_cell[1], d.z * G.inv_cell[2]};
   float inv[3];
   double tn = 0.0, tf = T_MAX;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    inv[k] = rt_clampf(rt_rcpf((float)dl[k]), -1e30f, 1e30f);
+    inv[k] = rt_slab_clamp(rt_rcpf((float)dl[k]));
     const double invd = (double)inv[k];
-    const double t1 = (0.0 - ol[k]) * invd, t2 = ((double)G.n[k] - ol[k]) * invd;
-    tn = rt_maxd(tn, rt_mind(t1, t2));
-    tf = rt_mind(tf, rt_maxd(t1, t2));
+    const double t1 = (-ol[k]) * invd, t2 = __builtin_fma(G.nd[k], invd, t1);  // (0 - ol) / dl, (n - ol) / dl
+    tn = rt_slab_max(tn, rt_slab_min(t1, t2));
+    tf = rt_slab_min(tf, rt_slab_max(t1, t2));
   }
   // the slab parameters carry the f32 reciprocal's relative error (< 4e-7): decide with 2^-12 slack
   const double slack = 1.0 / 4096.0;
-  if (tf + fabs(tf) * slack < tn - tn * slack) return GRID_MISS;
-  w.t0 = tn - tn * slack;  // never later than the true entry; >= 0
+  w.t0 = __builtin_fma(-tn, slack, tn);  // never later than the true entry; >= 0
+  if (__builtin_fma(fabs(tf), slack, tf) < w.t0) return GRID_MISS;
   bool sane = true;
   int lin = 0, stride = 1;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const double op = ol[k] + w.t0 * dl[k];
-    sane = sane && op >= -2.0 && op <= (double)G.n[k] + 2.0;
+    const double op = __builtin_fma(w.t0, dl[k], ol[k]);
+    sane = sane && op >= -2.0 && op <= G.nd[k] + 2.0;
     const float of = sane ? (float)op : 0.0f;
     int i = (int)floorf(of);
     i = i < 0 ? 0 : (i > (int)G.n[k] - 1 ? (int)G.n[k] - 1 : i);
@@ -1150,9 +1167,15 @@ RT_HD void lane_finish_sample(LaneT& L, Rgb leaf) {
 // the reference's sequential f32 sum only by that sum's own rounding (a few 1e-7 relative).
 constexpr double FIX_SCALE = 1099511627776.0;  // 2^40; sample values are in [0,1]
 RT_HD unsigned long long sample_to_fixed(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // clamp in f32, one v_med3_f32: NaN and negatives -> 0 (min3 of a NaN operand set), above 1 -> 1 — the same values as the
+  // compares below (the conversion to f64 is exact and monotone, so clamping before it changes nothing)
+  double x = (double)__builtin_amdgcn_fmed3f(v, 0.0f, 1.0f);
+#else
   double x = (double)v;
   if (!(x > 0.0)) return 0ull;
   if (x > 1.0) x = 1.0;  // every sample is clamp01'ed at the root level already
+#endif
   // (unsigned long long)(x * 2^40 + 0.5), written so that the GPU needs no 64-bit float->int
   // conversion (it has none: 10 instructions per channel): the truncated value is an integer
   // below 2^41, so adding 2^52 is exact and leaves it in the low mantissa bits.

@@ -130,6 +130,8 @@ inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
     const double w = ext[k] / ((double)G.n[k] - 2.0 * edge);  // cell width such that the spheres span [edge, n - edge] cells
     G.gmin[k] = lo[k] - edge * w;
     G.inv_cell[k] = 1.0 / w;
+    G.goff[k] = -G.gmin[k] * G.inv_cell[k];
+    G.nd[k] = (double)G.n[k];
   }
   G.pull = (float)(8.0 * grid_walk_eps(std::max(G.n[0], std::max(G.n[1], G.n[2]))));
   const uint32_t n_inner = G.n[0] * G.n[1] * G.n[2];
