@@ -257,10 +257,11 @@ int rt_hip_hit_probe(const double* rays, const double* spheres, double* out_t, u
  * (u, v) — v_rsq_f64 / v_rcp_f64 + Newton steps, which only the device build takes — beside the exact path, for n hit
  * points (device, 3 doubles each) on the sphere centre_radius (host, 4 doubles).  d_out = n x {fast_ok, fast col, fast
  * row, exact col, exact row} (u64); d_uv (optional) = n x {fast u, fast v, exact u, exact v}, fast u = NaN where the fast
- * path declined.  rt_hip_quot_probe: rt_fast_quot(x, y) and rt_fast_rsqrt(x) of n positive normal operands. */
+ * path declined.  rt_hip_quot_probe: rt_fast_quot(x, y), rt_fast_rsqrt(x) and (d_div optional) rt_div_inrange(x, y) — the
+ * library division without range scaling and fix-up: must equal the IEEE quotient — of n positive normal operands. */
 int rt_hip_texel_probe(const double* d_points, const double centre_radius[4], double h_offset, uint64_t tex_w, uint64_t tex_h,
                        uint64_t* d_out, double* d_uv, uint32_t n, void* stream);
-int rt_hip_quot_probe(const double* d_x, const double* d_y, double* d_quot, double* d_rsqrt, uint32_t n, void* stream);
+int rt_hip_quot_probe(const double* d_x, const double* d_y, double* d_quot, double* d_rsqrt, double* d_div, uint32_t n, void* stream);
 /* Tunables / A-B arms.  Keys: "variant" 0 = grid walk (default), 1 = the
  * reference's brute force (exact test on every sphere);
  * "chunk_spp" samples of a pixel per work item (0 = automatic); "tile_log2" pixel tiles of

@@ -573,9 +573,9 @@ extern "C" int rt_hip_texel_probe(const double* d_points, const double centre_ra
   return RT_OK;
 }
 
-extern "C" int rt_hip_quot_probe(const double* d_x, const double* d_y, double* d_quot, double* d_rsqrt, uint32_t n, void* stream) {
+extern "C" int rt_hip_quot_probe(const double* d_x, const double* d_y, double* d_quot, double* d_rsqrt, double* d_div, uint32_t n, void* stream) {
   if (!d_x || !d_y || !d_quot || !d_rsqrt) return fail(RT_ERR_INVALID, "null argument");
-  hipLaunchKernelGGL(rtk::rt_quot_probe, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_x, d_y, d_quot, d_rsqrt, n);
+  hipLaunchKernelGGL(rtk::rt_quot_probe, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_x, d_y, d_quot, d_rsqrt, d_div, n);
   RT_HIP_TRY(hipGetLastError());
   return RT_OK;
 }

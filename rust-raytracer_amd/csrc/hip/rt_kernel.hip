@@ -1040,12 +1040,13 @@ __global__ void rt_texel_probe(const double* points, double cx, double cy, doubl
   out[5 * i + 3] = sat_u64(floor(rot * (double)tex_w)); out[5 * i + 4] = sat_u64(floor((1.0 - ex.v) * (double)(tex_h - 1)));
   if (uv) { uv[4 * i] = fa.u; uv[4 * i + 1] = fa.v; uv[4 * i + 2] = ex.u; uv[4 * i + 3] = ex.v; }
 }
-// rt_fast_quot(x, y) and rt_fast_rsqrt(x) as the device evaluates them (x, y normal and positive)
-__global__ void rt_quot_probe(const double* x, const double* y, double* out_quot, double* out_rsqrt, uint32_t n) {
+// rt_fast_quot(x, y), rt_fast_rsqrt(x) and rt_div_inrange(x, y) as the device evaluates them (x, y normal and positive)
+__global__ void rt_quot_probe(const double* x, const double* y, double* out_quot, double* out_rsqrt, double* out_div, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   out_quot[i] = rt_fast_quot(x[i], y[i]);
   out_rsqrt[i] = rt_fast_rsqrt(x[i]);
+  if (out_div) out_div[i] = rt_div_inrange(x[i], y[i]);
 }
 
 }  // namespace rtk

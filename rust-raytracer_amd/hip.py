@@ -55,7 +55,7 @@ def lib():
         L.rt_hip_group_frame.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.rt_hip_group_frame.restype = C.c_void_p
         L.rt_hip_texel_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
-        L.rt_hip_quot_probe.argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_void_p]
+        L.rt_hip_quot_probe.argtypes = [C.c_void_p] * 5 + [C.c_uint32, C.c_void_p]
         L.rt_hip_group_stacked_row.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
         L.rt_hip_group_stacked_row.restype = C.c_uint32
         for name in ("RtSphere", "RtTexture", "RtScene", "RtRowTiles", "RtStats", "RtGroupInfo"):   # the binding's own layout check

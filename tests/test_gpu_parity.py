@@ -899,8 +899,8 @@ def test_device_fast_texel_arithmetic(pkg, torch_cuda):
     y = np.abs(rng.standard_normal(m)) * 10.0 ** rng.uniform(-100, 100, m) + 1e-300
     x[:4] = [1.0, 2.0, 0.5, 3.0]; y[:4] = [1.0, 3.0, 0.75, 7.0]
     dx, dy = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
-    dq, dr = torch.zeros_like(dx), torch.zeros_like(dx)
-    assert L.rt_hip_quot_probe(dx.data_ptr(), dy.data_ptr(), dq.data_ptr(), dr.data_ptr(), m, None) == 0
+    dq, dr, dd = torch.zeros_like(dx), torch.zeros_like(dx), torch.zeros_like(dx)
+    assert L.rt_hip_quot_probe(dx.data_ptr(), dy.data_ptr(), dq.data_ptr(), dr.data_ptr(), dd.data_ptr(), m, None) == 0
     torch.cuda.synchronize()
     q, r = dq.cpu().numpy(), dr.cpu().numpy()
     with np.errstate(over="ignore", under="ignore"):
@@ -910,6 +910,22 @@ def test_device_fast_texel_arithmetic(pkg, torch_cuda):
     rel_r = float(np.abs(r / want_r - 1.0).max())
     print(f"device rt_fast_quot: max rel err {rel_q:.2e} ({rel_q / 2.0 ** -53:.1f} x 2^-53); rt_fast_rsqrt: {rel_r:.2e}")
     assert rel_q < 4.0 * 2.0 ** -53 and rel_r < 8.0 * 2.0 ** -53
+    # rt_div_inrange (1/|d|^2 of every ray, 1/|d| of Glass hits): the library division without range scaling and fix-up
+    # must BE the IEEE quotient wherever the kernel uses it (divisor in [1e-150, 1e150], quotient in [1e-290, 1e290] or zero)
+    m2 = 1 << 21
+    yb = np.abs(rng.standard_normal(m2)) * 10.0 ** rng.uniform(-149, 149, m2) + 1e-150
+    xb = np.where(rng.random(m2) < 0.5, 1.0, np.abs(rng.standard_normal(m2)) * 10.0 ** rng.uniform(-100, 100, m2))
+    xb[:3] = [0.0, 1.0, 3.0]; yb[:3] = [7.0, 3.0, 1.0]
+    with np.errstate(over="ignore", under="ignore"):
+        want_d = xb / yb
+    use = (want_d == 0.0) | ((np.abs(want_d) > 1e-290) & (np.abs(want_d) < 1e290))
+    dxb, dyb = torch.from_numpy(xb).cuda(), torch.from_numpy(yb).cuda()
+    o1, o2, o3 = torch.zeros_like(dxb), torch.zeros_like(dxb), torch.zeros_like(dxb)
+    assert L.rt_hip_quot_probe(dxb.data_ptr(), dyb.data_ptr(), o1.data_ptr(), o2.data_ptr(), o3.data_ptr(), m2, None) == 0
+    torch.cuda.synchronize()
+    got_d = o3.cpu().numpy()
+    assert np.array_equal(got_d[use].view(np.uint64), want_d[use].view(np.uint64)), int((got_d[use] != want_d[use]).sum())
+    print(f"device rt_div_inrange: {int(use.sum())} in-range quotients equal the IEEE quotient bit for bit")
 
 
 def _cover_800x600(host, spp, seed=0):
