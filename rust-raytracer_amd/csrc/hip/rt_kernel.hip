@@ -190,6 +190,11 @@ __device__ __forceinline__ const KArgs& fresh_args() {
 // attempt 0, and get its first two words back in `glass_u`.
 // Lanes that just took a new sample (`fresh`; they hold no hit) make the Philox call of its camera jitter (node
 // NODE_CAMERA, slot 0, raytracer.rs:199-200) in the same stream and get its four words back in `cam_w`.
+// ceil(65536 / n) for n = 1 .. 64: (lane * m) >> 16 == lane / n for every lane < 64 (checked for all 4096 pairs by the generator)
+__device__ __constant__ const uint32_t kCeil65536Over[65] = {
+    0, 65536, 32768, 21846, 16384, 13108, 10923, 9363, 8192, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4096, 3856, 3641, 3450, 3277, 3121,
+    2979, 2850, 2731, 2622, 2521, 2428, 2341, 2260, 2185, 2115, 2048, 1986, 1928, 1873, 1821, 1772, 1725, 1681, 1639, 1599, 1561, 1525,
+    1490, 1457, 1425, 1395, 1366, 1338, 1311, 1286, 1261, 1237, 1214, 1192, 1171, 1150, 1130, 1111, 1093, 1075, 1058, 1041, 1024};
 // Glass lanes also get the light-sampling draw of their node back (same Philox call, words z w: raytracer.rs:100) in `glass_lu`.
 __device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, bool glass, bool fresh, const RngAddr& ra, uint32_t node, uint32_t lane,
                                                          uint4* xch, double& glass_u, double& glass_lu, U4& cam_w) {
@@ -209,11 +214,18 @@ __device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, bool glass, 
     const unsigned long long F = wave_ballot(pending);
     if (!F) break;
     const uint32_t nf = (uint32_t)__builtin_popcountll(F);
+    // Everything that depends on nf alone is wave-uniform and stays on the scalar unit: the compiler turned `64 / nf` and
+    // `ceil(65536 / nf)` into ~20 VECTOR instructions of float-reciprocal division per helper round (there is no scalar
+    // integer division), and the search for a failing lane's first accepted layer into ~20 more.
+#if RT_COOP_LAYERS == 4
+    const uint32_t layers = nf <= 16u ? 4u : (nf <= 21u ? 3u : (nf <= 32u ? 2u : 1u));  // min(4, 64 / nf)
+#else
     uint32_t layers = 64u / nf;
     if (layers > RT_COOP_LAYERS) layers = RT_COOP_LAYERS;
+#endif
     const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(F >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)F, 0u));
     if (pending) xch[r] = make_uint4(ra.pixel, ra.sample, node, 0u);
-    const uint32_t m = (65536u + nf - 1u) / nf;  // j = lane / nf for lane < 64 by multiplication
+    const uint32_t m = kCeil65536Over[nf];  // j = lane / nf for lane < 64 by multiplication (scalar load of a 65-entry table)
     const uint32_t j = (lane * m) >> 16, q = lane - j * nf;
     const bool helping = j < layers;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -229,14 +241,21 @@ __device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, bool glass, 
     const unsigned long long A = wave_ballot(acc);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every helper has read its slot: reuse them for the answers
     if (acc) xch[lane] = make_uint4(hx, hy, hz, 0u);
-    // failing lane #r: its helpers are lanes r, r + nf, r + 2 nf, ...: the lowest layer that accepted
-    uint32_t from = 0;
-    bool found = false;
-    if (pending) {
-      const unsigned long long mine = A >> r;
-      for (uint32_t l = 0; l < RT_COOP_LAYERS; ++l)
-        if (!found && l < layers && ((mine >> (l * nf)) & 1ull)) { found = true; from = r + l * nf; }
+    // failing lane #r: its helpers are lanes r, r + nf, r + 2 nf, ...: the lowest layer that accepted = the lowest set bit
+    // of (A >> r) under the (wave-uniform) pattern of bits 0, nf, 2 nf, ... below layers * nf
+    unsigned long long pat = 1ull;
+    {
+      const unsigned long long p1 = 1ull << (nf & 63u);
+      if (layers > 1u) pat |= p1;
+      if (layers > 2u) pat |= p1 << (nf & 63u);
+      if (layers > 3u) pat |= (p1 << (nf & 63u)) << (nf & 63u);
+#if RT_COOP_LAYERS > 4
+      for (uint32_t l = 4; l < layers; ++l) pat |= 1ull << (l * nf);
+#endif
     }
+    const unsigned long long mine = pending ? ((A >> r) & pat) : 0ull;
+    const bool found = mine != 0ull;
+    const uint32_t from = r + (uint32_t)__builtin_ctzll(mine | (1ull << 63));
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (found) {
       const uint4 g = xch[from];
