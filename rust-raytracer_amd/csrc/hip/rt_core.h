@@ -217,14 +217,19 @@ RT_HD bool recip_safe(double b) { double m = fabs(b); return m > 1e-150 && m < 1
 // (v_div_scale_f64 x 2, identity for such operands) and special-case fix-up (v_div_fixup_f64: zero / infinite / NaN
 // operands): the same instructions on the same values, three fewer of them.  The CPU build divides.
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ double rt_div_inrange(double x, double b) {
+__device__ __forceinline__ double rt_recip_refined(double b) {  // the division's refined reciprocal estimate (NOT RN(1/b): only for rt_div_by_refined)
   double y = __builtin_amdgcn_rcp(b);
   y = __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
-  y = __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
+  return __builtin_fma(y, __builtin_fma(-b, y, 1.0), y);
+}
+__device__ __forceinline__ double rt_div_by_refined(double x, double b, double y) {  // x / b given y = rt_recip_refined(b): several quotients by one divisor share y
   const double q = x * y;
   return __builtin_fma(__builtin_fma(-b, q, x), y, q);
 }
+__device__ __forceinline__ double rt_div_inrange(double x, double b) { return rt_div_by_refined(x, b, rt_recip_refined(b)); }
 #else
+RT_HD double rt_recip_refined(double b) { return b; }
+RT_HD double rt_div_by_refined(double x, double b, double) { return x / b; }
 RT_HD double rt_div_inrange(double x, double b) { return x / b; }
 #endif
 
@@ -474,6 +479,13 @@ struct GridWalk {
 };
 enum { GRID_MISS = 0, GRID_WALK = 1, GRID_FALLBACK = 2 };
 
+RT_HD int rt_mul24(int a, int b) {  // a * b for 0 <= a, b < 2^24
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (int)__umul24((unsigned)a, (unsigned)b);
+#else
+  return a * b;
+#endif
+}
 RT_HD float rt_rcpf(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_rcpf(x);  // 1 ulp; the walk's margins budget several
@@ -541,7 +553,7 @@ RT_HD int grid_begin(const GridDesc& G, V3 o, V3 d, GridWalk& w) {
     w.delta[k] = fabsf(inv[k]);
     w.tmax[k] = __builtin_fmaf(b - of, inv[k], -G.pull * w.delta[k]);
     w.dl[k] = pos ? stride : -stride;
-    lin += (i + 1) * stride;                          // +1: the EXIT border
+    lin += rt_mul24(i + 1, stride);                   // +1: the EXIT border (both factors < 2^24: v_mul_u32_u24 is full rate, v_mul_lo_u32 a quarter)
     stride *= (int)G.n[k] + 2;
   }
   if (!sane) return GRID_FALLBACK;
@@ -707,11 +719,25 @@ RT_HD void fwd_compose(FwdT<true>& f, const float*, const float a[3]) {
 // raytracer.rs:134-160: colour of a ray that left the scene
 RT_HD Rgb sky_color(const DevScene& sc, V3 d, uint32_t& tex_oob) {
   if (sc.sky_mode == RT_SKY_NONE) return rgb(0.0f, 0.0f, 0.0f);
-  double l = length(d);
-  float t = clamp01(0.5f * ((float)(d.y / l) + 1.0f));
-  if (sc.sky_mode == RT_SKY_GRADIENT)
+  // unit(dir).y and .x as f32 (raytracer.rs:135-136).  |d|^2 in [2^-500, 2^500] (every ordinary ray): the square root's short
+  // form and the division's core without range scaling, the two quotients sharing one refined reciprocal — the f64
+  // quotients are the IEEE ones unless they are so small (< 2^-300) that their f32 conversion is a signed zero either way.
+  const double a = length_squared(d);
+  const bool want_x = sc.sky_mode != RT_SKY_GRADIENT;
+  double qy, qx = 0.0;
+  if (a >= 0x1p-500 && a <= 0x1p+500) {
+    const double l = rt_sqrt(a), yl = rt_recip_refined(l);
+    qy = rt_div_by_refined(d.y, l, yl);
+    if (want_x) qx = rt_div_by_refined(d.x, l, yl);
+  } else {
+    const double l = rt_sqrt(a);
+    qy = d.y / l;
+    if (want_x) qx = d.x / l;
+  }
+  float t = clamp01(0.5f * ((float)qy + 1.0f));
+  if (!want_x)
     return rgb((1.0f - t) * 1.0f + t * 0.5f, (1.0f - t) * 1.0f + t * 0.7f, (1.0f - t) * 1.0f + t * 1.0f);
-  float u = clamp01(0.5f * ((float)(d.x / l) + 1.0f));
+  float u = clamp01(0.5f * ((float)qx + 1.0f));
   uint64_t x = sat_u64_f32(u * (float)(sc.sky_w - 1));
   uint64_t y = sat_u64_f32((1.0f - t) * (float)(sc.sky_h - 1));
   uint64_t base = (y * sc.sky_w + x) * 3;

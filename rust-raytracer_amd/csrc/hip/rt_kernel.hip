@@ -226,7 +226,7 @@ __device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, bool glass, 
     const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(F >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)F, 0u));
     if (pending) xch[r] = make_uint4(ra.pixel, ra.sample, node, 0u);
     const uint32_t m = kCeil65536Over[nf];  // j = lane / nf for lane < 64 by multiplication (scalar load of a 65-entry table)
-    const uint32_t j = (lane * m) >> 16, q = lane - j * nf;
+    const uint32_t j = __umul24(lane, m) >> 16, q = lane - __umul24(j, nf);
     const bool helping = j < layers;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     bool acc = false;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   // ---- a sample finished (its radiance is in L.val): add it to its pixel (raytracer.rs:203-205) ...
   auto add_sample = [&](bool finished) {
     if (finished) {
-      unsigned long long* acc = tile_acc + my_k * acc_stride + cur_p * 3u;
+      unsigned long long* acc = tile_acc + __umul24(my_k, acc_stride) + __umul24(cur_p, 3u);  // (24-bit factors: full-rate multiplies)
       atomicAdd(&acc[0], sample_to_fixed(L.val[0]));
       atomicAdd(&acc[1], sample_to_fixed(L.val[1]));
       atomicAdd(&acc[2], sample_to_fixed(L.val[2]));
