@@ -264,7 +264,8 @@ int rt_hip_texel_probe(const double* d_points, const double centre_radius[4], do
 int rt_hip_quot_probe(const double* d_x, const double* d_y, double* d_quot, double* d_rsqrt, double* d_div, uint32_t n, void* stream);
 /* Tunables / A-B arms.  Keys: "variant" 0 = grid walk (default), 1 = the
  * reference's brute force (exact test on every sphere);
- * "chunk_spp" samples of a pixel per work item (0 = automatic); "tile_log2" pixel tiles of
+ * "chunk_spp" samples of a pixel per work item (0 = automatic); "tile_batch" tiles a workgroup takes from the frame's
+ * queue at a time (0 = automatic, 1..64); "tile_log2" pixel tiles of
  * 4^k pixels (k = 0..3, -1 = automatic); "tile_shape" 0 (default) = a 2^k x 2^k square, 1 = a run of 4^k pixels of one
  * scanline (one contiguous piece of the framebuffer: half the HBM write traffic, 0.9 % slower), 2 and 3 = the square widened
  * once and twice (16x4 and 32x2 at k = 3); "tile_affinity" 1 (default) = on large frames, runs of 512 pixels of a

@@ -63,6 +63,7 @@ struct RtHipScene {
   int order_mode = 2;       // "tile_order" option: 0 top row first, 1 bottom row first, 2 deepest tiles of the previous frame first
   int light_pool_cap = 0;  // "light_pool" option: cap on the light-frame pool of lit scenes (0 = as many as fit; tests shrink it to force the fall-back)
   int chunk_spp = 0;       // 0 = automatic
+  int tile_batch = 0;      // 0 = automatic; else tiles a workgroup takes from the queue per atomic, 1..64
   int tile_log2 = -1;      // -1 = automatic; else tiles of 4^k pixels, k = 0..3
   int tile_shape = 0;      // 0: 2^k x 2^k squares (default: 0.9 % faster); 1: runs of 4^k pixels of one scanline (contiguous
                            // framebuffer bytes: HBM writes 10.9 -> 5.9 MiB per 1200x800 frame, profiles/r02_run8_*)
@@ -212,6 +213,7 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
   if (!std::strcmp(key, "tile_affinity")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_affinity must be 0 (off), 1 (large frames) or 2 (any frame of 8+ runs: tests)"); s->tile_affinity = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
   if (!std::strcmp(key, "tile_order")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_order must be 0, 1 or 2"); s->order_mode = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
   if (!std::strcmp(key, "light_pool")) { if (value < 0 || value > 1024 || (value != 0 && value < 32)) return fail(RT_ERR_INVALID, "light_pool must be 0 (automatic) or 32..1024"); s->light_pool_cap = (int)value; return RT_OK; }
+  if (!std::strcmp(key, "tile_batch")) { if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "tile_batch must be 0..64"); s->tile_batch = (int)value; return RT_OK; }
   if (!std::strcmp(key, "chunk_spp")) { if (value < 0) return fail(RT_ERR_INVALID, "chunk_spp must be >= 0"); s->chunk_spp = (int)value; return RT_OK; }
   if (!std::strcmp(key, "samples_per_pixel") || !std::strcmp(key, "max_depth")) {
     if (value < 0 || value > (int64_t)0xFFFFFFFFll) return fail(RT_ERR_INVALID, std::string(key) + " must be in 0 .. 2^32-1");
@@ -370,6 +372,17 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   ka.chunk_spp = chunk_spp;
   ka.n_chunks = spp ? (spp + chunk_spp - 1) / chunk_spp : 1;
   const uint32_t n_items = ka.n_tiles * ka.n_chunks;
+  // Tiles a workgroup takes from the frame's queue per atomic (rt_kernel.hip: wg_stash), at most, and the taper towards
+  // single tiles at the end of the frame: remaining tiles / (workgroups x 16).  Measured (profiles/r03_run26_batch_sweep.log):
+  // what counts is that ONE wave of a workgroup asks the queue at a time (cover frame at spp 8 / 32 / 128: 1.49 -> 1.15,
+  // 3.71 -> 3.35, 12.92 -> 12.80 ms with batches of one); batches of 4 add 5 % on frames of small tiles (test scene 1.09 ->
+  // 1.03 ms).  Not more: a batch is a run of the queue's order, and that order puts the deepest tiles first — 8 or 16 of
+  // them in one workgroup are the critical path of a short frame (1/8 shard: 1.76 -> 1.87 -> 2.45 ms).
+  ka.tile_batch = s->tile_batch > 0 ? (uint32_t)s->tile_batch : 4u;
+  ka.batch_share = 16u;
+#ifdef RT_DEV_KNOBS
+  if (const char* e = std::getenv("RT_BATCH_SHARE")) { const int v = std::atoi(e); if (v >= 1 && v <= 1024) ka.batch_share = (uint32_t)v; }
+#endif
   // LDS budget.  Tables + tile slots + (lit scenes) one light frame per lane: everything in LDS.  A lit scene whose tables do
   // not fit beside 1024 light frames (80 KB) keeps its TABLES in LDS and shares a pool of as many frames as still fit —
   // if that covers 1.5 x the expected demand: a camera path starts summing over the n lights with probability ~0.1 n at

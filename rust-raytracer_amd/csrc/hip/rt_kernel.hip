@@ -42,6 +42,7 @@ struct KArgs {
   uint32_t tile_wl, tile_hl;  // ... 2^tile_wl wide, 2^tile_hl high (tile_wl + tile_hl == 2 * tile_log2): square (8x8 ... 1x1) by
                               // default, or 64x1, 16x1, 4x1, 1x1 — one tile is one contiguous run of framebuffer bytes
   uint32_t t_slots;    // tile slots per workgroup (tile_slots() of tile_log2)
+  uint32_t tile_batch, batch_share;  // tiles a workgroup takes from the queue per atomic (at most), and the taper: rem / (workgroups * batch_share)
   // Queue order.  The frame ends on its deepest paths (50 sequential segments of a lone wave), so the tiles
   // that breed them should leave the queue FIRST: position i of the queue is tile tile_order[i] (null: n_tiles-1-i, bottom
   // of the image first — the sky rows last).  tile_depth[tile] receives the deepest camera path seen in the tile; the
@@ -173,6 +174,7 @@ __device__ __forceinline__ const KArgs& fresh_args() {
 #ifndef RT_FUSED_REFILL
 #define RT_FUSED_REFILL 1
 #endif
+
 #ifndef RT_HANDOUT_DIRECT
 #define RT_HANDOUT_DIRECT 0
 #endif
@@ -314,6 +316,13 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     hdr[i] = h;
   }
   if (threadIdx.x == 0) { wg_flags[0] = 0u; wg_flags[1] = 0u; wg_flags[2] = 0u; wg_flags[3] = 0u; }
+  // Tiles this workgroup has taken from the frame's queue and not opened yet: (end << 32 | next), positions in queue
+  // order; empty when next >= end.  The queue is ONE counter (eight with XCD affinity, in one cache line) that every
+  // workgroup of the chip adds to: taken one tile at a time, the opening wave waited ~27 us for it at 15 tiles/us
+  // (RT_PROFILE sections against samples per pixel, profiles/r03_run25_spp_prof.log) — a fixed ~0.4 ms of every frame.
+  unsigned long long* const wg_stash = reinterpret_cast<unsigned long long*>(lds_raw + 16);
+  uint32_t* const wg_batch = reinterpret_cast<uint32_t*>(lds_raw + 24);  // tiles the next batch asks for
+  if (threadIdx.x == 0) { *wg_stash = 0ull; *wg_batch = ka.tile_batch; }
   // the XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0; MI355X_MICROARCH.md): affinity only, never correctness
   const uint32_t my_xcd = (uint32_t)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;
   unsigned long long* const wg_counters = reinterpret_cast<unsigned long long*>(lds_raw + 32);
@@ -485,27 +494,60 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       uint32_t ok = 0;
       if (lane == 0) ok = atomicCAS(&hdr[k].state, (uint32_t)SLOT_FREE, (uint32_t)SLOT_OPENING) == (uint32_t)SLOT_FREE ? 1u : 0u;
       if (!bcast(ok)) continue;  // another wave claimed it: rescan
+      // the next tile: from the workgroup's stash; whoever finds it empty first fetches the next batch from the queue
       uint32_t tile = 0;
       if (lane == 0) {
-        if (ka.aff_group_log2 == 0xFFFFFFFFu) {
-          tile = atomicAdd(ka.queue, 1u);
-          if (tile < ka.n_tiles && ka.order_mode != 0u) tile = ka.tile_order ? ka.tile_order[tile] : ka.n_tiles - 1u - tile;
-        } else {  // this XCD's queue first, then the others'
-          tile = ka.n_tiles;
-          uint32_t dry = lds_load(&wg_flags[3]);  // queues this workgroup has seen empty
-          for (uint32_t q = 0; q < 8u && tile == ka.n_tiles; ++q) {
-            const uint32_t x = (my_xcd + q) & 7u;
-            if ((dry >> x) & 1u) continue;
-            const uint32_t cnt = ka.xcd_cnt[x];
-            uint32_t j = atomicAdd(&ka.queue[x], 1u);
-            if (j >= cnt) { dry |= 1u << x; continue; }
-            if (ka.tile_order) tile = ka.tile_order[ka.xcd_off[x] + j];
-            else tile = xcd_tile(x, ka.order_mode != 0u ? cnt - 1u - j : j, ka.aff_group_log2);
+        uint32_t g = 0xFFFFFFFFu;  // position in queue order; n_tiles: the frame has none left; ~0: a batch is on its way
+        const unsigned long long old = atomicAdd(wg_stash, 1ull);
+        const uint32_t s_next = (uint32_t)old, s_end = (uint32_t)(old >> 32);
+        if (s_next < s_end) g = s_next;
+        else if (s_next == s_end) {
+          const uint32_t B = lds_load(wg_batch);
+          uint32_t end = 0, rem = 0, share = gridDim.x * ka.batch_share;
+          g = ka.n_tiles;
+          if (ka.aff_group_log2 == 0xFFFFFFFFu) {
+            const uint32_t j = atomicAdd(ka.queue, B);
+            if (j < ka.n_tiles) { g = j; end = j + B < ka.n_tiles ? j + B : ka.n_tiles; rem = ka.n_tiles - end; }
+          } else {  // this XCD's queue first, then the others'
+            uint32_t dry = lds_load(&wg_flags[3]);  // queues this workgroup has seen empty
+            for (uint32_t q = 0; q < 8u && g == ka.n_tiles; ++q) {
+              const uint32_t x = (my_xcd + q) & 7u;
+              if ((dry >> x) & 1u) continue;
+              const uint32_t cnt = ka.xcd_cnt[x];
+              const uint32_t j = atomicAdd(&ka.queue[x], B);
+              if (j >= cnt) { dry |= 1u << x; continue; }
+              const uint32_t e = j + B < cnt ? j + B : cnt;
+              g = ka.xcd_off[x] + j; end = ka.xcd_off[x] + e; rem = cnt - e;
+            }
+            share = (gridDim.x + 7u) / 8u * ka.batch_share;
+            __hip_atomic_fetch_or(&wg_flags[3], dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
-          __hip_atomic_fetch_or(&wg_flags[3], dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (g < ka.n_tiles) {
+            // the next batch: a quarter of a workgroup's fair share of what the queue still holds — single tiles at the
+            // end of the frame, where a stashed tile is work no other workgroup can take
+            const uint32_t nb = rem / share;
+            lds_store(wg_batch, nb < 1u ? 1u : (nb > ka.tile_batch ? ka.tile_batch : nb));
+            __hip_atomic_exchange(wg_stash, ((unsigned long long)end << 32) | (unsigned long long)(g + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+        tile = g;
+        if (g < ka.n_tiles) {  // queue position -> tile
+          if (ka.aff_group_log2 == 0xFFFFFFFFu) {
+            if (ka.order_mode != 0u) tile = ka.tile_order ? ka.tile_order[g] : ka.n_tiles - 1u - g;
+          } else if (ka.tile_order) tile = ka.tile_order[g];
+          else {
+            uint32_t x = 0;
+            while (x < 7u && g >= ka.xcd_off[x + 1u]) ++x;
+            const uint32_t j = g - ka.xcd_off[x];
+            tile = xcd_tile(x, ka.order_mode != 0u ? ka.xcd_cnt[x] - 1u - j : j, ka.aff_group_log2);
+          }
         }
       }
       tile = bcast(tile);
+      if (tile == 0xFFFFFFFFu) {  // another wave is fetching a batch: ask again in the next iteration
+        if (lane == 0) lds_store(&hdr[k].state, (uint32_t)SLOT_FREE);
+        return 0;
+      }
       if (tile >= ka.n_tiles) {  // the frame's queue is empty
         if (lane == 0) { lds_store(&wg_flags[0], 1u); lds_store(&hdr[k].state, (uint32_t)SLOT_FREE); }
         continue;

@@ -166,6 +166,13 @@ def test_work_distribution_stress(gpu_render, load_scene):
     for tl, cs, order in ((0, 1, 2), (0, 5, 1), (1, 1, 0), (2, 2, 2), (3, 1, 2), (3, 5, 0)):
         rgb, lin, st = gpu_render(sc, chunk_spp=cs, tile_log2=tl, tile_order=order, tile_affinity=2, frames=3 if order == 2 else 1)
         assert np.array_equal(rgb, ref_rgb) and np.array_equal(lin, ref_lin) and st["segments"] == ref_st["segments"], ("affinity", tl, cs, order)
+    # tiles taken from the queue 1 / 3 / 64 at a time (the workgroup's stash): one queue and per-XCD queues, every order, and
+    # batches larger than a queue's share (the taper, the clipped last batch, a frame with fewer tiles than one batch)
+    for batch in (1, 3, 64):
+        for tl, cs, order, aff in ((0, 1, 2, 0), (0, 5, 1, 2), (1, 1, 0, 2), (2, 2, 2, 2), (3, 1, 2, 0), (3, 5, 0, 2)):
+            rgb, lin, st = gpu_render(sc, chunk_spp=cs, tile_log2=tl, tile_order=order, tile_affinity=aff, frames=3 if order == 2 else 1,
+                                      opts={"tile_batch": batch})
+            assert np.array_equal(rgb, ref_rgb) and np.array_equal(lin, ref_lin) and st["segments"] == ref_st["segments"], ("batch", batch, tl, cs, order, aff)
     # the lit kernel (parked light frames in LDS beside the tile slots) under the same contention
     lit = load_scene("test", 101, 67, 6, 8)
     l_rgb, l_lin, l_st = gpu_render(lit)
