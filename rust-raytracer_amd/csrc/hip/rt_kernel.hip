@@ -174,6 +174,9 @@ __device__ __forceinline__ const KArgs& fresh_args() {
 #ifndef RT_FUSED_REFILL
 #define RT_FUSED_REFILL 1
 #endif
+#ifndef RT_STASH_SPIN
+#define RT_STASH_SPIN 0
+#endif
 
 #ifndef RT_HANDOUT_DIRECT
 #define RT_HANDOUT_DIRECT 0
@@ -498,7 +501,13 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       uint32_t tile = 0;
       if (lane == 0) {
         uint32_t g = 0xFFFFFFFFu;  // position in queue order; n_tiles: the frame has none left; ~0: a batch is on its way
-        const unsigned long long old = atomicAdd(wg_stash, 1ull);
+        unsigned long long old = atomicAdd(wg_stash, 1ull);
+#if RT_STASH_SPIN  // (A/B arm: wait a few us for the batch another wave is fetching instead of idling the asking lanes for an iteration)
+        for (int spin = 0; spin < RT_STASH_SPIN && (uint32_t)old > (uint32_t)(old >> 32) && lds_load(&wg_flags[0]) == 0u; ++spin) {
+          __builtin_amdgcn_s_sleep(8);
+          old = atomicAdd(wg_stash, 1ull);
+        }
+#endif
         const uint32_t s_next = (uint32_t)old, s_end = (uint32_t)(old >> 32);
         if (s_next < s_end) g = s_next;
         else if (s_next == s_end) {
