@@ -115,6 +115,13 @@ def _pmc_head(pmc):
     return (pmc or {}).get("git_head")
 
 
+def _build_info(key):
+    try:
+        return json.load(open(os.path.join(ROOT, "rust-raytracer_amd", "BUILD_INFO.json"))).get(key)
+    except Exception:
+        return None
+
+
 def _git_head():
     """the commit librt_hip.so was built from (BUILD_INFO.json, written by build(): the GPU box has no .git)"""
     try:
@@ -125,7 +132,11 @@ def _git_head():
 
 def _scene_pmc(key):
     """newest profiles/rNN_*pmc_<key>.json (counters of another BASELINE config, tools/pmc_scene.sh)"""
-    c = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*pmc_{key}.json")))
+    def run_key(p):   # (round, run number): "r03_run11" is newer than "r03_run1" — a plain string sort says otherwise
+        b = os.path.basename(p)
+        run = re.search(r"run(\d+)", b)
+        return (b.split("_")[0], int(run.group(1)) if run else -1)
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*pmc_{key}.json")), key=run_key)
     if not c:
         return None
     try:
@@ -415,7 +426,8 @@ def run_ranks(args):
             roof["lane_utilisation"] = round(thr / (64.0 * act), 4)
             roof["counters"] = {"SQ_THREAD_CYCLES_VALU": thr, "SQ_ACTIVE_INST_VALU": act, "SQ_INSTS_VALU": m.get("SQ_INSTS_VALU"),
                                 "source": os.path.relpath(pmc_path, ROOT), "kernel_ms_of_that_run": pmc.get("kernel_ms"),
-                                "git_head_of_that_build": pmc.get("git_head"), "git_head_of_this_build": _git_head()}
+                                "git_head_of_that_build": pmc.get("git_head"), "git_head_of_this_build": _git_head(),
+                                "same_kernel_sources": (pmc.get("kernel_src_hash") == _build_info("kernel_src_hash")) if pmc.get("kernel_src_hash") else None}
             if pmc.get("hbm_bytes_per_launch") is not None:
                 alg_bytes = 3 * W * H + 32 * N_SPH * 2 + 8 * 4800   # framebuffer + one pass over geometry/material/cell tables
                 roof["traffic"] = pmc["hbm_bytes_per_launch"]

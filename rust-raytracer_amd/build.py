@@ -38,8 +38,7 @@ def build_host(force=False):
 def build_hip(force=False):
     out = os.path.join(HERE, "librt_hip.so")
     src = _srcs("csrc/hip/rt_hip_api.hip")
-    deps = src + _srcs("csrc/hip/rt_kernel.hip", "csrc/hip/rt_hip_group.hip", "csrc/hip/rt_core.h", "csrc/hip/rt_tables.h",
-                       "csrc/common/rt_atan2.h") + [os.path.join(ROOT, "include/rt_abi.h")]
+    deps = _srcs(*HIP_DEPS) + [os.path.join(ROOT, "include/rt_abi.h")]
     if force or _newer(out, deps):
         _run(["hipcc", *HIPFLAGS, "-shared", *src, "-o", out])
     return out
@@ -53,6 +52,21 @@ def build_cli(force=False):
     if os.path.exists(src[0]) and (force or _newer(out, deps)):
         _run(["g++", *CXXFLAGS, *src, "-o", out, "-L" + HERE, "-lrt_host", "-lrt_hip", "-lpthread", "-Wl,-rpath,$ORIGIN"])
     return out
+
+
+HIP_DEPS = ("csrc/hip/rt_hip_api.hip", "csrc/hip/rt_kernel.hip", "csrc/hip/rt_hip_group.hip", "csrc/hip/rt_core.h", "csrc/hip/rt_tables.h",
+            "csrc/common/rt_atan2.h")
+
+
+def kernel_src_hash():
+    """sha1 over the sources librt_hip.so is compiled from: what a counter file and a bench run must share to describe the
+    same kernel (a commit id changes with every documentation commit; this does not)"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in _srcs(*HIP_DEPS) + [os.path.join(ROOT, "include/rt_abi.h")]:
+        h.update(open(f, "rb").read())
+    h.update(" ".join(HIPFLAGS).encode())
+    return h.hexdigest()[:12]
 
 
 def write_build_info():
@@ -70,7 +84,8 @@ def write_build_info():
     if not head:
         return  # (not a git checkout: keep whatever file travelled with the snapshot)
     dirty = bool(git("status", "--porcelain", "--untracked-files=no"))
-    info = {"git_head": head + ("+dirty" if dirty else ""), "built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())}
+    info = {"git_head": head + ("+dirty" if dirty else ""), "built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+            "kernel_src_hash": kernel_src_hash()}
     with open(os.path.join(HERE, "BUILD_INFO.json"), "w") as f:
         json.dump(info, f)
 

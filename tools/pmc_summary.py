@@ -42,7 +42,9 @@ if kms:
     summary["kernel_ms"] = round(sum(kms) / len(kms), 4)
     summary["kernel_ms_note"] = f"mean over the {len(kms)} counter passes (HIP events; a pass with counters on can run slower than an unprofiled one)"
 try:
-    summary["git_head"] = json.load(open(os.path.join(ROOT, "rust-raytracer_amd", "BUILD_INFO.json")))["git_head"]
+    info = json.load(open(os.path.join(ROOT, "rust-raytracer_amd", "BUILD_INFO.json")))
+    summary["git_head"] = info["git_head"]
+    summary["kernel_src_hash"] = info.get("kernel_src_hash")
 except Exception:
     summary["git_head"] = None
 # TCC FETCH_SIZE / WRITE_SIZE count kilobytes (rocprof derived counters).  On gfx950 FETCH_SIZE can
