@@ -40,6 +40,7 @@ def main():
             gs = hip.HipScene(sc.ptr, 0)
             gs.set_option("variant", variant)
             gs.set_option("tile_log2", [-1, 0, 1, 2, 3][seed % 5])
+            gs.set_option("tile_batch", [0, 1, 2, 7, 64, 3, 0][seed % 7])       # tiles per queue atomic (the workgroup's stash)
             gs.set_option("light_pool", [0, 32, 64, 0, 96, 0][seed % 6])   # lit worlds beyond the one-frame-per-lane budget: small pools force repeats
             rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
             lin = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
