@@ -659,6 +659,9 @@ RT_HD Rgb texel_fetch(const DevScene& sc, const SphereMat& m, uint64_t col, uint
   uint64_t base_pixel = 3 * (row * m.tex_w + col);
   if (m.tex_nbytes < 3) { tex_oob++; return rgb(0.f, 0.f, 0.f); }
   if (base_pixel > m.tex_nbytes - 3) { tex_oob++; base_pixel = (m.tex_nbytes / 3 - 1) * 3; }
+#ifdef RT_EXP_TEX_HOT  // (timing experiment only — WRONG image: every texel fetch hits the same few cache lines)
+  base_pixel &= 1023u;
+#endif
   const uint8_t* px = sc.tex + m.tex_off + base_pixel;
   return rgb(rt_div255f((float)px[0]), rt_div255f((float)px[1]), rt_div255f((float)px[2]));
 }
@@ -742,6 +745,9 @@ RT_HD Rgb sky_color(const DevScene& sc, V3 d, uint32_t& tex_oob) {
   uint64_t y = sat_u64_f32((1.0f - t) * (float)(sc.sky_h - 1));
   uint64_t base = (y * sc.sky_w + x) * 3;
   if (base + 2 >= sc.sky_w * sc.sky_h * 3) { tex_oob++; base = (sc.sky_w * sc.sky_h - 1) * 3; }
+#ifdef RT_EXP_SKY_HOT  // (timing experiment only — WRONG image: every sky fetch hits the same few cache lines)
+  base &= 1023u;
+#endif
   const uint8_t* px = sc.sky + base;
   return rgb(rt_div255f(0.7f * (float)px[0]), rt_div255f(0.7f * (float)px[1]), rt_div255f(0.7f * (float)px[2]));
 }

@@ -104,7 +104,8 @@ def run(rounds, scene_path, only):
             if r == 0:
                 img = rgb.cpu().numpy()
                 ref.setdefault(0, img)
-                assert np.array_equal(img, ref[0]), f"{name}: image differs from the first variant"
+                if not os.environ.get("AB_ALLOW_DIFFERENT"):  # (timing-only arms that render a WRONG image on purpose set it)
+                    assert np.array_equal(img, ref[0]), f"{name}: image differs from the first variant"
             else:
                 times.append(st.kernel_ms)
             stats[name] = (st.exact_tests, st.grid_steps, st.segments)
