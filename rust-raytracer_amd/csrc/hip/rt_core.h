@@ -923,11 +923,13 @@ RT_HD int scatter(const DevScene& sc, const RngAddr& ra, uint32_t node, V3 in_di
       if (near_zero(sd)) sd = h.normal;
       V3 target = add(h.point, sd);
       out_dir = sub(target, h.point);  // (p + d) - p, as the reference computes it
+#ifndef RT_EXP_NO_TEXEL  // (timing experiment only — WRONG image when defined: Texture spheres shade with their plain albedo)
       if (m.kind == RT_MAT_TEXTURE) {
         const UV uv = sphere_uv_for_texel(h.point, g, sc.mat, idx);
         Rgb a = texture_albedo(sc, sc.mat[idx], uv.u, uv.v, tex_oob);
         att[0] = a.r; att[1] = a.g; att[2] = a.b;
       }
+#endif
       return SCATTER_RAY;
     }
     case RT_MAT_METAL: {  // :115-129
