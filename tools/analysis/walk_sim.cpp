@@ -28,17 +28,20 @@ struct RoundLog {  // per lane: which rounds it moved / tested in
 };
 
 struct SimGrid {
+  int cull = 0;               // 0: the product; 1: candidates whose exact test cannot accept are dropped for free when their cell is entered (ideal cull); 2: the conservative f32 cull of rt_core.h; 3 / 4: the same two, realisable form (the two candidates of the cell word only; a culled-out cell ends the step round)
   const DevScene* ds;
   std::vector<uint8_t> skip;  // per padded cell: Chebyshev distance to the nearest non-empty cell or EXIT border, capped (0 for non-empty)
   int max_cells = 2;          // cells a lane may advance per step round
   bool use_skip = false;
 };
 
+static void lane_walk_cull(const SimGrid& sg, V3 o, V3 d, double& closest, int& best, RoundLog& log);
 // the kernel's walk loop for ONE lane (rt_kernel.hip hit_world, part (3)), logging the rounds
 static void lane_walk(const SimGrid& sg, V3 o, V3 d, double& closest, int& best, RoundLog& log) {
   const DevScene& sc = *sg.ds;
   const GridDesc& G = sc.grid;
   const RayK rk = ray_consts(d);
+  if (sg.cull) { lane_walk_cull(sg, o, d, closest, best, log); return; }
   for (uint32_t i = 0; i < G.n_large; ++i) exact_hit_any_order(o, d, rk, sc.large_geom[i], sc.large[i], closest, best);
   if (G.n[0] == 0u) return;
   GridWalk w;
@@ -100,6 +103,99 @@ static void lane_walk(const SimGrid& sg, V3 o, V3 d, double& closest, int& best,
   log.rounds = r;
 }
 
+// Variant: an f32 (or ideal) cull of a cell's candidates INSIDE the step block — a cell whose candidates all fail counts as
+// empty (the lane moves on within its budget), the survivors take one exact-test round each.
+static void lane_walk_cull(const SimGrid& sg, V3 o, V3 d, double& closest, int& best, RoundLog& log) {
+  const DevScene& sc = *sg.ds;
+  const GridDesc& G = sc.grid;
+  const RayK rk = ray_consts(d);
+  for (uint32_t i = 0; i < G.n_large; ++i) exact_hit_any_order(o, d, rk, sc.geom[sc.large[i]], sc.large[i], closest, best);
+  if (G.n[0] == 0u) return;
+  GridWalk w;
+  const int mode = rk.fast ? grid_begin(G, o, d, w) : GRID_FALLBACK;
+  if (mode == GRID_MISS) return;
+  if (mode == GRID_FALLBACK) {
+    for (uint32_t idx = 0; idx < sc.n_spheres; ++idx) exact_hit_any_order(o, d, rk, sc.geom[idx], idx, closest, best);
+    return;
+  }
+  const RayF32 rf = make_ray_f32(o, d);
+  auto survives = [&](uint32_t idx) {
+    const SphereGeom& g = sc.geom[idx];
+    if (sg.cull == 2 || sg.cull == 4) {
+      const CullPair& cp = sc.cull[idx / 2];
+      return cull_pass(cull_disc(rf, cp.cx[idx & 1], cp.cy[idx & 1], cp.cz[idx & 1], cp.R[idx & 1]));
+    }
+    const V3 oc = sub(o, v3(g.cx, g.cy, g.cz));
+    const double half_b = dot(oc, d), c = length_squared(oc) - g.r * g.r;
+    return !(c > 0.0 && half_b > 0.0) && (half_b * half_b) - (rk.a * c) >= 0.0;
+  };
+  float tm0 = w.tmax[0], tm1 = w.tmax[1], tm2 = w.tmax[2];
+  const float dt0 = w.delta[0], dt1 = w.delta[1], dt2 = w.delta[2];
+  const int dl0 = w.dl[0], dl1 = w.dl[1], dl2 = w.dl[2];
+  int lin = w.lin;
+  const double t0 = w.t0;
+  uint32_t todo[64], n_todo = 0, last = 0xFFFFFFFFu;
+  auto enter = [&](int l) {  // candidates of cell l that survive the cull -> todo
+    n_todo = 0;
+    const uint32_t ex = sc.cell_word[2 * l], ey = sc.cell_word[2 * l + 1];
+    if (ex == CELL_EXIT) return;
+    const uint32_t first = ex & CELL_START_MASK, cnt = ex >> CELL_COUNT_SHIFT;
+    for (uint32_t k = 0; k < cnt && n_todo < 64; ++k) {
+      uint32_t idx = k < 2 ? (ey >> (16 * k)) & 0xFFFFu : 0xFFFFu;
+      if (idx == 0xFFFFu) idx = sc.cell_items[first + k];
+      if (idx == last) continue;
+      last = idx;
+      if ((sg.cull >= 3 && k >= 2) || survives(idx)) todo[n_todo++] = idx;   // (3 / 4: only the two candidates named in the cell word are culled)
+    }
+  };
+  if (sg.cull == 5) {  // 5: like 3, but the cell the ray STARTS in is not culled (its candidates all take a test round)
+    const uint32_t ex = sc.cell_word[2 * lin], ey = sc.cell_word[2 * lin + 1];
+    const uint32_t first = ex & CELL_START_MASK, cnt = ex == CELL_EXIT ? 0u : ex >> CELL_COUNT_SHIFT;
+    for (uint32_t k = cnt; k-- > 0;) {  // (todo is taken from the back)
+      uint32_t idx = k < 2 ? (ey >> (16 * k)) & 0xFFFFu : 0xFFFFu;
+      if (idx == 0xFFFFu) idx = sc.cell_items[first + k];
+      todo[n_todo++] = idx; last = idx;
+    }
+  } else enter(lin);
+  bool walking = true, moving = n_todo == 0;
+  uint32_t r = 0;
+  while (walking) {
+    const uint64_t bit = 1ull << (r < 63 ? r : 63);
+    if (moving) {
+      log.move |= bit;
+      float tc = (float)(closest - t0);
+      tc = tc + fabsf(tc) * 2.384185791015625e-07f;
+      const bool hit = best >= 0;
+      if (hit && tc < rt_min3f(tm0, tm1, tm2)) walking = false;
+      else {
+        for (int j = 1;; ++j) {
+          const float tmin = rt_min3f(tm0, tm1, tm2);
+          const bool ax = tm0 == tmin, ay = !ax && tm1 == tmin;
+          tm0 += ax ? dt0 : 0.0f; tm1 += ay ? dt1 : 0.0f; tm2 += (!ax && !ay) ? dt2 : 0.0f;
+          lin += ax ? dl0 : (ay ? dl1 : dl2);
+          log.steps++;
+          if (sc.cell_word[2 * lin] == CELL_EXIT) { walking = false; break; }
+          enter(lin);
+          if (n_todo) { moving = false; break; }
+          if (sg.cull >= 3 && (sc.cell_word[2 * lin] >> CELL_COUNT_SHIFT) != 0u) break;  // a cell whose candidates were all culled ends the round
+          if (j >= sg.max_cells) break;  // out of budget: keep moving next round
+          if (hit && tc < rt_min3f(tm0, tm1, tm2)) { walking = false; break; }
+        }
+      }
+    }
+    if (walking && !moving && n_todo) {  // one exact test (in the round it arrived in, like the product)
+      log.test |= bit;
+      const uint32_t idx = todo[--n_todo];
+      log.tests++;
+      exact_hit_any_order(o, d, rk, sc.geom[idx], idx, closest, best);
+      if (!n_todo) moving = true;
+    }
+    r++;
+    if (r > 63) log.over++;
+  }
+  log.rounds = r;
+}
+
 int main(int argc, char** argv) {
   if (argc < 5) { std::fprintf(stderr, "usage: walk_sim scene.json width height spp [cells_per_sphere] [skip] [max_cells]\n"); return 1; }
   RtSceneFile* sf = nullptr;
@@ -109,6 +205,7 @@ int main(int argc, char** argv) {
   const double cps = argc > 5 ? atof(argv[5]) : 0.0;
   const bool use_skip = argc > 6 && atoi(argv[6]) != 0;
   const int max_cells = argc > 7 ? atoi(argv[7]) : 2;
+  const int cull = argc > 8 ? atoi(argv[8]) : 0;
   const RtScene& sc = *scp;
   HostTables t;
   if (cps > 0.0) { char b[64]; snprintf(b, sizeof b, "%g", cps); setenv("RT_GRID_CELLS_PER_SPHERE", b, 1); }
@@ -127,7 +224,7 @@ int main(int argc, char** argv) {
     std::printf("grid %ux%ux%u, %u cells (%u padded), %u items, %u large, non-empty %.1f %%, cell bytes %u\n", G.n[0], G.n[1], G.n[2], inner, G.n_cells,
                 G.n_items, G.n_large, 100.0 * nonempty / inner, G.n_cells * 8u);
   }
-  SimGrid sg; sg.ds = &ds; sg.max_cells = max_cells; sg.use_skip = use_skip;
+  SimGrid sg; sg.ds = &ds; sg.max_cells = max_cells; sg.use_skip = use_skip; sg.cull = cull;
   const GlobalTables tb{ds.geom, ds.matc};
   const uint32_t TW = 4, TH = 4, NPX = TW * TH;
   const uint32_t tx = (sc.width + TW - 1) / TW, ty = (sc.height + TH - 1) / TH, n_tiles = tx * ty;
