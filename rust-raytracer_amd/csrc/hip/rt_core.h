@@ -446,6 +446,20 @@ RT_HD bool exact_hit_any_order_t(V3 o, V3 d, const RayK& rk, const SphereGeom& g
   return false;
 #endif
 }
+// The part of the test above that decides "cannot be accepted" without a square root: the same operations in the same
+// order (sphere.rs:47-53), so `may_hit == false` exactly when exact_hit_any_order_t returns false at its first branch.
+struct HitPrefix {
+  bool may_hit;
+};
+RT_HD HitPrefix exact_hit_prefix(V3 o, V3 d, const RayK& rk, const SphereGeom& g) {
+  V3 oc = sub(o, v3(g.cx, g.cy, g.cz));
+  double half_b = dot(oc, d);
+  double c = length_squared(oc) - g.r * g.r;
+  const double discriminant = (half_b * half_b) - (rk.a * c);
+  HitPrefix p;
+  p.may_hit = !(c > 0.0 && half_b > 0.0) && discriminant >= 0.0;
+  return p;
+}
 // a ray whose |d|^2 is outside div_by_recip's range: the reference's own arithmetic (cold).
 // Everything travels BY VALUE: a reference parameter of a real call would pin the caller's
 // closest/best (the hottest variables of the kernel) to stack memory.

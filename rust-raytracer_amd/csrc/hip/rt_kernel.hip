@@ -177,6 +177,9 @@ __device__ __forceinline__ const KArgs& fresh_args() {
 #ifndef RT_STASH_SPIN
 #define RT_STASH_SPIN 0
 #endif
+#ifndef RT_START_CELL_PREFIX
+#define RT_START_CELL_PREFIX 0  // (A/B arm, profiles/r03_run34_ab_start_cell_prefix.log: rounds 5.8 / 5.2 -> 5.5 / 4.7, time +-0: not adopted)
+#endif
 
 #ifndef RT_HANDOUT_DIRECT
 #define RT_HANDOUT_DIRECT 0
@@ -760,6 +763,19 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       if (walk0) {
         const uint2 e = cell_word[lin];
         it = e.x & CELL_START_MASK; end = it + (e.x >> CELL_COUNT_SHIFT); pend = e.y;
+#if RT_START_CELL_PREFIX
+        // The cell a ray STARTS in holds 0.55 of its 1.46 candidates (a bounce ray's: the sphere it just left), and 70 % of
+        // all candidates cannot be hit.  The exact test's own prefix (sphere.rs:47-53: discriminant < 0, or the sphere behind
+        // the origin — exact_hit_any_order_t's first branch, same operations) drops such a first candidate HERE, once per ray,
+        // instead of in a test round of the lock-step loop below: 6.1 -> 5.2 rounds per wave iteration
+        // (tools/analysis/walk_sim.cpp mode 6, profiles/r03_walk_sim_cull.log).  A dropped candidate counts as the exact
+        // test it replaces; a surviving one is tested in full by the loop.
+        if (it < end) {
+          const uint32_t idx0 = pend & 0xFFFFu;
+          const HitPrefix hp = exact_hit_prefix(L.o, L.d, rk, tb.geom(idx0));
+          if (!hp.may_hit) { pend = (pend >> 16) | 0xFFFF0000u; it++; last = idx0; n_exact++; }
+        }
+#endif
       }
 #ifdef RT_EXP_WALK_CAP  // (timing experiment only — WRONG image: the walk stops after this many rounds, unfinished lanes keep what they have)
       uint32_t exp_round = 0;

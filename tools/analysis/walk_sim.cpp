@@ -28,6 +28,7 @@ struct RoundLog {  // per lane: which rounds it moved / tested in
 };
 
 struct SimGrid {
+  bool dedupe_free = false;   // landing in a cell whose candidate is the sphere tested last drops it in the step block (no test round)
   int cull = 0;               // 0: the product; 1: candidates whose exact test cannot accept are dropped for free when their cell is entered (ideal cull); 2: the conservative f32 cull of rt_core.h; 3 / 4: the same two, realisable form (the two candidates of the cell word only; a culled-out cell ends the step round)
   const DevScene* ds;
   std::vector<uint8_t> skip;  // per padded cell: Chebyshev distance to the nearest non-empty cell or EXIT border, capped (0 for non-empty)
@@ -120,6 +121,7 @@ static void lane_walk_cull(const SimGrid& sg, V3 o, V3 d, double& closest, int& 
   }
   const RayF32 rf = make_ray_f32(o, d);
   auto survives = [&](uint32_t idx) {
+    if (sg.cull == 8) return true;
     const SphereGeom& g = sc.geom[idx];
     if (sg.cull == 2 || sg.cull == 4) {
       const CullPair& cp = sc.cull[idx / 2];
@@ -134,7 +136,7 @@ static void lane_walk_cull(const SimGrid& sg, V3 o, V3 d, double& closest, int& 
   const int dl0 = w.dl[0], dl1 = w.dl[1], dl2 = w.dl[2];
   int lin = w.lin;
   const double t0 = w.t0;
-  uint32_t todo[64], n_todo = 0, last = 0xFFFFFFFFu;
+  uint32_t todo[64], n_todo = 0, last = 0xFFFFFFFFu, last_tested = 0xFFFFFFFFu;
   auto enter = [&](int l) {  // candidates of cell l that survive the cull -> todo
     n_todo = 0;
     const uint32_t ex = sc.cell_word[2 * l], ey = sc.cell_word[2 * l + 1];
@@ -143,15 +145,24 @@ static void lane_walk_cull(const SimGrid& sg, V3 o, V3 d, double& closest, int& 
     for (uint32_t k = 0; k < cnt && n_todo < 64; ++k) {
       uint32_t idx = k < 2 ? (ey >> (16 * k)) & 0xFFFFu : 0xFFFFu;
       if (idx == 0xFFFFu) idx = sc.cell_items[first + k];
-      if (idx == last) continue;
+      if (idx == last && (sg.dedupe_free || sg.cull < 6)) continue;   // (modes 1-5 and dedupe_free: a repeated sphere is dropped on landing; else it costs its test round like in the product)
       last = idx;
-      if ((sg.cull >= 3 && k >= 2) || survives(idx)) todo[n_todo++] = idx;   // (3 / 4: only the two candidates named in the cell word are culled)
+      if ((sg.cull >= 3 && k >= 2) || sg.cull >= 6 || survives(idx)) todo[n_todo++] = idx;   // (3 / 4: only the two candidates named in the cell word are culled)
     }
   };
-  if (sg.cull == 5) {  // 5: like 3, but the cell the ray STARTS in is not culled (its candidates all take a test round)
+  if (sg.cull == 6 || sg.cull == 7) {  // 6 / 7: ONLY the start cell's first candidate (7: first two) is culled, nothing inside the loop
     const uint32_t ex = sc.cell_word[2 * lin], ey = sc.cell_word[2 * lin + 1];
     const uint32_t first = ex & CELL_START_MASK, cnt = ex == CELL_EXIT ? 0u : ex >> CELL_COUNT_SHIFT;
-    for (uint32_t k = cnt; k-- > 0;) {  // (todo is taken from the back)
+    for (uint32_t k = 0; k < cnt; ++k) {
+      uint32_t idx = k < 2 ? (ey >> (16 * k)) & 0xFFFFu : 0xFFFFu;
+      if (idx == 0xFFFFu) idx = sc.cell_items[first + k];
+      if (k < (sg.cull == 6 ? 1u : 2u) && !survives(idx)) { last_tested = idx; continue; }
+      todo[n_todo++] = idx;
+    }
+  } else if (sg.cull == 5) {  // 5: like 3, but the cell the ray STARTS in is not culled (its candidates all take a test round)
+    const uint32_t ex = sc.cell_word[2 * lin], ey = sc.cell_word[2 * lin + 1];
+    const uint32_t first = ex & CELL_START_MASK, cnt = ex == CELL_EXIT ? 0u : ex >> CELL_COUNT_SHIFT;
+    for (uint32_t k = 0; k < cnt; ++k) {
       uint32_t idx = k < 2 ? (ey >> (16 * k)) & 0xFFFFu : 0xFFFFu;
       if (idx == 0xFFFFu) idx = sc.cell_items[first + k];
       todo[n_todo++] = idx; last = idx;
@@ -177,7 +188,7 @@ static void lane_walk_cull(const SimGrid& sg, V3 o, V3 d, double& closest, int& 
           if (sc.cell_word[2 * lin] == CELL_EXIT) { walking = false; break; }
           enter(lin);
           if (n_todo) { moving = false; break; }
-          if (sg.cull >= 3 && (sc.cell_word[2 * lin] >> CELL_COUNT_SHIFT) != 0u) break;  // a cell whose candidates were all culled ends the round
+          if (sg.cull >= 3 && sg.cull < 6 && (sc.cell_word[2 * lin] >> CELL_COUNT_SHIFT) != 0u) break;  // a cell whose candidates were all culled ends the round
           if (j >= sg.max_cells) break;  // out of budget: keep moving next round
           if (hit && tc < rt_min3f(tm0, tm1, tm2)) { walking = false; break; }
         }
@@ -185,9 +196,8 @@ static void lane_walk_cull(const SimGrid& sg, V3 o, V3 d, double& closest, int& 
     }
     if (walking && !moving && n_todo) {  // one exact test (in the round it arrived in, like the product)
       log.test |= bit;
-      const uint32_t idx = todo[--n_todo];
-      log.tests++;
-      exact_hit_any_order(o, d, rk, sc.geom[idx], idx, closest, best);
+      const uint32_t idx = todo[0]; for (uint32_t q = 1; q < n_todo; ++q) todo[q - 1] = todo[q]; --n_todo;
+      if (idx != last_tested) { last_tested = idx; log.tests++; exact_hit_any_order(o, d, rk, sc.geom[idx], idx, closest, best); }
       if (!n_todo) moving = true;
     }
     r++;
@@ -224,7 +234,7 @@ int main(int argc, char** argv) {
     std::printf("grid %ux%ux%u, %u cells (%u padded), %u items, %u large, non-empty %.1f %%, cell bytes %u\n", G.n[0], G.n[1], G.n[2], inner, G.n_cells,
                 G.n_items, G.n_large, 100.0 * nonempty / inner, G.n_cells * 8u);
   }
-  SimGrid sg; sg.ds = &ds; sg.max_cells = max_cells; sg.use_skip = use_skip; sg.cull = cull;
+  SimGrid sg; sg.ds = &ds; sg.max_cells = max_cells; sg.use_skip = use_skip; sg.cull = cull; sg.dedupe_free = argc > 9 && atoi(argv[9]) != 0;
   const GlobalTables tb{ds.geom, ds.matc};
   const uint32_t TW = 4, TH = 4, NPX = TW * TH;
   const uint32_t tx = (sc.width + TW - 1) / TW, ty = (sc.height + TH - 1) / TH, n_tiles = tx * ty;
