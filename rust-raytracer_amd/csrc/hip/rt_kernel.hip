@@ -177,6 +177,9 @@ __device__ __forceinline__ const KArgs& fresh_args() {
 #ifndef RT_STASH_SPIN
 #define RT_STASH_SPIN 0
 #endif
+#ifndef RT_DEDUPE_ON_LANDING
+#define RT_DEDUPE_ON_LANDING 0  // (A/B arm, profiles/r03_run36_ab_dedupe_on_landing.log: test rounds 5.23 -> 4.80, frame +1.9 %: not adopted)
+#endif
 #ifndef RT_START_CELL_PREFIX
 #define RT_START_CELL_PREFIX 0  // (A/B arm, profiles/r03_run34_ab_start_cell_prefix.log: rounds 5.8 / 5.2 -> 5.5 / 4.7, time +-0: not adopted)
 #endif
@@ -824,6 +827,11 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
                 it = eB.x & CELL_START_MASK; end = it + (eB.x >> CELL_COUNT_SHIFT); pend = eB.y;
                 if (eB.x == CELL_EXIT) { it = 1; end = 0; }
               }
+#if RT_DEDUPE_ON_LANDING
+              // 2.7 cells list each sphere: a lane that lands in the next cell of the sphere it tested last would spend a test
+              // round on the `idx != last` skip below — drop that candidate here (walk_sim: rounds 5.59 / 5.08 -> 5.10 / 4.48)
+              if (it < end && (pend & 0xFFFFu) == last) { pend = (pend >> 16) | 0xFFFF0000u; it++; }
+#endif
             }
           }
         }
