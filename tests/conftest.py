@@ -67,6 +67,8 @@ def hostsim(abi):
     L.hostsim_cull_disc.restype = C.c_float
     L.hostsim_exact_root.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(abi.RtSphere), C.c_double, C.c_double]
     L.hostsim_exact_root.restype = C.c_double
+    L.hostsim_hit_prefix.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(abi.RtSphere)]
+    L.hostsim_hit_prefix.restype = C.c_int
     L.hostsim_texels.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.c_double, C.c_uint64, C.c_uint64, C.c_void_p]
     L.hostsim_texels.restype = None
     L.hostsim_div_by_recip.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]

@@ -169,6 +169,13 @@ extern "C" double hostsim_exact_root(const double o[3], const double d[3], const
   return exact_root(v3(o[0], o[1], o[2]), dd, length_squared(dd), g, t_min, t_max);
 }
 
+// rt_core.h exact_hit_prefix (the square-root-free part of the hit test; the kernel's RT_START_CELL_PREFIX arm): 1 = may hit
+extern "C" int hostsim_hit_prefix(const double o[3], const double d[3], const RtSphere* s) {
+  SphereGeom g{s->center[0], s->center[1], s->center[2], s->radius};
+  const V3 dd = v3(d[0], d[1], d[2]);
+  return exact_hit_prefix(v3(o[0], o[1], o[2]), dd, ray_consts(dd), g).may_hit ? 1 : 0;
+}
+
 // grid layout of a scene (for tests): out = n[3], n_large, n_cells, n_items
 extern "C" int hostsim_grid_info(const RtScene* scene, uint32_t out[6]) {
   HostTables t;

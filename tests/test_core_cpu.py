@@ -234,7 +234,7 @@ def test_exact_root_equals_sphere_hit(hostsim, oracle, abi):
     rng = np.random.default_rng(99)
     L = oracle.lib(abi)
     out = (C.c_double * 10)()
-    hits = 0
+    hits = culled = 0
     for trial in range(30000):
         c = rng.standard_normal(3) * 10.0 ** rng.uniform(-1, 2)
         r = 10.0 ** rng.uniform(-2, 2) * (1 if trial % 5 else -1)
@@ -249,12 +249,15 @@ def test_exact_root_equals_sphere_hit(hostsim, oracle, abi):
             s.center[i] = c[i]
         hit = L.rt_oracle_sphere_hit(dvec(*c), r, dvec(*o), dvec(*d), 0.001, t_max, out)
         got = hostsim.hostsim_exact_root(dvec(*o), dvec(*d), C.byref(s), 0.001, min(t_max, 1.7976931348623157e308))
+        may = hostsim.hostsim_hit_prefix(dvec(*o), dvec(*d), C.byref(s))   # the prefix alone never rejects a sphere the test accepts
         if hit:
             hits += 1
             assert got == out[0], (trial, got, out[0])
+            assert may == 1, (trial, "prefix rejected an accepted hit")
         else:
             assert got < 0.0, (trial, got)
-    assert hits > 5000
+        culled += may == 0
+    assert hits > 5000 and culled > 5000
 
 
 def test_row_tiles_are_bit_identical(hostsim, oracle, abi, load_scene):
