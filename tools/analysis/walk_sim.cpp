@@ -246,11 +246,13 @@ int main(int argc, char** argv) {
   double cls_segs[2] = {0, 0}, cls_rounds[2] = {0, 0}, cls_steps[2] = {0, 0}, cls_tests[2] = {0, 0}, max_by_cls[2] = {0, 0};
   std::vector<double> hist_wave(65, 0.0), hist_lane0(65, 0.0), hist_lane1(65, 0.0);
   unsigned long long mismatches = 0;
+  double g_kl_sum[6] = {0, 0, 0, 0, 0, 0}, g_kl_any[6] = {0, 0, 0, 0, 0, 0};
 #pragma omp parallel
   {
     std::vector<double> hw(65, 0.0), hl0(65, 0.0), hl1(65, 0.0);
     double a_w = 0, a_s = 0, a_t = 0, a_ls = 0, a_lst = 0, a_lt = 0, a_tr = 0, c_s[2] = {0, 0}, c_r[2] = {0, 0}, c_st[2] = {0, 0}, c_t[2] = {0, 0}, m_c[2] = {0, 0};
     unsigned long long mm = 0;
+    double kl_sum[6] = {0, 0, 0, 0, 0, 0}, kl_any[6] = {0, 0, 0, 0, 0, 0};
 #pragma omp for schedule(dynamic, 4)
     for (uint32_t wv = 0; wv < n_waves; ++wv) {
       Lane<false, false> L[64];
@@ -284,6 +286,7 @@ int main(int argc, char** argv) {
         if (!live) break;
         uint64_t any_move = 0, any_test = 0;
         uint32_t max_r[2] = {0, 0}, over = 0;
+        uint32_t kind_lanes[6] = {0, 0, 0, 0, 0, 0};  // lanes of this iteration by what their segment ends in: [0] miss, [1 + RT_MAT_*] hit material
         for (int l = 0; l < 64; ++l) {
           if (!has_ray[l]) continue;
           RoundLog lg;
@@ -298,12 +301,14 @@ int main(int argc, char** argv) {
           max_r[cls] = std::max(max_r[cls], lg.rounds);
           (cls ? hl1 : hl0)[std::min<uint32_t>(lg.rounds, 64)] += 1;
           a_ls += 1; a_lst += lg.steps; a_lt += lg.tests;
+          kind_lanes[best < 0 ? 0 : 1 + std::min<uint32_t>(t.matc[best].kind, 4u)]++;
           const bool fin = lane_shade(ds, tb, L[l], best, closest);
           if (fin) has_ray[l] = take(l);
         }
         const uint32_t mr = std::max(max_r[0], max_r[1]);
         a_w += 1; a_s += __builtin_popcountll(any_move) + over; a_t += __builtin_popcountll(any_test) + over; a_tr += mr;
         hw[std::min<uint32_t>(mr, 64)] += 1;
+        for (int q = 0; q < 6; ++q) { kl_sum[q] += kind_lanes[q]; kl_any[q] += kind_lanes[q] != 0; }
         m_c[max_r[1] > max_r[0] ? 1 : 0] += 1;
       }
     }
@@ -312,6 +317,7 @@ int main(int argc, char** argv) {
       w_iters += a_w; step_rounds += a_s; test_rounds += a_t; lane_segs += a_ls; lane_steps += a_lst; lane_tests += a_lt; tot_rounds += a_tr; mismatches += mm;
       for (int c = 0; c < 2; ++c) { cls_segs[c] += c_s[c]; cls_rounds[c] += c_r[c]; cls_steps[c] += c_st[c]; cls_tests[c] += c_t[c]; max_by_cls[c] += m_c[c]; }
       for (int i = 0; i < 65; ++i) { hist_wave[i] += hw[i]; hist_lane0[i] += hl0[i]; hist_lane1[i] += hl1[i]; }
+      for (int q = 0; q < 6; ++q) { g_kl_sum[q] += kl_sum[q]; g_kl_any[q] += kl_any[q]; }
     }
   }
   std::printf("wave iterations %.0f, lanes with a ray per iteration %.2f\n", w_iters, lane_segs / w_iters);
@@ -321,6 +327,12 @@ int main(int argc, char** argv) {
   for (int c = 0; c < 2; ++c)
     std::printf("  class %s: %.1f %% of segments, rounds/lane %.2f steps %.2f tests %.2f; sets the wave's maximum in %.1f %% of iterations\n", c ? "bounce (k>=1)" : "camera (k=0)",
                 100 * cls_segs[c] / lane_segs, cls_rounds[c] / cls_segs[c], cls_steps[c] / cls_segs[c], cls_tests[c] / cls_segs[c], 100 * max_by_cls[c] / w_iters);
+  {
+    static const char* names[6] = {"miss (sky)", "kind 0", "kind 1", "kind 2", "kind 3", "kind 4"};
+    std::printf("what the segments of a wave iteration end in (RT_MAT_* of include/rt_abi.h): lanes per iteration | share of iterations with at least one such lane\n");
+    for (int q = 0; q < 6; ++q)
+      if (g_kl_sum[q] > 0) std::printf("  %-12s %6.2f lanes   %5.1f %%\n", names[q], g_kl_sum[q] / w_iters, 100.0 * g_kl_any[q] / w_iters);
+  }
   std::printf("rounds histogram (share of wave iterations | camera lanes | bounce lanes):\n");
   for (int i = 0; i < 65; ++i)
     if (hist_wave[i] + hist_lane0[i] + hist_lane1[i] > 0)
