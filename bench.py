@@ -428,6 +428,16 @@ def run_ranks(args):
                                 "source": os.path.relpath(pmc_path, ROOT), "kernel_ms_of_that_run": pmc.get("kernel_ms"),
                                 "git_head_of_that_build": pmc.get("git_head"), "git_head_of_this_build": _git_head(),
                                 "same_kernel_sources": (pmc.get("kernel_src_hash") == _build_info("kernel_src_hash")) if pmc.get("kernel_src_hash") else None}
+            # the executed basis falls when work is REMOVED: the same frame priced with the lane work of the end-of-round-2
+            # kernel (same scene, same image) says what the time alone bought
+            try:
+                r2 = json.load(open(os.path.join(ROOT, "profiles", "r02_run29_pmc.json")))["mean_per_launch"]["SQ_THREAD_CYCLES_VALU"]
+                roof["work_removed_since_round2"] = {
+                    "lane_cycles_round2_kernel": r2, "lane_cycles_this_kernel": thr, "removed_frac": round(1.0 - thr / r2, 4),
+                    "frac_if_priced_with_round2_work": round(r2 / kernel_s / 1e12 / PEAK_LANE_SLOTS_T, 4),
+                    "note": "frac fell from 0.50 because executed lane work fell faster than time; this is round 2's lane work / this run's time"}
+            except Exception:
+                pass
             if pmc.get("hbm_bytes_per_launch") is not None:
                 alg_bytes = 3 * W * H + 32 * N_SPH * 2 + 8 * 4800   # framebuffer + one pass over geometry/material/cell tables
                 roof["traffic"] = pmc["hbm_bytes_per_launch"]
