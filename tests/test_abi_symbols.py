@@ -163,3 +163,21 @@ def test_group_deinterleave_layout_inverts_the_rank_packing(pkg, abi):
                     seen[r * pad + lr] = y                      # what rank r wrote at packed row lr
             got = [seen.get(L.rt_hip_group_stacked_row(y, world, pad, None)) for y in range(h)]
             assert got == list(range(h)), (h, world)
+
+
+def test_build_info_describes_the_sources_in_the_tree(pkg):
+    """BUILD_INFO.json (next to the libraries; what bench.py and the PMC tools quote) carries the hash of the kernel
+    sources the in-tree librt_hip.so was compiled from — a stale library, or counters of another kernel, show up as a
+    mismatch (`roofline.counters.same_kernel_sources` on the bench line) instead of silently describing different code."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rt_build", os.path.join(root, "rust-raytracer_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    h = b.kernel_src_hash()
+    assert len(h) == 12 and h == b.kernel_src_hash()
+    info_path = os.path.join(root, "rust-raytracer_amd", "BUILD_INFO.json")
+    if os.path.exists(info_path):   # (written by build(); a snapshot without .git keeps the file that travelled with it)
+        info = json.load(open(info_path))
+        assert info.get("kernel_src_hash") == h, "librt_hip.so is older than the kernel sources: run build()"
