@@ -114,7 +114,7 @@ struct SlotHdr {
 static_assert(sizeof(SlotHdr) == 48, "slot header is 48 B");
 constexpr uint32_t SLOT_HDR_BYTES = (uint32_t)sizeof(SlotHdr);
 enum { SLOT_FREE = 0, SLOT_OPEN = 1, SLOT_OPENING = 2 };
-constexpr uint32_t LDS_FLAGS_BYTES = 32u + 32u * 8u;          // {queue_empty, hint, waves retired} + pad, then the workgroup's 32 launch counters
+constexpr uint32_t LDS_FLAGS_BYTES = 32u + 32u * 8u;          // {queue_empty, hint, waves retired, dry queues}, the tile stash (u64) and its next batch size, pad; then the workgroup's 32 launch counters
 constexpr uint32_t LDS_SLOT_BUDGET = WAVES * 3u * 1024u;     // 48 KB at 16 waves (3 KB per wave)
 constexpr uint32_t T_SLOTS_MAX = 512u;
 __host__ __device__ inline uint32_t tile_slots(uint32_t tile_log2) {
@@ -538,8 +538,8 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
             __hip_atomic_fetch_or(&wg_flags[3], dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
           if (g < ka.n_tiles) {
-            // the next batch: a quarter of a workgroup's fair share of what the queue still holds — single tiles at the
-            // end of the frame, where a stashed tile is work no other workgroup can take
+            // the next batch: 1 / batch_share (a sixteenth) of a workgroup's fair share of what the queue still holds —
+            // single tiles at the end of the frame, where a stashed tile is work no other workgroup can take
             const uint32_t nb = rem / share;
             lds_store(wg_batch, nb < 1u ? 1u : (nb > ka.tile_batch ? ka.tile_batch : nb));
             __hip_atomic_exchange(wg_stash, ((unsigned long long)end << 32) | (unsigned long long)(g + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
