@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3u /* v3: RtScene.n_gpus, RtStats.{segments_discarded, n_gpus_used, gather_ms, setup_ms}, rt_abi_sizeof */
+#define RT_ABI_VERSION 4u /* v4: RtStats.group_us, rt_hip_group_submit / _collect; v3: RtScene.n_gpus, RtStats.{segments_discarded, n_gpus_used, gather_ms, setup_ms}, rt_abi_sizeof */
 
 /* Nested light-ray recursion (raytracer.rs:103-110 calls ray_color(.., 2, 1), which can
  * itself trigger light sampling again) is unbounded in the reference.  Oracle and kernel
@@ -138,11 +138,19 @@ typedef struct RtStats {
   uint64_t segments_discarded;
   uint32_t n_gpus_used; /* rt_render_rgb8: devices the frame was sharded over (1 elsewhere) */
   uint32_t reserved0;
-  double gather_ms; /* n_gpus_used > 1: end of RANK 0's kernel -> frame in scanline order on device 0 (events of one device only:
-                     * includes waiting for slower ranks, the gather and the de-interleave) */
+  double gather_ms; /* rt_hip_group_*: what the frame spent NOT rendering, on device 0's clock: (start of rank 0's kernel -> frame in
+                     * scanline order on device 0) minus kernel_ms of the slowest rank = launch skew between the ranks + the gather +
+                     * the de-interleave.  (Until ABI v3 it started at the END of rank 0's kernel and so held the load imbalance.) */
   double setup_ms;  /* rt_render_rgb8: HIP context + table build + scene upload, NOT part of frame_ms
                      * (frame_ms is the window the reference times, raytracer.rs:259-263: the parallel loop
                      * until the pixels are in the caller's buffer) */
+  /* rt_hip_group_*: host clock, microseconds since the frame's submit was entered (0 elsewhere):
+   * [0] the last rank's host thread is running, [1] the last rank's launch (+ its side of the transfer) is enqueued,
+   * [2] the submitting thread knows that, [3] the gather is enqueued (ncclGroupEnd returned / the peer copies' events are
+   * waited for), [4] submit returns (de-interleave + device-to-host copy enqueued), [5] collect saw the frame assembled on
+   * device 0, [6] ... and in the caller's buffer (= frame_ms), [7] the ranks' counters are read: collect returns.
+   * A blocking frame's non-kernel time is frame_ms - kernel_ms; [5]/[6] of a pipelined frame include the wait of its collect. */
+  double group_us[8];
 } RtStats;
 
 /* rows this call renders (its packed RGB8 output is rows*width*3 bytes) */
@@ -266,14 +274,22 @@ int rt_hip_quot_probe(const double* d_x, const double* d_y, double* d_quot, doub
  * reference's brute force (exact test on every sphere);
  * "chunk_spp" samples of a pixel per work item (0 = automatic); "tile_batch" tiles a workgroup takes from the frame's
  * queue at a time (0 = automatic, 1..64); "tile_log2" pixel tiles of
- * 4^k pixels (k = 0..3, -1 = automatic); "tile_shape" 0 (default) = a 2^k x 2^k square, 1 = a run of 4^k pixels of one
+ * 4^k pixels (k = 0..3, -1 = automatic); "tile_shape" 0 (default) = a 2^k x 2^k square — except k = 1, which is a 4x1 strip (12 contiguous
+ * framebuffer bytes: one packed store instead of two rows of byte stores; same time, 20 % less write traffic on the shards of a
+ * multi-GPU frame), 1 = a run of 4^k pixels of one
  * scanline (one contiguous piece of the framebuffer: half the HBM write traffic, 0.9 % slower), 2 and 3 = the square widened
- * once and twice (16x4 and 32x2 at k = 3); "tile_affinity" 1 (default) = on large frames, runs of 512 pixels of a
+ * once and twice (16x4 and 32x2 at k = 3; 2 at k = 1 is the 2x2 square no other value selects); "tile_affinity" 1 (default) = on large frames, runs of 512 pixels of a
  * tile row are handed out by the XCD they belong to first (a framebuffer line then fills up in ONE L2 before it is written
  * back: half the HBM traffic, +0.5 % time), 0 = one queue, 2 = per-XCD queues on any frame of 8 or more runs (tests); "samples_per_pixel", "max_depth" (0 .. 2^32-1) and
  * "seed" override the scene's values; "tile_order" 0 = tiles leave the queue top row first, 1 = bottom row
  * first, 2 (default) = the tiles whose paths ran deepest in this scene's previous frame first (the frame ends on
- * its deepest paths; the image does not depend on the order).  Out-of-range values are RT_ERR_INVALID. */
+ * its deepest paths; the image does not depend on the order) — a frame that has no previous one sorts its tiles by a SEED:
+ * "order_seed" 1 (default) = a depth guess from the spheres' projections (Glass > Metal > other > bare ground / sky; host
+ * arithmetic + a 4-byte-per-tile upload + the sort, inside kernel_ms), 2 = a probe launch (one sample per pixel, 8 segments
+ * at most) measures it, 0 = none (bottom row first); "tile_order" 3 = the seeded order alone, nothing measured or sorted
+ * for a next frame (what the one-shot rt_render_rgb8 uses).  rt_hip_group_set_option also takes "spin_us" (0 .. 10^6,
+ * default 0): how long a rank's idle host thread polls for the next frame before it sleeps.
+ * Out-of-range values are RT_ERR_INVALID. */
 int rt_hip_set_option(RtHipScene*, const char* key, int64_t value);
 /* Animation (the reference's `anim/frame_%03d.png` workflow, README.md:43-57, main.rs:17): move the
  * camera of a resident scene — the four vectors of camera.rs:52-63 — without touching its tables,
@@ -308,6 +324,16 @@ int rt_hip_group_info(const RtHipGroup*, RtGroupInfo* info);
  * pointer, valid until the group is destroyed, and that device's ordinal) — no device-to-host copy.  Blocking. */
 int rt_hip_group_render(RtHipGroup*, RtStats* stats);
 const void* rt_hip_group_frame(const RtHipGroup*, int* device_out);
+/* The same frame in two halves, for callers that render frame after frame (an animation): submit enqueues everything
+ * frame i needs — G launches, the gather, the de-interleave and, if out_rgb8 is not NULL, the copy into that host buffer —
+ * and returns; collect blocks until the OLDEST submitted frame is complete and fills its stats.  Two frames may be in flight
+ * (a third submit is RT_ERR_INVALID): every buffer exists twice, a rank's tiles travel on a transfer stream of their own,
+ * so frame i's gather + copy run while frame i+1 renders and a step costs the slowest rank's kernel.  The camera and
+ * options a frame is rendered with are those in force when it is SUBMITTED.  out_rgb8 must stay valid until the frame
+ * is collected; rt_hip_group_frame() points at the frame collected last.  rt_hip_group_render / _render_to_host are
+ * submit + collect (after collecting whatever was still in flight). */
+int rt_hip_group_submit(RtHipGroup*, uint8_t* out_rgb8);
+int rt_hip_group_collect(RtHipGroup*, RtStats* stats);
 void rt_hip_group_destroy(RtHipGroup*);
 uint32_t rt_hip_group_size(const RtHipGroup*);
 int rt_hip_group_set_camera(RtHipGroup*, const double origin[3], const double lower_left[3], const double horizontal[3],

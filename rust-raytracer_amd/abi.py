@@ -1,7 +1,7 @@
 """ctypes mirror of include/rt_abi.h (plain C ABI; no torch types cross this boundary)."""
 import ctypes as C
 
-RT_ABI_VERSION = 3
+RT_ABI_VERSION = 4
 RT_MAX_LIGHT_NEST = 8
 RT_OK, RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP = 0, -1, -2, -3
 RT_ERR_IO, RT_ERR_PARSE, RT_ERR_TEXTURE, RT_ERR_PNG, RT_ERR_UNSUPPORTED = -4, -5, -6, -7, -8
@@ -41,10 +41,10 @@ class RtStats(C.Structure):
                 ("exact_tests", C.c_uint64), ("tex_oob", C.c_uint64),
                 ("kernel_ms", C.c_double), ("frame_ms", C.c_double), ("grid_steps", C.c_uint64), ("wave_iters", C.c_uint64 * 4), ("prof_cycles", C.c_uint64 * 12),
                 ("segments_discarded", C.c_uint64), ("n_gpus_used", C.c_uint32), ("reserved0", C.c_uint32),
-                ("gather_ms", C.c_double), ("setup_ms", C.c_double)]
+                ("gather_ms", C.c_double), ("setup_ms", C.c_double), ("group_us", C.c_double * 8)]
 
     def as_dict(self):
-        return {k: (list(getattr(self, k)) if k in ("wave_iters", "prof_cycles") else getattr(self, k)) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if k in ("wave_iters", "prof_cycles", "group_us") else getattr(self, k)) for k, _ in self._fields_}
 
 
 RT_GROUP_INFO_MAX_RANKS = 64

@@ -42,15 +42,30 @@ namespace rtc {
 struct SphereGeom {  // 32 B, f64: sphere.rs:18-23 center + radius
   double cx, cy, cz, r;
 };
-struct SphereMat {  // 64 B: materials.rs:35-42 payloads
+struct SphereMat {  // 80 B: materials.rs:35-42 payloads
   float albedo[3];
   uint32_t kind;
   double fuzz_or_ior;
   double h_offset;
   uint64_t tex_w, tex_h;  // as written in the JSON (materials.rs:206-210)
-  uint64_t tex_off;       // byte offset of this texture in the texture blob
+  uint64_t tex_off;       // byte offset of this texture in the RGB8 blob (DevScene::tex; the general path)
   uint64_t tex_nbytes;
+  // the texture as 4-byte texels (DevScene::tex4, texels_fast() below): ONE aligned dword load per Texture hit instead of
+  // three byte loads behind 64-bit index arithmetic
+  uint32_t texel_off;     // index of its first texel in DevScene::tex4
+  uint32_t texel_last;    // tex_nbytes / 3 - 1: the texel an out-of-range index is clamped to
+  uint32_t tex_fast;      // 1: take that path (the record's sizes are in texels_fast()'s range)
+  uint32_t pad;
 };
+static_assert(sizeof(SphereMat) == 80, "SphereMat is 80 B");
+// When the 4-byte-texel path returns what materials.rs:236-254 returns.  With width, height <= 2^24 and |h_offset| <= 1024
+// the reference's index arithmetic cannot wrap: row <= height - 1 < 2^24 (v lies in [0, 1]), col <= 1025 * 2^24 < 2^35, so
+// row * width + col < 2^49 — a column beyond 2^32 - 1 may be clamped there (the index is out of range either way) and
+// v_mad_u64_u32 forms the index exactly.  Anything else keeps the u64 arithmetic on the RGB8 bytes.
+RT_HD bool texels_fast(uint64_t tex_w, uint64_t tex_h, double h_offset, uint64_t nbytes, uint64_t texels_before) {
+  return tex_w <= (1ull << 24) && tex_h <= (1ull << 24) && h_offset >= -1024.0 && h_offset <= 1024.0 && nbytes >= 3 &&
+         texels_before + nbytes / 3 < (1ull << 31);
+}
 // f32 cull record for TWO spheres (SoA so one packed f32 instruction handles both):
 // centre rounded to f32 and R = r^2 inflated by the rounding budget of that sphere.
 struct CullPair {  // 32 B
@@ -63,7 +78,7 @@ struct CullPair {  // 32 B
 constexpr uint32_t CULL_CHUNK = RT_CULL_CHUNK;  // pairs per scan chunk; the table is padded to this
 
 // Per-sphere fields every hit needs besides the geometry (48 B; the LDS copy of the material
-// table).  Texture parameters stay in the 64 B SphereMat and are fetched only when a Texture
+// table).  Texture parameters stay in the 80 B SphereMat and are fetched only when a Texture
 // sphere is hit.
 struct MatCore {
   float albedo[3];
@@ -104,7 +119,6 @@ struct GridDesc {
   uint32_t n_items;
   float pull;         // 8 * grid_walk_eps(max n): how far the crossing planes are pulled back
   float pad;
-  double goff[3];     // -gmin * inv_cell: x_cell = fma(x, inv_cell, goff)
   double nd[3];       // n[] as doubles (the slab test's far planes)
 };
 constexpr uint32_t GRID_MAX_AXIS = 256;        // cells per axis (bounds the f32 error of the walk)
@@ -139,9 +153,14 @@ struct DevScene {
   const SphereMat* mat;
   const CullPair* cull;
   const uint32_t* lights;  // sphere indices of Light spheres, object order (raytracer.rs:220-229)
-  const uint8_t* tex;      // all textures back to back, RGB8
-  const uint8_t* sky;      // sky texture RGB8
+  const uint8_t* tex;      // all textures back to back, RGB8 (null on the device when every texture takes the 4-byte path)
+  const uint8_t* sky;      // sky texture RGB8 (null on the device when sky_fast)
   uint64_t sky_w, sky_h;
+  const uint32_t* tex4;    // the same texels, R | G << 8 | B << 16, 4 bytes each (SphereMat::texel_off indexes it)
+  const uint32_t* sky4;
+  uint32_t sky_fast;       // sky_w, sky_h <= 2^24 and sky_w * sky_h < 2^31: 24-bit index arithmetic on sky4
+  float sky_wm1_f, sky_hm1_f;  // (float)(sky_w - 1), (float)(sky_h - 1) (raytracer.rs:149-150), converted once
+  uint32_t pad2;
   GridDesc grid;
   const uint32_t* cell_word;   // [n_cells][2]: {first item | count << 20, first two item indices (u16 | u16 << 16, 0xFFFF = none)}
   const uint16_t* cell_items;  // [n_items] sphere indices, object order inside a cell
@@ -679,12 +698,29 @@ RT_HD Rgb texel_fetch(const DevScene& sc, const SphereMat& m, uint64_t col, uint
   const uint8_t* px = sc.tex + m.tex_off + base_pixel;
   return rgb(rt_div255f((float)px[0]), rt_div255f((float)px[1]), rt_div255f((float)px[2]));
 }
+RT_HD uint32_t sat_u32(double x) {  // min(Rust's `f64 as u64`, 2^32 - 1): NaN and negatives -> 0
+  const double c = fmin(fmax(x, 0.0), 4294967295.0);  // (fmax / fmin drop a NaN operand)
+  return (uint32_t)c;
+}
+RT_HD Rgb rgb_of_texel(uint32_t w) {  // bytes -> colour / 255 (materials.rs:247-252): v_cvt_f32_ubyte0/1/2 + rt_div255f
+  return rgb(rt_div255f((float)(w & 0xFFu)), rt_div255f((float)((w >> 8) & 0xFFu)), rt_div255f((float)((w >> 16) & 0xFFu)));
+}
 RT_HD Rgb texture_albedo(const DevScene& sc, const SphereMat& m, double u, double v, uint32_t& tex_oob) {
   double rot = u + m.h_offset;
   if (rot > 1.0) rot = rot - 1.0;
   double uu = rot * (double)m.tex_w;
   double vv = (1.0 - v) * (double)(m.tex_h - 1);
-  return texel_fetch(sc, m, sat_u64(floor(uu)), sat_u64(floor(vv)), tex_oob);
+  const double fu = floor(uu), fv = floor(vv);
+  if (m.tex_fast) {  // (texels_fast: the same texel by construction — one multiply-add, one compare, one dword load)
+    const unsigned long long pi = (unsigned long long)sat_u32(fv) * (unsigned long long)(uint32_t)m.tex_w + (unsigned long long)sat_u32(fu);
+    uint32_t idx = (uint32_t)pi;
+    if (pi > (unsigned long long)m.texel_last) { tex_oob++; idx = m.texel_last; }
+#ifdef RT_EXP_TEX_HOT  // (timing experiment only — WRONG image: every texel fetch hits the same few cache lines)
+    idx &= 255u;
+#endif
+    return rgb_of_texel(sc.tex4[m.texel_off + idx]);
+  }
+  return texel_fetch(sc, m, sat_u64(fu), sat_u64(fv), tex_oob);
 }
 
 // ------------------------------------------------------------------ colour: forward form
@@ -755,8 +791,22 @@ RT_HD Rgb sky_color(const DevScene& sc, V3 d, uint32_t& tex_oob) {
   if (!want_x)
     return rgb((1.0f - t) * 1.0f + t * 0.5f, (1.0f - t) * 1.0f + t * 0.7f, (1.0f - t) * 1.0f + t * 1.0f);
   float u = clamp01(0.5f * ((float)qx + 1.0f));
-  uint64_t x = sat_u64_f32(u * (float)(sc.sky_w - 1));
-  uint64_t y = sat_u64_f32((1.0f - t) * (float)(sc.sky_h - 1));
+  const float xf = u * sc.sky_wm1_f, yf = (1.0f - t) * sc.sky_hm1_f;  // raytracer.rs:149-150
+  if (sc.sky_fast) {
+    // u and 1 - t lie in [0, 1] (or are NaN), so xf <= sky_w - 1 < 2^24 and yf <= sky_h - 1 < 2^24 exactly: `as usize` is a
+    // plain conversion, the index a 24-bit multiply-add below 2^31, and it cannot leave the texture (the check stays)
+    const uint32_t x = !(xf > 0.0f) ? 0u : (uint32_t)xf, y = !(yf > 0.0f) ? 0u : (uint32_t)yf;
+    const uint32_t last = (uint32_t)sc.sky_w * (uint32_t)sc.sky_h - 1u;
+    uint32_t idx = (uint32_t)rt_mul24((int)y, (int)(uint32_t)sc.sky_w) + x;
+    if (idx > last) { tex_oob++; idx = last; }
+#ifdef RT_EXP_SKY_HOT  // (timing experiment only — WRONG image: every sky fetch hits the same few cache lines)
+    idx &= 255u;
+#endif
+    const uint32_t w = sc.sky4[idx];
+    return rgb(rt_div255f(0.7f * (float)(w & 0xFFu)), rt_div255f(0.7f * (float)((w >> 8) & 0xFFu)), rt_div255f(0.7f * (float)((w >> 16) & 0xFFu)));
+  }
+  uint64_t x = sat_u64_f32(xf);
+  uint64_t y = sat_u64_f32(yf);
   uint64_t base = (y * sc.sky_w + x) * 3;
   if (base + 2 >= sc.sky_w * sc.sky_h * 3) { tex_oob++; base = (sc.sky_w * sc.sky_h - 1) * 3; }
 #ifdef RT_EXP_SKY_HOT  // (timing experiment only — WRONG image: every sky fetch hits the same few cache lines)
@@ -901,11 +951,19 @@ RT_HD bool texel_fast(V3 point, const SphereGeom& g, double h_offset, uint64_t t
 }
 // (u, v) for texture_albedo: the fast pair when it is sure of its texel (texture_albedo repeats texel_sure's arithmetic
 // on it, bit for bit, and so floors to that texel), else u = NaN: take sphere_uv.
-RT_HD_COLD UV sphere_uv_for_texel(V3 point, SphereGeom g, const SphereMat* mats, uint32_t idx) {
-  const UV a = fast_uv_core(point, g);
+// A LEAF on purpose: as a function that may call sphere_uv itself it had to keep its return address in a VGPR lane and
+// spill that register around the call — one 256-byte scratch store and load per wave and Texture hit, 5.65 GB of HBM
+// writes per 4K textured frame (profiles/r03_run40_pmc_cfg3.json).  The caller asks sphere_uv when u comes back NaN.
+RT_HD_COLD UV fast_uv_for_texel(V3 point, SphereGeom g, const SphereMat* mats, uint32_t idx) {
+  UV a = fast_uv_core(point, g);
   uint64_t col, row;
-  if (texel_sure(a.u, a.v, mats[idx].h_offset, mats[idx].tex_w, mats[idx].tex_h, col, row)) return a;
-  return sphere_uv(point, g);
+  if (!texel_sure(a.u, a.v, mats[idx].h_offset, mats[idx].tex_w, mats[idx].tex_h, col, row)) a.u = rt_nan();
+  return a;
+}
+RT_HD UV sphere_uv_for_texel(V3 point, const SphereGeom& g, const SphereMat* mats, uint32_t idx) {
+  const UV a = fast_uv_for_texel(point, g, mats, idx);
+  if (a.u == a.u) return a;
+  return sphere_uv(point, g);  // ~1e-8 of the hits: a texel boundary closer than TEXEL_EPS, the poles, non-finite input
 }
 // unit_vector (point3d.rs:67-70) with one real division: 1/l, then div_by_recip per component
 RT_HD V3 unit_vector_fast(V3 a) {

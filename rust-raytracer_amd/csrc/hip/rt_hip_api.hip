@@ -39,7 +39,7 @@ struct RtHipScene {
   rtc::DevScene dev{};     // device pointers filled in
   bool has_lights = false, simple_colour = false;
   void* d_geom = nullptr; void* d_mat = nullptr; void* d_cull = nullptr; void* d_lights = nullptr;
-  void* d_tex = nullptr; void* d_sky = nullptr;
+  void* d_tex = nullptr; void* d_sky = nullptr; void* d_tex4 = nullptr; void* d_sky4 = nullptr;
   void* d_matc = nullptr; void* d_cell_word = nullptr; void* d_cell_items = nullptr; void* d_large = nullptr;
   void* d_all = nullptr;   // 0..n-1: the `large` list of the brute-force arm (variant 1)
   void* d_large_geom = nullptr;
@@ -61,6 +61,12 @@ struct RtHipScene {
   int order_age = 0;        // frames since the order was last invalidated (geometry / camera / option change)
   int tile_affinity = 1;    // "tile_affinity" option: runs of tiles belong to one XCD's queue (framebuffer lines complete in one L2)
   int order_mode = 2;       // "tile_order" option: 0 top row first, 1 bottom row first, 2 deepest tiles of the previous frame first
+                            // (a first frame: seeded, below), 3 the seeded order alone (a one-shot render: nothing measured or sorted for a next frame)
+  int order_seed = 1;       // "order_seed" option: 1 = a frame without a measured order sorts its tiles by what the spheres' projections
+                            // say about path depth (seed_tile_depths); 0 = bottom row first, as before round 4; 2 = a probe launch instead
+  struct SeedSphere { double c[3], r; uint32_t kind; };
+  std::vector<SeedSphere> seed_spheres;  // host copy of (centre, radius, material kind): what the seed projects
+  std::vector<uint32_t> seed_depth;      // staging of the seeded depths (kept alive until the copy that reads it has run)
   int light_pool_cap = 0;  // "light_pool" option: cap on the light-frame pool of lit scenes (0 = as many as fit; tests shrink it to force the fall-back)
   int chunk_spp = 0;       // 0 = automatic
   int tile_batch = 0;      // 0 = automatic; else tiles a workgroup takes from the queue per atomic, 1..64
@@ -68,15 +74,27 @@ struct RtHipScene {
   int tile_shape = 0;      // 0: 2^k x 2^k squares (default: 0.9 % faster); 1: runs of 4^k pixels of one scanline (contiguous
                            // framebuffer bytes: HBM writes 10.9 -> 5.9 MiB per 1200x800 frame, profiles/r02_run8_*)
 
-  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  // What rt_hip_wait reports about a launch lives in one of two SLOTS, used alternately: its event pair, the rows and waves
+  // it covered, and a pinned host copy of its counters that an async copy fills right behind the kernel (stream-ordered:
+  // the next launch's counter reset cannot overtake it).  Two launches of a scene may therefore be in flight on its stream
+  // — frame i+1 rendering while frame i is gathered, rt_hip_group_submit / _collect — and a wait never issues a synchronous
+  // device-to-host copy (it cost every rank of a multi-GPU frame ~25 us on the frame's critical path).
+  struct Slot {
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_copied = nullptr;
+    unsigned long long* h_counters = nullptr;  // pinned, RT_SLOT_COUNTERS words
+    uint32_t rows = 0;
+    uint64_t waves = 0;
+    bool launched = false;   // a kernel ran for it (false: an empty shard)
+    std::chrono::steady_clock::time_point t_launch;
+  } slot[2];
+  uint64_t n_launches = 0;   // launch i uses slot[i & 1]
   hipStream_t last_stream = nullptr;
-  bool launched = false;
   bool in_flight = false;  // a launch has been enqueued and rt_hip_wait has not returned for it yet
-  uint32_t last_rows = 0;
   uint64_t last_waves = 0;
   int variant = 0;
-  std::chrono::steady_clock::time_point t_launch;
+  Slot& last_slot() { return slot[(n_launches + 1) & 1]; }  // the slot of the most recent launch
 };
+constexpr uint32_t RT_SLOT_COUNTERS = 24;  // segments, exact tests, tex_oob, grid steps, 4 x wave trip counts, 8 x section cycles, profile clocks
 
 extern "C" const char* rt_hip_last_error(void) { return g_err.c_str(); }
 
@@ -116,12 +134,14 @@ extern "C" int rt_hip_device_count(void) {
 extern "C" void rt_hip_scene_destroy(RtHipScene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  for (void* p : {s->d_geom, s->d_mat, s->d_cull, s->d_lights, s->d_tex, s->d_sky, (void*)s->d_counters, s->d_matc,
+  for (void* p : {s->d_geom, s->d_mat, s->d_cull, s->d_lights, s->d_tex, s->d_sky, s->d_tex4, s->d_sky4, (void*)s->d_counters, s->d_matc,
                   s->d_cell_word, s->d_cell_items, s->d_large, s->d_all, s->d_large_geom, s->d_frame, (void*)s->d_tile_depth,
                   (void*)s->d_tile_order})
     if (p) (void)hipFree(p);
-  if (s->ev_start) (void)hipEventDestroy(s->ev_start);
-  if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
+  for (auto& sl : s->slot) {
+    for (hipEvent_t e : {sl.ev_start, sl.ev_stop, sl.ev_copied}) if (e) (void)hipEventDestroy(e);
+    if (sl.h_counters) (void)hipHostFree(sl.h_counters);
+  }
   delete s;
 }
 
@@ -144,6 +164,7 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   rtc::HostTables t;
   std::string why = rtc::build_tables(*scene, t);
   if (!why.empty()) return fail(RT_ERR_INVALID, why);
+  rtc::build_texels(*scene, t);
   RT_HIP_TRY(hipSetDevice(device));
   RtHipScene* s = new RtHipScene;
   s->device = device;
@@ -151,6 +172,11 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   s->host.spheres = nullptr; s->host.textures = nullptr; s->host.sky_rgb8 = nullptr;
   s->has_lights = !t.lights.empty();
   s->simple_colour = t.simple_colour;
+  s->seed_spheres.resize(scene->n_spheres);
+  for (uint32_t i = 0; i < scene->n_spheres; ++i) {
+    const RtSphere& sp = scene->spheres[i];
+    s->seed_spheres[i] = RtHipScene::SeedSphere{{sp.center[0], sp.center[1], sp.center[2]}, std::fabs(sp.radius), sp.kind};
+  }
   s->grid = t.grid;
   rtc::fill_dev_scene(*scene, t, s->dev);
   {
@@ -174,25 +200,37 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
     for (uint32_t i = 0; i < scene->n_spheres; ++i) all[i] = i;
     if ((rc = upload(&s->d_all, all)) != RT_OK) return bail(rc);
   }
+  // textures and sky: resident as 4-byte texels (rt_tables.h build_texels; one dword load per fetch); the caller's RGB8
+  // bytes are uploaded too only if some record is outside that path's range (rt_core.h texels_fast)
+  if ((rc = upload(&s->d_tex4, t.tex4)) != RT_OK) return bail(rc);
+  if ((rc = upload(&s->d_sky4, t.sky4)) != RT_OK) return bail(rc);
   {
-    std::vector<uint8_t> blob(t.tex_bytes);
-    for (uint32_t i = 0; i < scene->n_textures; ++i)
-      if (scene->textures[i].nbytes) std::memcpy(&blob[t.tex_off[i]], scene->textures[i].rgb8, scene->textures[i].nbytes);
+    std::vector<uint8_t> blob(t.need_rgb8 ? t.tex_bytes : 0);
+    if (t.need_rgb8)
+      for (uint32_t i = 0; i < scene->n_textures; ++i)
+        if (scene->textures[i].nbytes) std::memcpy(&blob[t.tex_off[i]], scene->textures[i].rgb8, scene->textures[i].nbytes);
     if ((rc = upload(&s->d_tex, blob)) != RT_OK) return bail(rc);
   }
   {
     std::vector<uint8_t> sky;
-    if (scene->sky_mode == RT_SKY_TEXTURE) sky.assign(scene->sky_rgb8, scene->sky_rgb8 + scene->sky_w * scene->sky_h * 3);
+    if (scene->sky_mode == RT_SKY_TEXTURE && !t.sky_fast) sky.assign(scene->sky_rgb8, scene->sky_rgb8 + scene->sky_w * scene->sky_h * 3);
     if ((rc = upload(&s->d_sky, sky)) != RT_OK) return bail(rc);
   }
-  if (hipMalloc((void**)&s->d_counters, (32 + 4 * RT_TIMELINE_WAVES) * sizeof(unsigned long long)) != hipSuccess ||
-      hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess)
-    return bail(fail(RT_ERR_HIP, "hipMalloc/hipEventCreate failed"));
+  if (hipMalloc((void**)&s->d_counters, (32 + 4 * RT_TIMELINE_WAVES) * sizeof(unsigned long long)) != hipSuccess)
+    return bail(fail(RT_ERR_HIP, "hipMalloc(counters) failed"));
+  for (auto& sl : s->slot) {
+    if (hipEventCreate(&sl.ev_start) != hipSuccess || hipEventCreate(&sl.ev_stop) != hipSuccess ||
+        hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void**)&sl.h_counters, RT_SLOT_COUNTERS * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess)
+      return bail(fail(RT_ERR_HIP, "hipEventCreate/hipHostMalloc failed"));
+    std::memset(sl.h_counters, 0, RT_SLOT_COUNTERS * sizeof(unsigned long long));
+  }
   if (hipMemset(s->d_counters, 0, (32 + 4 * RT_TIMELINE_WAVES) * sizeof(unsigned long long)) != hipSuccess)
     return bail(fail(RT_ERR_HIP, "hipMemset failed"));
   s->dev.geom = (const rtc::SphereGeom*)s->d_geom; s->dev.mat = (const rtc::SphereMat*)s->d_mat;
   s->dev.cull = (const rtc::CullPair*)s->d_cull; s->dev.lights = (const uint32_t*)s->d_lights;
   s->dev.tex = (const uint8_t*)s->d_tex; s->dev.sky = (const uint8_t*)s->d_sky;
+  s->dev.tex4 = (const uint32_t*)s->d_tex4; s->dev.sky4 = (const uint32_t*)s->d_sky4;
   s->dev.matc = (const rtc::MatCore*)s->d_matc; s->dev.cell_word = (const uint32_t*)s->d_cell_word;
   s->dev.cell_items = (const uint16_t*)s->d_cell_items; s->dev.large = (const uint32_t*)s->d_large;
   s->dev.large_geom = (const rtc::SphereGeom*)s->d_large_geom;
@@ -211,7 +249,8 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
   if (!std::strcmp(key, "tile_log2")) { if (value < -1 || value > 3) return fail(RT_ERR_INVALID, "tile_log2 must be -1..3"); s->tile_log2 = (int)value; return RT_OK; }
   if (!std::strcmp(key, "tile_shape")) { if (value < 0 || value > 3) return fail(RT_ERR_INVALID, "tile_shape must be 0 (square), 1 (scanline runs), 2 (4:1) or 3 (16:1)"); s->tile_shape = (int)value; return RT_OK; }
   if (!std::strcmp(key, "tile_affinity")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_affinity must be 0 (off), 1 (large frames) or 2 (any frame of 8+ runs: tests)"); s->tile_affinity = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
-  if (!std::strcmp(key, "tile_order")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_order must be 0, 1 or 2"); s->order_mode = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
+  if (!std::strcmp(key, "tile_order")) { if (value < 0 || value > 3) return fail(RT_ERR_INVALID, "tile_order must be 0, 1, 2 or 3"); s->order_mode = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
+  if (!std::strcmp(key, "order_seed")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "order_seed must be 0 (off), 1 (projection) or 2 (probe launch)"); s->order_seed = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
   if (!std::strcmp(key, "light_pool")) { if (value < 0 || value > 1024 || (value != 0 && value < 32)) return fail(RT_ERR_INVALID, "light_pool must be 0 (automatic) or 32..1024"); s->light_pool_cap = (int)value; return RT_OK; }
   if (!std::strcmp(key, "tile_batch")) { if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "tile_batch must be 0..64"); s->tile_batch = (int)value; return RT_OK; }
   if (!std::strcmp(key, "chunk_spp")) { if (value < 0) return fail(RT_ERR_INVALID, "chunk_spp must be >= 0"); s->chunk_spp = (int)value; return RT_OK; }
@@ -274,15 +313,74 @@ int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka, size_t lds_bytes, uint32_
 }
 }  // namespace
 
+namespace {
+// A depth guess per pixel tile without tracing anything: where the spheres project.  The frame ends on its deepest paths
+// (DESIGN.md §4.1), and those start where a camera ray meets glass (internal reflections), metal, or any sphere resting on
+// the ground (bounces between the two) — so a tile under the projected bounding box of a Glass sphere gets depth 40, Metal
+// 20, anything else 10, bare ground and sky 0; rt_order_tiles sorts by it like by a measured depth.  Spheres that cover more
+// than half the frame (the ground) or cross the camera plane say nothing and are skipped.  Fills s->seed_depth[n_tiles].
+void rt_seed_tile_depths(RtHipScene* s, const rtk::KArgs& ka, const RtRowTiles* tiles, uint32_t local_rows) {
+  std::vector<uint32_t>& out = s->seed_depth;
+  out.assign(ka.n_tiles, 0u);
+  const double* O = s->host.cam_origin;
+  double M[3][3], inv[3][3];  // columns: lower_left - origin, horizontal, vertical (camera.rs:79-84: dir = ll + u h + v v - o)
+  for (int i = 0; i < 3; ++i) { M[i][0] = s->host.cam_lower_left[i] - O[i]; M[i][1] = s->host.cam_horizontal[i]; M[i][2] = s->host.cam_vertical[i]; }
+  const double det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                     M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+  if (!(std::fabs(det) > 1e-300) || !std::isfinite(det)) return;  // degenerate camera: no seed (bottom row first within one bucket)
+  inv[0][0] = (M[1][1] * M[2][2] - M[1][2] * M[2][1]) / det; inv[0][1] = (M[0][2] * M[2][1] - M[0][1] * M[2][2]) / det; inv[0][2] = (M[0][1] * M[1][2] - M[0][2] * M[1][1]) / det;
+  inv[1][0] = (M[1][2] * M[2][0] - M[1][0] * M[2][2]) / det; inv[1][1] = (M[0][0] * M[2][2] - M[0][2] * M[2][0]) / det; inv[1][2] = (M[0][2] * M[1][0] - M[0][0] * M[1][2]) / det;
+  inv[2][0] = (M[1][0] * M[2][1] - M[1][1] * M[2][0]) / det; inv[2][1] = (M[0][1] * M[2][0] - M[0][0] * M[2][1]) / det; inv[2][2] = (M[0][0] * M[1][1] - M[0][1] * M[1][0]) / det;
+  const double W = (double)s->host.width, H = (double)s->host.height;
+  const bool tiled = tiles && tiles->tile_rows && tiles->tile_stride;
+  const uint32_t tiles_y = (local_rows + (1u << ka.tile_hl) - 1u) >> ka.tile_hl;
+  for (const RtHipScene::SeedSphere& sp : s->seed_spheres) {
+    if (!(sp.r > 0.0) || !std::isfinite(sp.r) || sp.kind == RT_MAT_LIGHT) continue;
+    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+    bool behind = false;
+    for (int corner = 0; corner < 8 && !behind; ++corner) {
+      double w[3];
+      for (int i = 0; i < 3; ++i) w[i] = sp.c[i] + (((corner >> i) & 1) ? sp.r : -sp.r) - O[i];
+      const double a = inv[0][0] * w[0] + inv[0][1] * w[1] + inv[0][2] * w[2];
+      const double b = inv[1][0] * w[0] + inv[1][1] * w[1] + inv[1][2] * w[2];
+      const double c = inv[2][0] * w[0] + inv[2][1] * w[1] + inv[2][2] * w[2];
+      if (!(a > 1e-9)) { behind = true; break; }
+      const double px = b / a * (W - 1.0), py = H - c / a * (H - 1.0);  // raytracer.rs:199-200 inverted
+      if (!std::isfinite(px) || !std::isfinite(py)) { behind = true; break; }
+      x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
+    }
+    if (behind || x1 < 0.0 || y1 < 0.0 || x0 > W - 1.0 || y0 > H - 1.0) continue;
+    x0 = std::max(x0, 0.0); y0 = std::max(y0, 0.0); x1 = std::min(x1, W - 1.0); y1 = std::min(y1, H - 1.0);
+    if ((x1 - x0 + 1.0) * (y1 - y0 + 1.0) > 0.5 * W * H) continue;
+    const uint32_t depth = sp.kind == RT_MAT_GLASS ? 40u : (sp.kind == RT_MAT_METAL ? 20u : 10u);
+    const uint32_t bx0 = (uint32_t)x0 >> ka.tile_wl, bx1 = (uint32_t)x1 >> ka.tile_wl;
+    for (uint32_t y = (uint32_t)y0; y <= (uint32_t)y1; ++y) {
+      uint32_t lr = y;  // the packed row of scanline y in this launch, if it renders it (inverse of rt_tiles_global_row)
+      if (tiled) {
+        const uint32_t k = y / tiles->tile_rows;
+        if (k < tiles->first_tile || (k - tiles->first_tile) % tiles->tile_stride != 0u) continue;
+        lr = (k - tiles->first_tile) / tiles->tile_stride * tiles->tile_rows + y % tiles->tile_rows;
+      }
+      const uint32_t by = lr >> ka.tile_hl;
+      if (by >= tiles_y) continue;
+      uint32_t* row = out.data() + (size_t)by * ka.tiles_x;
+      for (uint32_t bx = bx0; bx <= bx1 && bx < ka.tiles_x; ++bx) if (row[bx] < depth) row[bx] = depth;
+    }
+  }
+}
+}  // namespace
+
 extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb8, void* d_linear, void* stream_) {
   if (!s) return fail(RT_ERR_INVALID, "null argument");
   const uint32_t local_rows = rt_tiles_local_rows(s->host.height, tiles);
   if (!d_rgb8 && local_rows != 0) return fail(RT_ERR_INVALID, "null framebuffer");
   hipStream_t stream = (hipStream_t)stream_;
-  // one tile-queue cursor / counter block / event pair per scene: launches of a scene are ordered on ONE stream
-  // (a caller that drained the first stream itself — hipStreamSynchronize, an event — need not call rt_hip_wait first)
-  // (hipErrorNotReady = work pending; anything else — success, or a stream the caller has destroyed since — holds no work of ours)
-  if (s->in_flight && stream != s->last_stream && hipStreamQuery(s->last_stream) != hipErrorNotReady) s->in_flight = false;
+  // one tile-queue cursor / counter block per scene: launches of a scene are ordered on ONE stream
+  // (a caller that drained the first stream itself — hipStreamSynchronize, an event — need not call rt_hip_wait first:
+  //  the scene asks its OWN event, recorded behind the last launch's counter copy — never the caller's stream handle,
+  //  which may have been destroyed since.  The abandoned launch's counters stay readable in its slot until two more
+  //  launches have reused it; nobody waited for them.)
+  if (s->in_flight && stream != s->last_stream && hipEventQuery(s->last_slot().ev_copied) != hipErrorNotReady) s->in_flight = false;
   (void)hipGetLastError();  // (the query's status is not an error of this call)
   if (s->in_flight && stream != s->last_stream)
     return fail(RT_ERR_INVALID, "rt_hip_render: this scene has a launch in flight on another stream (call rt_hip_wait first, "
@@ -291,20 +389,30 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   if (s->host.samples_per_pixel > (1u << 22)) return fail(RT_ERR_UNSUPPORTED, "more than 2^22 samples per pixel");
   if (s->host.width > 524280u) return fail(RT_ERR_UNSUPPORTED, "frames wider than 524280 pixels");
   RT_HIP_TRY(hipSetDevice(s->device));
-  s->last_rows = local_rows;
+  RtHipScene::Slot& sl = s->slot[s->n_launches & 1];
+  s->n_launches++;
+  sl.rows = local_rows; sl.waves = 0; sl.launched = false;
   s->last_stream = stream;
-  s->t_launch = std::chrono::steady_clock::now();
+  sl.t_launch = std::chrono::steady_clock::now();
   RT_HIP_TRY(hipMemsetAsync(s->d_counters, 0, 32 * sizeof(unsigned long long), stream));
-  if (local_rows == 0) { s->launched = false; return RT_OK; }
+  // behind the kernel(s) of this launch: its counters into the slot's pinned words (what rt_hip_wait reads)
+  auto finish_launch = [&](bool launched) -> int {
+    sl.launched = launched; sl.waves = s->last_waves;
+    if (launched) RT_HIP_TRY(hipMemcpyAsync(sl.h_counters, s->d_counters, RT_SLOT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    else std::memset(sl.h_counters, 0, RT_SLOT_COUNTERS * sizeof(unsigned long long));
+    RT_HIP_TRY(hipEventRecord(sl.ev_copied, stream));
+    s->in_flight = true;
+    return RT_OK;
+  };
+  if (local_rows == 0) return finish_launch(false);
 #ifdef RT_WITH_SCAN_KERNEL
   if (s->variant == 2) {
-    RT_HIP_TRY(hipEventRecord(s->ev_start, stream));
+    RT_HIP_TRY(hipEventRecord(sl.ev_start, stream));
     int rc = launch_scan(s, tiles, d_rgb8, d_linear, stream, local_rows);
     if (rc != RT_OK) return rc;
     RT_HIP_TRY(hipGetLastError());
-    RT_HIP_TRY(hipEventRecord(s->ev_stop, stream));
-    s->launched = true; s->in_flight = true;
-    return RT_OK;
+    RT_HIP_TRY(hipEventRecord(sl.ev_stop, stream));
+    return finish_launch(true);
   }
 #endif
 
@@ -438,7 +546,8 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
       for (int x = 1; x < 8; ++x) ka.xcd_off[x] = ka.xcd_off[x - 1] + ka.xcd_cnt[x - 1];
     }
   }
-  if (s->order_mode == 2) {
+  bool seed_now = false;  // this frame has no measured order: sort its tiles by a seed first
+  if (s->order_mode >= 2) {
     RtHipScene::OrderKey key;
     key.n_tiles = ka.n_tiles; key.tile_log2 = tl; key.tile_shape = (uint32_t)s->tile_shape; key.aff_group_log2 = ka.aff_group_log2;
     key.tile_rows = ka.tile_rows; key.first_tile = ka.first_tile; key.tile_stride = ka.tile_stride; key.local_rows = local_rows;
@@ -451,36 +560,68 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
       s->order_cap = ka.n_tiles;
     }
     if (!(key == s->order_key)) { s->order_key = key; s->order_ready = false; s->order_age = 0; }
-    if (s->order_age < 2) ka.tile_depth = s->d_tile_depth;  // (measured only while the order is still being built)
-    if (s->order_ready) ka.tile_order = s->d_tile_order;
+    if (s->order_mode == 2 && s->order_age < 2) ka.tile_depth = s->d_tile_depth;  // (measured only while the order is still being built)
+    seed_now = !s->order_ready && s->order_seed != 0;
+    if (s->order_ready || seed_now) ka.tile_order = s->d_tile_order;
   }
 
-  RT_HIP_TRY(hipEventRecord(s->ev_start, stream));
   int rc;
   // instantiation = (lights, every albedo in [0, 1], tables in LDS, light-frame pool)
+  auto launch = [&](const rtk::KArgs& ka, uint32_t n_items) -> int {
+    int rc;
 #define RT_GO(HL, SIMPLE, LDS, POOLED) rc = launch_grid_t<HL, SIMPLE, LDS, POOLED>(s, ka, lds_bytes, n_items, stream)
-  const bool simple = s->simple_colour;
-  if (s->has_lights) {
-    if (pool_slots) { if (simple) RT_GO(true, true, true, true); else RT_GO(true, false, true, true); }
-    else if (lds_tables) { if (simple) RT_GO(true, true, true, false); else RT_GO(true, false, true, false); }
-    else { if (simple) RT_GO(true, true, false, false); else RT_GO(true, false, false, false); }
-  } else if (lds_tables) { if (simple) RT_GO(false, true, true, false); else RT_GO(false, false, true, false); }
-  else { if (simple) RT_GO(false, true, false, false); else RT_GO(false, false, false, false); }
+    const bool simple = s->simple_colour;
+    if (s->has_lights) {
+      if (pool_slots) { if (simple) RT_GO(true, true, true, true); else RT_GO(true, false, true, true); }
+      else if (lds_tables) { if (simple) RT_GO(true, true, true, false); else RT_GO(true, false, true, false); }
+      else { if (simple) RT_GO(true, true, false, false); else RT_GO(true, false, false, false); }
+    } else if (lds_tables) { if (simple) RT_GO(false, true, true, false); else RT_GO(false, false, true, false); }
+    else { if (simple) RT_GO(false, true, false, false); else RT_GO(false, false, false, false); }
 #undef RT_GO
-  if (rc != RT_OK) return rc;
-  RT_HIP_TRY(hipGetLastError());
-  RT_HIP_TRY(hipEventRecord(s->ev_stop, stream));
+    if (rc != RT_OK) return rc;
+    RT_HIP_TRY(hipGetLastError());
+    return RT_OK;
+  };
+  auto sort_tiles = [&]() -> int {
+    hipLaunchKernelGGL(rtk::rt_order_tiles, dim3(1), dim3(1024), 0, stream, (const uint32_t*)s->d_tile_depth, s->d_tile_order, ka.n_tiles, ka.aff_group_log2);
+    RT_HIP_TRY(hipGetLastError());
+    return RT_OK;
+  };
+  RT_HIP_TRY(hipEventRecord(sl.ev_start, stream));  // (a seeded frame's upload / probe and sort are inside its kernel_ms)
+  // A frame without a measured order (the first of a scene, a one-shot render) would leave the queue bottom row first
+  // and end on whatever deep path started last: 13.40 instead of 12.85 ms on the headline frame, 2.0 instead of 1.75 ms
+  // on its 1/8 shards.  Seed the order instead:
+  //   order_seed 1: a depth GUESS per tile from the spheres' projections (seed_tile_depths: no GPU work but a 4-byte-per-
+  //                 tile upload and the 50 us sort);
+  //   order_seed 2: a PROBE — this kernel at one sample per pixel and 8 segments at most measures the tiles' depths
+  //                 (its pixels are overwritten by the frame that follows), then the sort.
+  // The image never depends on the order.
+  if (seed_now) {
+    if (s->order_seed == 2) {
+      rtk::KArgs kp = ka;
+      kp.sc.spp = 1; kp.sc.max_depth = ka.sc.max_depth < 8u ? ka.sc.max_depth : 8u;
+      kp.chunk_spp = 1; kp.n_chunks = 1; kp.out_linear = nullptr;
+      kp.tile_order = nullptr; kp.tile_depth = s->d_tile_depth;
+      if ((rc = launch(kp, ka.n_tiles)) != RT_OK) return rc;
+      RT_HIP_TRY(hipMemsetAsync(s->d_counters, 0, 32 * sizeof(unsigned long long), stream));  // counters and queue cursors of the probe
+    } else {
+      rt_seed_tile_depths(s, ka, tiles, local_rows);
+      RT_HIP_TRY(hipMemcpyAsync(s->d_tile_depth, s->seed_depth.data(), (size_t)ka.n_tiles * 4, hipMemcpyHostToDevice, stream));
+    }
+    if ((rc = sort_tiles()) != RT_OK) return rc;
+    if (s->order_mode == 3) s->order_ready = true;  // (mode 2: this frame's measured depths replace the seed below)
+  }
+  if ((rc = launch(ka, n_items)) != RT_OK) return rc;
+  RT_HIP_TRY(hipEventRecord(sl.ev_stop, stream));
   // The next frame's order from this frame's depths (stream-ordered: ready before the next launch reads it).  Which tiles
   // breed deep paths is a property of scene and camera, so the order is rebuilt after the first two frames of a view
   // only — later frames of the same view reuse it and pay nothing; rt_hip_set_camera starts over.
   if (ka.tile_depth) {
     s->order_age++;
-    hipLaunchKernelGGL(rtk::rt_order_tiles, dim3(1), dim3(1024), 0, stream, (const uint32_t*)s->d_tile_depth, s->d_tile_order, ka.n_tiles, ka.aff_group_log2);
-    RT_HIP_TRY(hipGetLastError());
+    if ((rc = sort_tiles()) != RT_OK) return rc;
     s->order_ready = true;
   }
-  s->launched = true; s->in_flight = true;
-  return RT_OK;
+  return finish_launch(true);
 }
 
 extern "C" int rt_hip_debug_timeline(RtHipScene* s, uint64_t* out, uint32_t max_waves) {
@@ -492,34 +633,49 @@ extern "C" int rt_hip_debug_timeline(RtHipScene* s, uint64_t* out, uint32_t max_
   return (int)n;
 }
 
+namespace {
+// the report of the launch that used `sl` (its counter copy must have completed: the caller synchronised)
+void fill_stats(const RtHipScene* s, const RtHipScene::Slot& sl, RtStats* stats) {
+  std::memset(stats, 0, sizeof *stats);
+  stats->n_gpus_used = 1;
+  const unsigned long long* c = sl.h_counters;  // segments, exact tests, tex_oob, grid steps, 4 x wave trip counts, 8 x section cycles, profile clocks
+  float ms = 0.f;
+  if (sl.launched && hipEventElapsedTime(&ms, sl.ev_start, sl.ev_stop) != hipSuccess) { ms = 0.f; (void)hipGetLastError(); }
+  stats->samples = (uint64_t)sl.rows * s->host.width * s->host.samples_per_pixel;
+  stats->segments = c[0];
+  stats->sphere_tests = c[0] * (uint64_t)s->host.n_spheres;
+  stats->exact_tests = c[1];
+  stats->tex_oob = c[2];
+  stats->grid_steps = c[3];
+  for (int k = 0; k < 4; ++k) stats->wave_iters[k] = c[4 + k];
+  for (int k = 0; k < 8; ++k) stats->prof_cycles[k] = c[8 + k];
+  if (c[14] && sl.waves) {  // profile builds: longest / shortest wave, waves launched
+    stats->prof_cycles[7] = c[15];
+    stats->prof_cycles[8] = ~c[17];
+    stats->prof_cycles[10] = sl.waves;
+  }
+  stats->kernel_ms = ms;
+  stats->frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sl.t_launch).count();
+}
+// wait for ONE launch — the one that used slot `which` — and report it (the group's pipelined frames: frame i is collected
+// while frame i+1 is in flight on the same stream)
+int wait_slot(RtHipScene* s, int which, RtStats* stats) {
+  RT_HIP_TRY(hipSetDevice(s->device));
+  RtHipScene::Slot& sl = s->slot[which & 1];
+  RT_HIP_TRY(hipEventSynchronize(sl.ev_copied));
+  if (&sl == &s->last_slot()) s->in_flight = false;
+  if (stats) fill_stats(s, sl, stats);
+  return RT_OK;
+}
+}  // namespace
+
 extern "C" int rt_hip_wait(RtHipScene* s, RtStats* stats) {
   if (!s) return fail(RT_ERR_INVALID, "null argument");
   RT_HIP_TRY(hipSetDevice(s->device));
+  if (s->n_launches == 0) { if (stats) { std::memset(stats, 0, sizeof *stats); stats->n_gpus_used = 1; } return RT_OK; }
   RT_HIP_TRY(hipStreamSynchronize(s->last_stream));
   s->in_flight = false;
-  if (stats) {
-    std::memset(stats, 0, sizeof *stats);
-    stats->n_gpus_used = 1;
-    unsigned long long c[20] = {0};  // segments, exact tests, tex_oob, grid steps, 4 x wave trip counts, 8 x section cycles, profile clocks
-    RT_HIP_TRY(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
-    float ms = 0.f;
-    if (s->launched) RT_HIP_TRY(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
-    stats->samples = (uint64_t)s->last_rows * s->host.width * s->host.samples_per_pixel;
-    stats->segments = c[0];
-    stats->sphere_tests = c[0] * (uint64_t)s->host.n_spheres;
-    stats->exact_tests = c[1];
-    stats->tex_oob = c[2];
-    stats->grid_steps = c[3];
-    for (int k = 0; k < 4; ++k) stats->wave_iters[k] = c[4 + k];
-    for (int k = 0; k < 8; ++k) stats->prof_cycles[k] = c[8 + k];
-    if (c[14] && s->last_waves) {  // profile builds: longest / shortest wave, waves launched
-      stats->prof_cycles[7] = c[15];
-      stats->prof_cycles[8] = ~c[17];
-      stats->prof_cycles[10] = s->last_waves;
-    }
-    stats->kernel_ms = ms;
-    stats->frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s->t_launch).count();
-  }
+  if (stats) fill_stats(s, s->last_slot(), stats);
   return RT_OK;
 }
 

@@ -10,6 +10,12 @@
 // ONE device-to-host copy.  No intra-frame communication.  Philox is addressed by GLOBAL pixel index and
 // pixel sums are order-free, so the frame is bit-identical for every G.
 //
+// Frames are PIPELINED two deep (rt_hip_group_submit / rt_hip_group_collect; the blocking calls are submit + collect):
+// everything a frame touches exists twice (gather buffer, frame buffer, per-rank tile buffers, events, the scenes' stats
+// slots), a rank's kernels run on its render stream and its tiles travel on a second, TRANSFER stream that waits for the
+// kernel's event — so frame i's gather, de-interleave and device-to-host copy run while frame i+1 renders, and an
+// animation's step is the slowest rank's kernel, not kernel + gather + copy.
+//
 // Test hooks: RT_GPUS_EMULATE=1 lets ranks share devices (rank r -> device r mod visible devices; peer
 // transport only), so the whole path — threads, sharding, gather buffer layout, de-interleave — runs on a
 // one-GPU box; RT_GATHER_SELFTEST=1 makes a ONE-rank group go through the gather (RCCL communicator of one
@@ -17,6 +23,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library is dlopen'ed below, never linked
 
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -84,25 +91,42 @@ struct RtHipGroup {
   bool gather = false;               // G > 1 (or the one-rank self-test): gather + de-interleave after the kernels
   std::vector<int> device;
   std::vector<RtHipScene*> scene;
-  std::vector<hipStream_t> stream;
-  std::vector<hipEvent_t> ev_done;   // rank r: its tiles are in `stacked` (peer transport) / its kernel was enqueued (rccl)
-  std::vector<void*> d_tiles;        // rank r's packed tiles on ITS device (rank 0: a slice of `stacked`)
-  std::vector<RtRowTiles> tiles;
-  void* d_stacked = nullptr;         // device 0: G x pad_rows rows
-  void* d_frame = nullptr;           // device 0: height rows (G == 1: the same buffer)
-  hipEvent_t ev_assembled = nullptr;
+  std::vector<RtRowTiles> tiles;     // rank r renders RtRowTiles{RT_GROUP_TILE_ROWS, r, G}
+  std::vector<hipStream_t> stream;   // rank r: its kernels
+  std::vector<hipStream_t> xstream;  // rank r: the transfer of its tiles (peer copy / its side of the gather); xstream[0] also
+                                     // assembles: de-interleave + the device-to-host copy
+  // One frame in flight: its buffers and events (two of them, used alternately).
+  struct Frame {
+    void* d_stacked = nullptr;         // device 0: G x pad_rows rows
+    void* d_frame = nullptr;           // device 0: height rows (no gather: the same buffer)
+    std::vector<void*> d_tiles;        // rank r's packed tiles on ITS device (rank 0: a slice of `d_stacked`)
+    std::vector<hipEvent_t> ev_done;   // rank r: its kernel finished (recorded on stream[r])
+    std::vector<hipEvent_t> ev_sent;   // peer transport, r > 0: its tiles are in `d_stacked` (recorded on xstream[r])
+    std::vector<int> slot;             // the stats slot of scene[r] this frame's launch used
+    hipEvent_t ev_assembled = nullptr; // frame in scanline order on device 0 (xstream[0]; timed)
+    hipEvent_t ev_final = nullptr;     // ... and in the caller's buffer, if one was given
+    bool busy = false;                 // submitted, not collected
+    uint8_t* out = nullptr;
+    std::chrono::steady_clock::time_point t0;
+    double us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // RtStats.group_us
+  } frame[2];
+  uint64_t n_submitted = 0, n_collected = 0;
+  const Frame* last = nullptr;       // the frame rt_hip_group_frame points at (the last one collected)
   rtg::RcclApi api;
   std::vector<ncclComm_t> comm;
-  // one persistent host thread per rank: the launches of a frame go out in parallel (a serial launch loop
-  // would start rank 7 ~8 x 40 us late on a 2 ms shard)
+  // one persistent host thread per rank r >= 1 (rank 0 is launched by the submitting thread itself, which is awake
+  // anyway): the launches of a frame go out in parallel — a serial loop would start rank 7 ~8 x 40 us late on a 2 ms shard
   std::vector<std::thread> worker;
   std::mutex mu;
   std::condition_variable cv_go, cv_done;
-  uint64_t generation = 0;
-  uint32_t n_done = 0;
+  std::atomic<uint64_t> generation{0};
+  std::atomic<uint32_t> n_done{0};
+  int cur = 0;                       // the Frame the workers are enqueuing
   bool quit = false;
+  std::atomic<int> spin_us{0};       // "spin_us" option: a worker polls for the next frame this long before it sleeps on the condition variable
   std::vector<int> rc;
   std::vector<std::string> err;
+  std::vector<double> t_wake_us, t_enq_us;  // per rank: since Frame::t0 — thread running; its launch (+ transfer) enqueued
 };
 
 namespace rtg {
@@ -120,33 +144,50 @@ int resolve_gpus(const RtScene* scene, uint32_t n_gpus, uint32_t* out) {
   return RT_OK;
 }
 
+inline double us_since(std::chrono::steady_clock::time_point t0) {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// rank r's part of frame `f`: kernel on its render stream, then — on its transfer stream, behind the kernel's event —
+// its slice of the gather (peer transport; RCCL's gather is enqueued for all ranks together by the submitting thread)
+void enqueue_rank(RtHipGroup* g, RtHipGroup::Frame& f, uint32_t r) {
+  g->t_wake_us[r] = us_since(f.t0);
+  f.slot[r] = (int)(g->scene[r]->n_launches & 1);
+  int rc = rt_hip_render(g->scene[r], g->G > 1 ? &g->tiles[r] : nullptr, f.d_tiles[r], nullptr, g->stream[r]);
+  std::string err;
+  if (rc != RT_OK) err = rt_hip_last_error();
+  auto hip = [&](hipError_t e, const char* what) { if (rc == RT_OK && e != hipSuccess) { rc = RT_ERR_HIP; err = std::string(what) + ": " + hipGetErrorString(e); } };
+  if (rc == RT_OK) hip(hipEventRecord(f.ev_done[r], g->stream[r]), "hipEventRecord");
+  if (rc == RT_OK && g->gather) {
+    hip(hipStreamWaitEvent(g->xstream[r], f.ev_done[r], 0), "hipStreamWaitEvent");
+    if (!g->rccl && r != 0) {
+      hip(hipMemcpyPeerAsync(static_cast<uint8_t*>(f.d_stacked) + (size_t)r * g->pad_bytes, g->device[0], f.d_tiles[r], g->device[r], g->pad_bytes,
+                             g->xstream[r]), "hipMemcpyPeerAsync");
+      hip(hipEventRecord(f.ev_sent[r], g->xstream[r]), "hipEventRecord");
+    }
+  }
+  g->rc[r] = rc; g->err[r] = err;
+  g->t_enq_us[r] = us_since(f.t0);
+}
+
 void worker_main(RtHipGroup* g, uint32_t r) {
   uint64_t seen = 0;
   for (;;) {
+    if (const int spin = g->spin_us.load(std::memory_order_relaxed)) {  // (frames of an animation follow each other closely: poll before sleeping)
+      const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin);
+      while (g->generation.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
+    }
     {
       std::unique_lock<std::mutex> lk(g->mu);
-      g->cv_go.wait(lk, [&] { return g->quit || g->generation != seen; });
+      g->cv_go.wait(lk, [&] { return g->quit || g->generation.load(std::memory_order_acquire) != seen; });
       if (g->quit) return;
-      seen = g->generation;
+      seen = g->generation.load(std::memory_order_acquire);
     }
-    int rc = rt_hip_render(g->scene[r], g->G > 1 ? &g->tiles[r] : nullptr, g->d_tiles[r], nullptr, g->stream[r]);
-    std::string err;
-    if (rc != RT_OK) err = rt_hip_last_error();
-    if (rc == RT_OK && g->gather && !g->rccl && r != 0) {  // peer transport: this rank's slice of the gather
-      const hipError_t e = hipMemcpyPeerAsync(static_cast<uint8_t*>(g->d_stacked) + (size_t)r * g->pad_bytes, g->device[0], g->d_tiles[r],
-                                              g->device[r], g->pad_bytes, g->stream[r]);
-      if (e != hipSuccess) { rc = RT_ERR_HIP; err = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e); }
+    enqueue_rank(g, g->frame[g->cur], r);
+    if (g->n_done.fetch_add(1, std::memory_order_acq_rel) + 1 == g->G - 1) {
+      std::lock_guard<std::mutex> lk(g->mu);  // (the waiter re-checks n_done under this mutex: no lost wake-up)
+      g->cv_done.notify_one();
     }
-    if (rc == RT_OK) {
-      const hipError_t e = hipEventRecord(g->ev_done[r], g->stream[r]);
-      if (e != hipSuccess) { rc = RT_ERR_HIP; err = std::string("hipEventRecord: ") + hipGetErrorString(e); }
-    }
-    {
-      std::lock_guard<std::mutex> lk(g->mu);
-      g->rc[r] = rc; g->err[r] = err;
-      g->n_done++;
-    }
-    g->cv_done.notify_one();
   }
 }
 
@@ -167,20 +208,31 @@ extern "C" void rt_hip_group_destroy(RtHipGroup* g) {
   }
   g->cv_go.notify_all();
   for (auto& t : g->worker) if (t.joinable()) t.join();
+  for (uint32_t r = 0; r < g->scene.size(); ++r) {  // nothing of ours may be running when buffers and communicators go
+    (void)hipSetDevice(g->device[r]);
+    if (r < g->stream.size() && g->stream[r]) (void)hipStreamSynchronize(g->stream[r]);
+    if (r < g->xstream.size() && g->xstream[r]) (void)hipStreamSynchronize(g->xstream[r]);
+  }
   for (uint32_t r = 0; r < g->comm.size(); ++r)
     if (g->comm[r]) { (void)hipSetDevice(g->device[r]); (void)g->api.CommDestroy(g->comm[r]); }
   for (uint32_t r = 0; r < g->scene.size(); ++r) {
     (void)hipSetDevice(g->device[r]);
-    if (r < g->stream.size() && g->stream[r]) (void)hipStreamSynchronize(g->stream[r]);
-    if (r != 0 && r < g->d_tiles.size() && g->d_tiles[r]) (void)hipFree(g->d_tiles[r]);
-    if (r < g->ev_done.size() && g->ev_done[r]) (void)hipEventDestroy(g->ev_done[r]);
+    for (auto& f : g->frame) {
+      if (r != 0 && r < f.d_tiles.size() && f.d_tiles[r]) (void)hipFree(f.d_tiles[r]);
+      if (r < f.ev_done.size() && f.ev_done[r]) (void)hipEventDestroy(f.ev_done[r]);
+      if (r < f.ev_sent.size() && f.ev_sent[r]) (void)hipEventDestroy(f.ev_sent[r]);
+    }
     if (g->scene[r]) rt_hip_scene_destroy(g->scene[r]);
     if (r < g->stream.size() && g->stream[r]) (void)hipStreamDestroy(g->stream[r]);
+    if (r < g->xstream.size() && g->xstream[r]) (void)hipStreamDestroy(g->xstream[r]);
   }
   if (!g->device.empty()) (void)hipSetDevice(g->device[0]);
-  if (g->d_frame && g->d_frame != g->d_stacked) (void)hipFree(g->d_frame);
-  if (g->d_stacked) (void)hipFree(g->d_stacked);
-  if (g->ev_assembled) (void)hipEventDestroy(g->ev_assembled);
+  for (auto& f : g->frame) {
+    if (f.d_frame && f.d_frame != f.d_stacked) (void)hipFree(f.d_frame);
+    if (f.d_stacked) (void)hipFree(f.d_stacked);
+    if (f.ev_assembled) (void)hipEventDestroy(f.ev_assembled);
+    if (f.ev_final) (void)hipEventDestroy(f.ev_final);
+  }
   delete g;
 }
 
@@ -199,8 +251,9 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
   RtHipGroup* g = new RtHipGroup;
   g->G = G; g->width = scene->width; g->height = scene->height;
   g->row_bytes = (size_t)scene->width * 3;
-  g->device.resize(G); g->scene.assign(G, nullptr); g->stream.assign(G, nullptr); g->ev_done.assign(G, nullptr);
-  g->d_tiles.assign(G, nullptr); g->tiles.resize(G); g->rc.assign(G, RT_OK); g->err.resize(G);
+  g->device.resize(G); g->scene.assign(G, nullptr); g->stream.assign(G, nullptr); g->xstream.assign(G, nullptr);
+  g->tiles.resize(G); g->rc.assign(G, RT_OK); g->err.resize(G); g->t_wake_us.assign(G, 0.0); g->t_enq_us.assign(G, 0.0);
+  for (auto& f : g->frame) { f.d_tiles.assign(G, nullptr); f.ev_done.assign(G, nullptr); f.ev_sent.assign(G, nullptr); f.slot.assign(G, 0); }
   bool& shared_device = g->shared_device;
   for (uint32_t r = 0; r < G; ++r) {
     g->device[r] = (int)(r % (uint32_t)ndev);
@@ -224,24 +277,30 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
       th.emplace_back([g, scene, r]() {
         g->rc[r] = rt_hip_scene_create(scene, g->device[r], &g->scene[r]);
         if (g->rc[r] != RT_OK) { g->err[r] = rt_hip_last_error(); return; }
-        if (hipStreamCreateWithFlags(&g->stream[r], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&g->ev_done[r], hipEventDisableTiming) != hipSuccess) {
-          g->rc[r] = RT_ERR_HIP; g->err[r] = "hipStreamCreate/hipEventCreate failed";
-          return;
+        bool ok = hipStreamCreateWithFlags(&g->stream[r], hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&g->xstream[r], hipStreamNonBlocking) == hipSuccess;
+        for (auto& f : g->frame) {
+          ok = ok && hipEventCreateWithFlags(&f.ev_done[r], hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&f.ev_sent[r], hipEventDisableTiming) == hipSuccess;
+          if (ok && r != 0 && hipMalloc(&f.d_tiles[r], g->pad_bytes ? g->pad_bytes : 16) != hipSuccess) ok = false;
         }
-        if (r != 0 && hipMalloc(&g->d_tiles[r], g->pad_bytes ? g->pad_bytes : 16) != hipSuccess) { g->rc[r] = RT_ERR_HIP; g->err[r] = "hipMalloc(tiles) failed"; }
+        if (!ok) { g->rc[r] = RT_ERR_HIP; g->err[r] = "hipStreamCreate / hipEventCreate / hipMalloc(tiles) failed"; }
       });
     for (auto& t : th) t.join();
     for (uint32_t r = 0; r < G; ++r)
       if (g->rc[r] != RT_OK) return bail(g->rc[r], "rank " + std::to_string(r) + ": " + g->err[r]);
   }
   if (hipSetDevice(g->device[0]) != hipSuccess) return bail(RT_ERR_HIP, "hipSetDevice failed");
-  if (hipMalloc(&g->d_stacked, g->pad_bytes * G ? g->pad_bytes * G : 16) != hipSuccess) return bail(RT_ERR_HIP, "hipMalloc(gather buffer) failed");
-  g->d_tiles[0] = g->d_stacked;  // rank 0 renders into its own slice: the gather is in place on the root
-  if (g->gather) {
-    if (hipMalloc(&g->d_frame, (size_t)g->height * g->row_bytes ? (size_t)g->height * g->row_bytes : 16) != hipSuccess) return bail(RT_ERR_HIP, "hipMalloc(frame) failed");
-  } else g->d_frame = g->d_stacked;
-  if (hipEventCreate(&g->ev_assembled) != hipSuccess) return bail(RT_ERR_HIP, "hipEventCreate failed");
+  for (auto& f : g->frame) {
+    if (hipMalloc(&f.d_stacked, g->pad_bytes * G ? g->pad_bytes * G : 16) != hipSuccess) return bail(RT_ERR_HIP, "hipMalloc(gather buffer) failed");
+    f.d_tiles[0] = f.d_stacked;  // rank 0 renders into its own slice: the gather is in place on the root
+    if (g->gather) {
+      if (hipMalloc(&f.d_frame, (size_t)g->height * g->row_bytes ? (size_t)g->height * g->row_bytes : 16) != hipSuccess) return bail(RT_ERR_HIP, "hipMalloc(frame) failed");
+    } else f.d_frame = f.d_stacked;
+    if (hipEventCreate(&f.ev_assembled) != hipSuccess || hipEventCreateWithFlags(&f.ev_final, hipEventDisableTiming) != hipSuccess)
+      return bail(RT_ERR_HIP, "hipEventCreate failed");
+  }
+  g->last = &g->frame[0];
   if (g->rccl) {
     std::string why;
     if (!g->api.load(why)) return bail(RT_ERR_HIP, why);
@@ -253,7 +312,7 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
       if (g->device[r] != g->device[0]) { (void)hipSetDevice(g->device[r]); (void)hipDeviceEnablePeerAccess(g->device[0], 0); }
     (void)hipGetLastError();  // (already enabled / not supported: the copy is staged instead)
   }
-  for (uint32_t r = 0; r < G; ++r) g->worker.emplace_back(rtg::worker_main, g, r);
+  for (uint32_t r = 1; r < G; ++r) g->worker.emplace_back(rtg::worker_main, g, r);
   *out = g;
   return RT_OK;
 }
@@ -269,7 +328,12 @@ extern "C" int rt_hip_group_set_camera(RtHipGroup* g, const double origin[3], co
 }
 
 extern "C" int rt_hip_group_set_option(RtHipGroup* g, const char* key, int64_t value) {
-  if (!g) return fail(RT_ERR_INVALID, "null argument");
+  if (!g || !key) return fail(RT_ERR_INVALID, "null argument");
+  if (!std::strcmp(key, "spin_us")) {  // the group's own option: how long an idle rank thread polls before it sleeps
+    if (value < 0 || value > 1000000) return fail(RT_ERR_INVALID, "spin_us must be 0 .. 1000000");
+    g->spin_us.store((int)value, std::memory_order_relaxed);
+    return RT_OK;
+  }
   for (uint32_t r = 0; r < g->G; ++r) {
     const int rc = rt_hip_set_option(g->scene[r], key, value);
     if (rc != RT_OK) return rc;
@@ -298,88 +362,151 @@ extern "C" int rt_hip_group_info(const RtHipGroup* g, RtGroupInfo* info) {
 extern "C" const void* rt_hip_group_frame(const RtHipGroup* g, int* device_out) {
   if (!g) return nullptr;
   if (device_out) *device_out = g->device.empty() ? 0 : g->device[0];
-  return g->d_frame;
+  return g->last ? g->last->d_frame : nullptr;
 }
 
 namespace rtg {
-// One frame: G parallel launches, ONE gather, de-interleave; the frame is left in scanline order on the group's first
-// device (rt_hip_group_frame) and, when out_rgb8 is given, leaves in ONE device-to-host copy.  Blocking.
-int group_frame(RtHipGroup* g, uint8_t* out_rgb8, RtStats* stats) {
-  const auto t0 = std::chrono::steady_clock::now();
+// whatever failed, every stream is drained and every scene is released before the error is returned (a scene left "in
+// flight" would refuse the caller's next frame); frames in flight are dropped
+void drain(RtHipGroup* g) {
+  const std::string keep = g_err;
+  for (uint32_t q = 0; q < g->G; ++q) {
+    (void)hipSetDevice(g->device[q]);
+    (void)hipStreamSynchronize(g->stream[q]); (void)hipStreamSynchronize(g->xstream[q]);
+    g->scene[q]->in_flight = false;
+  }
+  (void)hipGetLastError();
+  for (auto& f : g->frame) f.busy = false;
+  g->n_collected = g->n_submitted;
+  g_err = keep;
+}
+
+// Enqueue one frame: G parallel launches, ONE gather, de-interleave, (optionally) ONE device-to-host copy.  Returns as
+// soon as everything is in the streams.  At most two frames may be in flight.
+int group_submit(RtHipGroup* g, uint8_t* out_rgb8) {
+  if (g->n_submitted - g->n_collected >= 2) return fail(RT_ERR_INVALID, "rt_hip_group_submit: two frames are in flight already (collect one first)");
   const uint32_t G = g->G;
-  {
-    std::lock_guard<std::mutex> lk(g->mu);
-    g->n_done = 0;
-    g->generation++;
+  const int b = (int)(g->n_submitted & 1);
+  RtHipGroup::Frame& f = g->frame[b];
+  f.t0 = std::chrono::steady_clock::now();
+  f.out = out_rgb8;
+  for (double& u : f.us) u = 0.0;
+  if (G > 1) {
+    {
+      std::lock_guard<std::mutex> lk(g->mu);
+      g->cur = b;
+      g->n_done.store(0, std::memory_order_release);
+      g->generation.fetch_add(1, std::memory_order_acq_rel);
+    }
+    g->cv_go.notify_all();
   }
-  g->cv_go.notify_all();
-  {
-    std::unique_lock<std::mutex> lk(g->mu);
-    g->cv_done.wait(lk, [&] { return g->n_done == G; });
+  enqueue_rank(g, f, 0);  // (this thread is awake: rank 0's launch goes out while the other ranks' threads wake up)
+  if (G > 1) {  // the other ranks finish within microseconds of this thread: poll briefly, then sleep
+    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+    while (g->n_done.load(std::memory_order_acquire) != G - 1 && std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
+    if (g->n_done.load(std::memory_order_acquire) != G - 1) {
+      std::unique_lock<std::mutex> lk(g->mu);
+      g->cv_done.wait(lk, [&] { return g->n_done.load(std::memory_order_acquire) == G - 1; });
+    }
   }
-  // whatever fails from here on, every stream is drained and every scene is released before the error is returned
-  // (a scene left "in flight" would refuse the caller's next frame)
-  auto drain = [&]() {
-    const std::string keep = g_err;
-    for (uint32_t q = 0; q < G; ++q) { (void)hipSetDevice(g->device[q]); (void)hipStreamSynchronize(g->stream[q]); g->scene[q]->in_flight = false; }
-    (void)hipGetLastError();
-    g_err = keep;
-  };
+  for (uint32_t r = 0; r < G; ++r) {
+    if (g->t_wake_us[r] > f.us[0]) f.us[0] = g->t_wake_us[r];
+    if (g->t_enq_us[r] > f.us[1]) f.us[1] = g->t_enq_us[r];
+  }
+  f.us[2] = us_since(f.t0);
   for (uint32_t r = 0; r < G; ++r)
     if (g->rc[r] != RT_OK) {
-      drain();
+      drain(g);
       return fail(g->rc[r], "rank " + std::to_string(r) + ": " + g->err[r]);
     }
-  RtStats total;
-  std::memset(&total, 0, sizeof total);
-  double frame_ms = 0.0;
   auto assemble = [&]() -> int {
     RT_HIP_TRY(hipSetDevice(g->device[0]));
-    hipStream_t s0 = g->stream[0];
+    hipStream_t x0 = g->xstream[0];
     if (g->gather) {
-      if (g->rccl) {  // ONE gather over xGMI: every rank's packed tiles -> rank 0's `stacked`, stream-ordered after its kernel
+      if (g->rccl) {  // ONE gather over xGMI: every rank's packed tiles -> rank 0's `stacked`, each rank's side behind its kernel's event
         ncclResult_t nr = g->api.GroupStart();
         for (uint32_t r = 0; r < G && nr == ncclSuccess; ++r)
-          nr = g->api.Gather(g->d_tiles[r], g->d_stacked, g->pad_bytes, ncclUint8, 0, g->comm[r], g->stream[r]);
+          nr = g->api.Gather(f.d_tiles[r], f.d_stacked, g->pad_bytes, ncclUint8, 0, g->comm[r], g->xstream[r]);
         const ncclResult_t ne = g->api.GroupEnd();
         if (nr == ncclSuccess) nr = ne;
         if (nr != ncclSuccess) return fail(RT_ERR_HIP, std::string("ncclGather: ") + g->api.GetErrorString(nr));
+        RT_HIP_TRY(hipSetDevice(g->device[0]));
       } else {
-        for (uint32_t r = 1; r < G; ++r) RT_HIP_TRY(hipStreamWaitEvent(s0, g->ev_done[r], 0));
+        for (uint32_t r = 1; r < G; ++r) RT_HIP_TRY(hipStreamWaitEvent(x0, f.ev_sent[r], 0));
       }
-      hipLaunchKernelGGL(rtg::deinterleave_rows, dim3(g->height), dim3(256), 0, s0, static_cast<const uint8_t*>(g->d_stacked),
-                         static_cast<uint8_t*>(g->d_frame), g->height, (uint32_t)g->row_bytes, G, RT_GROUP_TILE_ROWS, g->pad_rows);
+      f.us[3] = us_since(f.t0);
+      hipLaunchKernelGGL(rtg::deinterleave_rows, dim3(g->height), dim3(256), 0, x0, static_cast<const uint8_t*>(f.d_stacked),
+                         static_cast<uint8_t*>(f.d_frame), g->height, (uint32_t)g->row_bytes, G, RT_GROUP_TILE_ROWS, g->pad_rows);
       RT_HIP_TRY(hipGetLastError());
+    } else {
+      RT_HIP_TRY(hipStreamWaitEvent(x0, f.ev_done[0], 0));
+      f.us[3] = us_since(f.t0);
     }
-    RT_HIP_TRY(hipEventRecord(g->ev_assembled, s0));
-    if (out_rgb8) RT_HIP_TRY(hipMemcpyAsync(out_rgb8, g->d_frame, (size_t)g->height * g->row_bytes, hipMemcpyDeviceToHost, s0));
-    RT_HIP_TRY(hipStreamSynchronize(s0));
-    frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    for (uint32_t r = 0; r < G; ++r) {  // (also drains the other ranks' streams: with RCCL their gather kernels)
+    RT_HIP_TRY(hipEventRecord(f.ev_assembled, x0));
+    if (f.out) RT_HIP_TRY(hipMemcpyAsync(f.out, f.d_frame, (size_t)g->height * g->row_bytes, hipMemcpyDeviceToHost, x0));
+    RT_HIP_TRY(hipEventRecord(f.ev_final, x0));
+    return RT_OK;
+  };
+  const int rc = assemble();
+  if (rc != RT_OK) { drain(g); return rc; }
+  f.us[4] = us_since(f.t0);
+  f.busy = true;
+  g->n_submitted++;
+  return RT_OK;
+}
+
+// Wait for the OLDEST frame in flight; its stats.  The frame is then what rt_hip_group_frame points at.
+int group_collect(RtHipGroup* g, RtStats* stats) {
+  if (g->n_collected == g->n_submitted) return fail(RT_ERR_INVALID, "rt_hip_group_collect: no frame in flight");
+  const uint32_t G = g->G;
+  RtHipGroup::Frame& f = g->frame[g->n_collected & 1];
+  auto finish = [&]() -> int {
+    RT_HIP_TRY(hipSetDevice(g->device[0]));
+    RT_HIP_TRY(hipEventSynchronize(f.ev_assembled));
+    f.us[5] = us_since(f.t0);
+    RT_HIP_TRY(hipEventSynchronize(f.ev_final));
+    f.us[6] = us_since(f.t0);
+    const double frame_ms = f.us[6] * 1e-3;
+    RtStats total;
+    std::memset(&total, 0, sizeof total);
+    for (uint32_t r = 0; r < G; ++r) {  // (with RCCL the other ranks' sides of the gather are behind ev_copied of their launch only on the render stream: their transfer streams are drained by the root's receive)
       RtStats st;
-      const int rc = rt_hip_wait(g->scene[r], &st);
+      const int rc = wait_slot(g->scene[r], f.slot[r], &st);
       if (rc != RT_OK) return rc;
       total.samples += st.samples; total.segments += st.segments; total.sphere_tests += st.sphere_tests;
       total.exact_tests += st.exact_tests; total.tex_oob += st.tex_oob; total.grid_steps += st.grid_steps;
       for (int k = 0; k < 4; ++k) total.wave_iters[k] += st.wave_iters[k];
+      for (int k = 0; k < 12; ++k) total.prof_cycles[k] += st.prof_cycles[k];
       if (st.kernel_ms > total.kernel_ms) total.kernel_ms = st.kernel_ms;  // the slowest rank
     }
+    f.us[7] = us_since(f.t0);
     if (stats) {
       *stats = total;
       stats->n_gpus_used = G;
       stats->frame_ms = frame_ms;
-      if (g->gather && g->scene[0]->launched) {
+      const RtHipScene::Slot& s0 = g->scene[0]->slot[f.slot[0] & 1];
+      if (s0.launched) {
         RT_HIP_TRY(hipSetDevice(g->device[0]));
-        float ms = 0.f;
-        RT_HIP_TRY(hipEventElapsedTime(&ms, g->scene[0]->ev_stop, g->ev_assembled));
-        stats->gather_ms = ms;  // rank 0's kernel end -> frame in scanline order on device 0 (includes waiting for slower ranks)
+        float ms = 0.f;  // device 0's clock: rank 0's kernel start -> frame in scanline order; minus the slowest rank's kernel =
+        RT_HIP_TRY(hipEventElapsedTime(&ms, s0.ev_start, f.ev_assembled));  // what the frame spent NOT rendering (start skew, gather, de-interleave)
+        stats->gather_ms = (double)ms > total.kernel_ms ? (double)ms - total.kernel_ms : 0.0;
       }
+      for (int k = 0; k < 8; ++k) stats->group_us[k] = f.us[k];
     }
     return RT_OK;
   };
-  const int rc = assemble();
-  if (rc != RT_OK) drain();
-  return rc;
+  const int rc = finish();
+  if (rc != RT_OK) { drain(g); return rc; }
+  f.busy = false;
+  g->last = &f;
+  g->n_collected++;
+  return RT_OK;
+}
+
+int group_frame(RtHipGroup* g, uint8_t* out_rgb8, RtStats* stats) {  // blocking: one frame, nothing else in flight
+  while (g->n_collected != g->n_submitted) { const int rc = group_collect(g, nullptr); if (rc != RT_OK) return rc; }
+  const int rc = group_submit(g, out_rgb8);
+  return rc != RT_OK ? rc : group_collect(g, stats);
 }
 }  // namespace rtg
 
@@ -391,7 +518,14 @@ extern "C" int rt_hip_group_render(RtHipGroup* g, RtStats* stats) {
   if (!g) return fail(RT_ERR_INVALID, "null argument");
   return rtg::group_frame(g, nullptr, stats);
 }
-
+extern "C" int rt_hip_group_submit(RtHipGroup* g, uint8_t* out_rgb8) {
+  if (!g) return fail(RT_ERR_INVALID, "null argument");
+  return rtg::group_submit(g, out_rgb8);
+}
+extern "C" int rt_hip_group_collect(RtHipGroup* g, RtStats* stats) {
+  if (!g) return fail(RT_ERR_INVALID, "null argument");
+  return rtg::group_collect(g, stats);
+}
 // drop-in for the parallel loop of render() (raytracer.rs:254-263): host scene in, host RGB8 out
 extern "C" int rt_render_rgb8(const RtScene* scene, uint8_t* out_rgb8, RtStats* stats) {
   if (!scene || !out_rgb8) return fail(RT_ERR_INVALID, "null argument");
@@ -400,8 +534,8 @@ extern "C" int rt_render_rgb8(const RtScene* scene, uint8_t* out_rgb8, RtStats* 
   int rc = rt_hip_group_create(scene, 0, &g);
   if (rc != RT_OK) return rc;
   // one frame per scene: no later frame could use a queue order learned from this one (tile_order 2 would measure
-  // the tile depths and run rt_order_tiles inside frame_ms for nothing) — bottom row first
-  (void)rt_hip_group_set_option(g, "tile_order", 1);
+  // the tile depths and run rt_order_tiles once more inside frame_ms for nothing) — the seeded order alone
+  (void)rt_hip_group_set_option(g, "tile_order", 3);
   const double setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   RtStats st;
   rc = rt_hip_group_render_to_host(g, out_rgb8, &st);

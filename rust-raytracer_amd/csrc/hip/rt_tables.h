@@ -20,6 +20,10 @@ struct HostTables {
   std::vector<uint32_t> lights;
   std::vector<uint64_t> tex_off;  // per RtTexture, byte offset in the blob
   uint64_t tex_bytes = 0;
+  // the 4-byte-texel copies the device reads (build_texels): every texture whose records are in texels_fast()'s range, and the sky
+  std::vector<uint32_t> tex4, sky4;
+  bool need_rgb8 = false;            // some Texture sphere takes the general path: the RGB8 blob must be resident too
+  bool sky_fast = false;
   uint32_t n_pairs = 0;           // real pairs (cull.size() includes chunk padding)
   bool simple_colour = true;  // every albedo in [0,1] (textures always are): the short colour maps of rt_core.h apply
   // hit_world acceleration (GridDesc, rt_core.h)
@@ -130,7 +134,6 @@ inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
     const double w = ext[k] / ((double)G.n[k] - 2.0 * edge);  // cell width such that the spheres span [edge, n - edge] cells
     G.gmin[k] = lo[k] - edge * w;
     G.inv_cell[k] = 1.0 / w;
-    G.goff[k] = -G.gmin[k] * G.inv_cell[k];
     G.nd[k] = (double)G.n[k];
   }
   G.pull = (float)(8.0 * grid_walk_eps(std::max(G.n[0], std::max(G.n[1], G.n[2]))));
@@ -240,6 +243,7 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
   t.n_pairs = n_pairs;
   t.lights.clear();
   t.simple_colour = true;
+  t.need_rgb8 = false;
   for (uint32_t i = 0; i < n; ++i) {
     const RtSphere& s = sc.spheres[i];
     if (s.kind > RT_MAT_LIGHT) return "bad material kind";
@@ -253,6 +257,12 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
       if (s.tex_id >= sc.n_textures) return "texture id out of range";
       m.tex_off = t.tex_off[s.tex_id];
       m.tex_nbytes = sc.textures[s.tex_id].nbytes;
+      // 4-byte texels: texture k starts at the texel count of textures 0..k-1 (build_texels lays them out the same way)
+      uint64_t before = 0;
+      for (uint32_t k = 0; k < s.tex_id; ++k) before += sc.textures[k].nbytes / 3;
+      if (texels_fast(s.tex_w, s.tex_h, s.h_offset, m.tex_nbytes, before)) {
+        m.tex_fast = 1u; m.texel_off = (uint32_t)before; m.texel_last = (uint32_t)(m.tex_nbytes / 3 - 1);
+      } else t.need_rgb8 = true;
     }
     t.mat[i] = m;
     MatCore mc;
@@ -296,6 +306,28 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
   return "";
 }
 
+// The textures and the sky as the device reads them: R | G << 8 | B << 16 per texel, textures back to back in table order
+// (texture k's first texel = the texel count of textures 0..k-1, as build_tables wrote into SphereMat::texel_off).  The
+// C ABI takes the caller's RGB8 (materials.rs:213-219, config.rs:36-47); this is a device-resident re-layout of the same
+// values.  Only as many textures as fit 2^31 texels are expanded (the records beyond take the RGB8 path).
+inline void build_texels(const RtScene& sc, HostTables& t) {
+  auto expand = [](const uint8_t* p, uint64_t n_px, std::vector<uint32_t>& out) {
+    const size_t at = out.size();
+    out.resize(at + n_px);
+    for (uint64_t i = 0; i < n_px; ++i) out[at + i] = (uint32_t)p[3 * i] | ((uint32_t)p[3 * i + 1] << 8) | ((uint32_t)p[3 * i + 2] << 16);
+  };
+  t.tex4.clear(); t.sky4.clear();
+  uint64_t before = 0;
+  for (uint32_t k = 0; k < sc.n_textures; ++k) {
+    const uint64_t n_px = sc.textures[k].nbytes / 3;
+    if (before + n_px >= (1ull << 31)) break;
+    expand(sc.textures[k].rgb8, n_px, t.tex4);
+    before += n_px;
+  }
+  t.sky_fast = sc.sky_mode == RT_SKY_TEXTURE && sc.sky_w <= (1ull << 24) && sc.sky_h <= (1ull << 24) && sc.sky_w * sc.sky_h < (1ull << 31);
+  if (t.sky_fast) expand(sc.sky_rgb8, sc.sky_w * sc.sky_h, t.sky4);
+}
+
 inline void fill_dev_scene(const RtScene& sc, const HostTables& t, DevScene& d) {
   std::memset(&d, 0, sizeof d);
   d.width = sc.width; d.height = sc.height; d.spp = sc.samples_per_pixel; d.max_depth = sc.max_depth;
@@ -307,6 +339,8 @@ inline void fill_dev_scene(const RtScene& sc, const HostTables& t, DevScene& d) 
     d.cam_h[i] = sc.cam_horizontal[i]; d.cam_v[i] = sc.cam_vertical[i];
   }
   d.sky_w = sc.sky_w; d.sky_h = sc.sky_h;
+  d.sky_wm1_f = (float)(sc.sky_w - 1); d.sky_hm1_f = (float)(sc.sky_h - 1);
+  d.sky_fast = t.sky_fast ? 1u : 0u;  // (build_texels must have run: callers set sky4 / tex4 next to it)
   d.wm1 = (double)sc.width - 1.0; d.hm1 = (double)sc.height - 1.0; d.height_d = (double)sc.height;
   d.inv_wm1 = sc.width > 1 ? 1.0 / d.wm1 : 0.0; d.inv_hm1 = sc.height > 1 ? 1.0 / d.hm1 : 0.0;
   d.grid = t.grid;

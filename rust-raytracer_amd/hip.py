@@ -51,6 +51,8 @@ def lib():
         L.rt_hip_group_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.rt_hip_group_render_to_host.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.RtStats)]
         L.rt_hip_group_render.argtypes = [C.c_void_p, C.POINTER(abi.RtStats)]
+        L.rt_hip_group_submit.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_hip_group_collect.argtypes = [C.c_void_p, C.POINTER(abi.RtStats)]
         L.rt_hip_group_info.argtypes = [C.c_void_p, C.POINTER(abi.RtGroupInfo)]
         L.rt_hip_group_frame.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.rt_hip_group_frame.restype = C.c_void_p
@@ -167,8 +169,19 @@ class HipGroup:
         _check(lib().rt_hip_group_render(self._h, C.byref(st)))
         return st.as_dict()
 
+    def submit(self, out=None):
+        """enqueue one frame (rt_hip_group_submit); `out`: a numpy uint8 [h,w,3] array the frame is copied into (it must stay
+        alive until the frame is collected), or None to leave it in HBM.  Two frames may be in flight."""
+        _check(lib().rt_hip_group_submit(self._h, out.ctypes.data if out is not None else None))
+
+    def collect(self):
+        """wait for the oldest submitted frame (rt_hip_group_collect); returns its stats"""
+        st = abi.RtStats()
+        _check(lib().rt_hip_group_collect(self._h, C.byref(st)))
+        return st.as_dict()
+
     def frame_ptr(self):
-        """(device pointer of the assembled RGB8 frame, device ordinal)"""
+        """(device pointer of the assembled RGB8 frame collected last, device ordinal)"""
         dev = C.c_int(0)
         return lib().rt_hip_group_frame(self._h, C.byref(dev)), dev.value
 

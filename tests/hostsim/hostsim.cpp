@@ -138,8 +138,10 @@ extern "C" int hostsim_render(const RtScene* scene, const RtRowTiles* tiles, uin
                               RtStats* stats, int use_cull) {
   HostTables t;
   if (!scene || !build_tables(*scene, t).empty()) return RT_ERR_INVALID;
+  build_texels(*scene, t);  // (the 4-byte-texel path the device takes; the RGB8 blob serves the records outside its range)
   DevScene ds;
   fill_dev_scene(*scene, t, ds);
+  ds.tex4 = t.tex4.data(); ds.sky4 = t.sky4.data();
   std::vector<uint8_t> blob(t.tex_bytes ? t.tex_bytes : 1);
   for (uint32_t i = 0; i < scene->n_textures; ++i)
     if (scene->textures[i].nbytes) std::memcpy(&blob[t.tex_off[i]], scene->textures[i].rgb8, scene->textures[i].nbytes);

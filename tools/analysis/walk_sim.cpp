@@ -221,7 +221,9 @@ int main(int argc, char** argv) {
   if (cps > 0.0) { char b[64]; snprintf(b, sizeof b, "%g", cps); setenv("RT_GRID_CELLS_PER_SPHERE", b, 1); }
   const std::string why = build_tables(sc, t);
   if (!why.empty()) { std::fprintf(stderr, "%s\n", why.c_str()); return 1; }
+  build_texels(sc, t);
   DevScene ds; fill_dev_scene(sc, t, ds);
+  ds.tex4 = t.tex4.data(); ds.sky4 = t.sky4.data();
   ds.geom = t.geom.data(); ds.mat = t.mat.data(); ds.cull = t.cull.data(); ds.lights = t.lights.data(); ds.sky = sc.sky_rgb8;
   ds.matc = t.matc.data(); ds.cell_word = t.cell_word.data(); ds.cell_items = t.cell_items.data(); ds.large = t.large.data(); ds.large_geom = t.large_geom.data();
   std::vector<uint8_t> blob(t.tex_bytes ? t.tex_bytes : 1);

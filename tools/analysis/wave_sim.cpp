@@ -18,7 +18,9 @@ int main(int argc, char** argv) {
   scp->width = atoi(argv[2]); scp->height = atoi(argv[3]); scp->samples_per_pixel = atoi(argv[4]);
   const RtScene& sc = *scp;
   HostTables t; build_tables(sc, t);
+  build_texels(sc, t);
   DevScene ds; fill_dev_scene(sc, t, ds);
+  ds.tex4 = t.tex4.data(); ds.sky4 = t.sky4.data();
   ds.geom = t.geom.data(); ds.mat = t.mat.data(); ds.cull = t.cull.data(); ds.lights = t.lights.data(); ds.sky = sc.sky_rgb8;
   std::vector<uint8_t> blob(t.tex_bytes ? t.tex_bytes : 1);
   for (uint32_t i = 0; i < sc.n_textures; ++i) std::memcpy(&blob[t.tex_off[i]], sc.textures[i].rgb8, sc.textures[i].nbytes);
