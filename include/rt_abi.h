@@ -261,6 +261,9 @@ int rt_hip_debug_timeline(RtHipScene*, uint64_t* out, uint32_t max_waves);
 int rt_hip_math_probe(const double* x, const double* y, double* out_sqrt, double* out_div, float* out_sqrtf, double* out_atan2,
                       uint32_t n, void* stream);
 int rt_hip_hit_probe(const double* rays, const double* spheres, double* out_t, uint32_t n, void* stream);
+/* f64::atan2 (sphere.rs:39) of n (y, x) pairs through the device build of the routine kernel and CPU checker share
+ * (csrc/common/rt_atan2.h): tests compare it with a committed fixture of correctly rounded results. */
+int rt_hip_atan2_probe(const double* d_y, const double* d_x, double* d_out, uint32_t n, void* stream);
 /* The texel of a Texture hit on the device, both ways (materials.rs:236-254 through sphere.rs:35-43): the kernel's fast
  * (u, v) — v_rsq_f64 / v_rcp_f64 + Newton steps, which only the device build takes — beside the exact path, for n hit
  * points (device, 3 doubles each) on the sphere centre_radius (host, 4 doubles).  d_out = n x {fast_ok, fast col, fast

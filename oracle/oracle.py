@@ -57,6 +57,8 @@ def lib(abi):
         L.rt_oracle_p3_op.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]
         L.rt_oracle_ray_at.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]
         L.rt_oracle_ray_at.restype = None
+        L.rt_oracle_atan2_v.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.rt_oracle_atan2_v.restype = None
         L.rt_oracle_atan2.argtypes = [C.c_double, C.c_double]
         L.rt_oracle_atan2.restype = C.c_double
         _LIB = L

@@ -183,6 +183,9 @@ int rt_oracle_sphere_hit(const double center[3], double radius, const double ori
 }
 
 double rt_oracle_atan2(double y, double x) { return rt_atan2(y, x); }
+void rt_oracle_atan2_v(const double* y, const double* x, double* out, uint64_t n) {
+  for (uint64_t i = 0; i < n; ++i) out[i] = rt_atan2(y[i], x[i]);
+}
 
 /* hooks for the reference's vector / ray unit tests (point3d.rs:197-272, ray.rs:38-63) */
 int rt_oracle_p3_op(int op, const double a[3], const double b[3], double s, double out[3]) {

@@ -50,6 +50,7 @@ int rt_oracle_sphere_hit(const double center[3], double radius, const double ori
                          const double dir[3], double t_min, double t_max, double out[10]);
 /* f64::atan2 of sphere.rs:39 as both sides evaluate it (rust-raytracer_amd/csrc/common/rt_atan2.h) */
 double rt_oracle_atan2(double y, double x);
+void rt_oracle_atan2_v(const double* y, const double* x, double* out, uint64_t n); /* ... of n pairs */
 /* point3d.rs:52-177 one operation at a time: op 0 add, 1 sub, 2 neg, 3 mul (componentwise), 4 div (componentwise),
  * 5 mul by s, 6 div by s, 7 dot -> out[0], 8 length_squared -> out[0], 9 near_zero -> out[0], 10 length -> out[0],
  * 11 unit_vector, 12 cross; returns -1 for an unknown op */

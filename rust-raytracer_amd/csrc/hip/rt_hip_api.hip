@@ -731,6 +731,13 @@ extern "C" int rt_hip_math_probe(const double* x, const double* y, double* out_s
   return RT_OK;
 }
 
+extern "C" int rt_hip_atan2_probe(const double* d_y, const double* d_x, double* d_out, uint32_t n, void* stream) {
+  if (!d_y || !d_x || !d_out) return fail(RT_ERR_INVALID, "null argument");
+  hipLaunchKernelGGL(rtk::rt_atan2_probe, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_y, d_x, d_out, n);
+  RT_HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
 // device probe of the Texture hit's fast texel path beside the exact one (see rtk::rt_texel_probe); d_* are DEVICE pointers
 extern "C" int rt_hip_texel_probe(const double* d_points, const double centre_radius[4], double h_offset, uint64_t tex_w, uint64_t tex_h,
                                   uint64_t* d_out, double* d_uv, uint32_t n, void* stream) {

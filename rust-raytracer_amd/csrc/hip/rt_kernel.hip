@@ -1097,6 +1097,12 @@ __global__ void rt_math_probe(const double* x, const double* y, double* out_sqrt
   out_atan2[i] = rt_atan2(x[i] - 0.5, y[i] - 0.5);  // the shared routine (csrc/common/rt_atan2.h): must equal its CPU build bit for bit
 }
 
+// the shared atan2 (csrc/common/rt_atan2.h) of n (y, x) pairs as the device evaluates it
+__global__ void rt_atan2_probe(const double* y, const double* x, double* out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = rt_atan2(y[i], x[i]);
+}
+
 // Sphere::hit on the device, one (ray, sphere) pair per thread, through the kernel's own hit test
 // (closest-so-far = f64::MAX): out_t = accepted root or -1.  tests/test_gpu_parity.py compares it
 // with the CPU build of the same function on random, tangent (discriminant 0 / denormal-range) and

@@ -39,6 +39,7 @@ def lib():
         L.rt_hip_render_to_host.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.RtStats)]
         L.rt_hip_math_probe.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_void_p]
         L.rt_hip_hit_probe.argtypes = [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p]
+        L.rt_hip_atan2_probe.argtypes = [C.c_void_p] * 3 + [C.c_uint32, C.c_void_p]
         L.rt_abi_sizeof.argtypes = [C.c_char_p]
         L.rt_abi_sizeof.restype = C.c_size_t
         L.rt_abi_version.restype = C.c_uint32

@@ -483,3 +483,45 @@ def test_more_than_65535_spheres_fall_back_to_the_full_scan(hostsim, oracle, abi
     rgb, lin, st = hostsim.render(sc.ptr, None, 3)
     assert_parity(rgb, lin, o_rgb, o_lin, "66001 spheres")
     assert st["segments"] == o_st["segments"] and st["exact_tests"] == st["sphere_tests"]
+
+
+TEXEL_RECORDS = [
+    ("as shipped", {}),
+    ("JSON width smaller than the decoded one", {"tex_w": 777}),
+    ("JSON height larger than the decoded one: indices past the end are clamped and counted", {"tex_h": 5000}),
+    ("negative offset: columns saturate at 0", {"h_offset": -0.3}),
+    ("offset 3: columns beyond the row (texels of later rows; past the end only in the last rows)", {"h_offset": 3.0}),
+    ("offset beyond the 4-byte-texel path's range: the u64 arithmetic on the RGB8 bytes", {"h_offset": 1500.0}),
+    ("width beyond the 4-byte-texel path's range", {"tex_w": 1 << 25}),
+    ("a one-pixel texture", {"tex_w": 1, "tex_h": 1}),
+]
+
+
+def texel_record_scene(load_scene, abi, changes, w=56, h=42, spp=2):
+    """the reference's test scene (two Texture spheres, a sky texture) with the Texture records changed as given"""
+    sc = load_scene("test", w, h, spp, 8)
+    n_tex = 0
+    for i in range(sc.c.n_spheres):
+        s = sc.c.spheres[i]
+        if s.kind == abi.RT_MAT_TEXTURE:
+            n_tex += 1
+            for k, v in changes.items():
+                setattr(s, k, v)
+    assert n_tex >= 1
+    return sc
+
+
+@pytest.mark.parametrize("what,changes", TEXEL_RECORDS, ids=[t[0].split(":")[0] for t in TEXEL_RECORDS])
+def test_texel_paths_agree_with_the_oracle(what, changes, hostsim, oracle, abi, load_scene):
+    """The device reads textures and sky as 4-byte texels with 32-bit index arithmetic (rt_core.h texels_fast /
+    texture_albedo, sky_color) where the reference indexes RGB8 bytes in u64 (materials.rs:236-254, raytracer.rs:149-160);
+    records outside that path's range keep the u64 form.  Both against the oracle's literal arithmetic, with Texture
+    records that clamp, saturate and overflow the row: same pixels, same count of out-of-range fetches."""
+    sc = texel_record_scene(load_scene, abi, changes)
+    o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+    rgb, lin, st = hostsim.render(sc.ptr, None, 3)
+    assert_parity(rgb, lin, o_rgb, o_lin, what)
+    assert st["tex_oob"] == o_st["tex_oob"], what
+    assert st["segments"] == o_st["segments"] - o_st["segments_discarded"]
+    if changes.get("tex_h") == 5000:
+        assert st["tex_oob"] > 0

@@ -612,7 +612,7 @@ def test_group_in_library_sharding_is_bit_identical(pkg, gpu_render, load_scene,
         grp.close()
 
 
-def test_full_size_cfg4_through_the_8_rank_group(pkg, gpu_render, load_scene):
+def test_full_size_cfg4_through_the_8_rank_group(pkg, gpu_render, oracle, abi, load_scene):
     """BASELINE configs[3] at FULL size (3840x2160, spp 512, textured): the in-library group with 8 ranks (sharing this
     box's GPU) against the single launch — byte-identical frame, same path count; two frames (the second with the queue
     order learnt from the first)."""
@@ -626,6 +626,13 @@ def test_full_size_cfg4_through_the_8_rank_group(pkg, gpu_render, load_scene):
         assert gst["n_gpus_used"] == 8 and gst["samples"] == st["samples"] == 3840 * 2160 * 512 and gst["segments"] == st["segments"]
     print(f"cfg4 full size: single launch {st['kernel_ms']:.1f} ms; 8 emulated ranks on one GPU: slowest rank {gst['kernel_ms']:.1f} ms, frame {gst['frame_ms']:.1f} ms")
     grp.close()
+    # ... and that frame against the ORACLE at the full 512 spp: four whole 4K scanlines (sky, the textured spheres incl.
+    # the seam of the u wrap, the small spheres, the ground) — rows of ranks 6, 5, 4 and 7 of the 2-row interleave
+    _, lin, _ = gpu_render(sc)
+    rows = (300, 1002, 1320, 2159)
+    assert sorted({(y // 2) % 8 for y in rows}) == [4, 5, 6, 7]
+    worst = _check_rows_against_oracle(out, lin, oracle, abi, sc, rows, 512, "cfg4")
+    print(f"cfg4 full size: {len(rows)} scanlines x 3840 px x 512 spp of the 8-rank frame vs oracle, max |dlin| {worst:.2e}")
 
 
 def test_group_gather_through_rccl_one_rank(pkg, gpu_render, load_scene):
@@ -1055,3 +1062,88 @@ def test_scene_may_change_streams_once_the_first_stream_is_drained(pkg, load_sce
     gs.wait()
     assert np.array_equal(a.cpu().numpy(), first) and first.any()
     gs.close()
+
+
+@pytest.mark.parametrize("world,env", [(1, {}), (1, {"RT_GATHER_SELFTEST": "1", "RT_GATHER": "rccl"}), (3, {"RT_GPUS_EMULATE": "1"}), (8, {"RT_GPUS_EMULATE": "1"})])
+def test_group_submit_collect_pipelines_frames_bit_identically(pkg, gpu_render, load_scene, world, env):
+    """rt_hip_group_submit / _collect (ABI v4): two frames in flight — frame i's gather, de-interleave and device-to-host
+    copy under frame i+1's kernels, every buffer twice — deliver the bytes and the path counts of blocking frames with the
+    same settings, in submission order, each into the buffer it was submitted with; a third submit and a collect with
+    nothing in flight are refused; the stage clocks of a frame are ordered."""
+    sc = load_scene("test", 72, 50, 3, 8)
+    want = {}
+    for seed in (0, 1, 2, 3, 4):
+        sc.c.seed = seed
+        rgb, _, st = gpu_render(sc, want_linear=False)
+        want[seed] = (rgb, st["segments"])
+    sc.c.seed = 0
+    grp = _with_env(env, lambda: pkg.hip.HipGroup(sc.ptr, world))
+    with pytest.raises(pkg.host.RtError) as e:
+        grp.collect()
+    assert e.value.code == pkg.abi.RT_ERR_INVALID
+    bufs = [np.zeros((50, 72, 3), np.uint8) for _ in range(5)]
+    grp.set_option("seed", 0)
+    grp.submit(bufs[0])
+    for seed in (1, 2, 3, 4):
+        grp.set_option("seed", seed)          # (a frame is rendered with the options in force when it is submitted)
+        grp.submit(bufs[seed])
+        if seed == 1:
+            with pytest.raises(pkg.host.RtError) as e:
+                grp.submit(None)
+            assert e.value.code == pkg.abi.RT_ERR_INVALID
+        st = grp.collect()                    # the OLDEST frame: seed - 1
+        assert np.array_equal(bufs[seed - 1], want[seed - 1][0]), (world, seed - 1)
+        assert st["segments"] == want[seed - 1][1] and st["n_gpus_used"] == world and st["kernel_ms"] > 0
+        us = st["group_us"]
+        assert 0 <= us[0] <= us[1] <= us[2] <= us[3] <= us[4] <= us[5] <= us[6] <= us[7], us
+        assert abs(st["frame_ms"] * 1e3 - us[6]) < 1.0
+    st = grp.collect()
+    assert np.array_equal(bufs[4], want[4][0]) and st["segments"] == want[4][1]
+    # blocking calls still work, also with a frame left in flight (it is collected first)
+    grp.set_option("seed", 2)
+    grp.submit(None)
+    out, st = grp.render_to_host()
+    assert np.array_equal(out, want[2][0]) and st["segments"] == want[2][1]
+    grp.close()
+
+
+def test_seeded_first_frame_order_is_only_an_order(gpu_render, abi, load_scene):
+    """A frame without a measured queue order sorts its tiles by a seed (rt_hip_api.hip: projection of the spheres, or a
+    probe launch) — the bytes, the linear image and the path count never depend on it: whole frames and shards, lit and
+    unlit, against the fixed bottom-row-first order."""
+    for scene, w, h, spp, depth in (("cover", 200, 120, 4, 50), ("test", 96, 72, 3, 8)):
+        sc = load_scene(scene, w, h, spp, depth)
+        for tiles in (None, abi.RtRowTiles(2, 1, 3)):
+            ref = gpu_render(sc, tiles=tiles, tile_order=1)
+            for opts in ({"tile_order": 3, "order_seed": 1}, {"tile_order": 3, "order_seed": 2}, {"tile_order": 2, "order_seed": 1},
+                         {"tile_order": 2, "order_seed": 2}, {"tile_order": 2, "order_seed": 0}, {"tile_order": 3, "order_seed": 1, "tile_affinity": 2}):
+                got = gpu_render(sc, tiles=tiles, opts=opts, frames=2)
+                assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), (scene, opts)
+                assert got[2]["segments"] == ref[2]["segments"] and got[2]["samples"] == ref[2]["samples"]
+
+
+def test_texel_paths_on_the_gpu(gpu_render, oracle, abi, load_scene):
+    """tests/test_core_cpu.py::test_texel_paths_agree_with_the_oracle on the device: 4-byte texels + 32-bit index
+    arithmetic, and the u64 / RGB8 path for records outside its range, against the oracle's literal arithmetic"""
+    from test_core_cpu import TEXEL_RECORDS, texel_record_scene
+    for what, changes in TEXEL_RECORDS:
+        sc = texel_record_scene(load_scene, abi, changes, 96, 72, 3)
+        o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+        rgb, lin, st = gpu_render(sc)
+        assert_parity(rgb, lin, o_rgb, o_lin, what, atol=pooled_atol(3))
+        assert st["tex_oob"] == o_st["tex_oob"], what
+        assert st["segments"] == o_st["segments"] - o_st["segments_discarded"], what
+
+
+def test_device_atan2_against_a_million_correctly_rounded_results(pkg, torch_cuda):
+    """tests/test_oracle_kat.py::test_shared_atan2_against_a_million_correctly_rounded_results through the DEVICE build of
+    rt_atan2.h (rt_hip_atan2_probe): the same 1.1 M pairs, every result the correctly rounded one of the mpmath fixture."""
+    from atan2_points import points
+    from test_oracle_kat import check_atan2_against_the_fixture
+    torch = torch_cuda
+    y, x, _ = points()
+    dy, dx = torch.from_numpy(y).cuda(), torch.from_numpy(x).cuda()
+    out = torch.empty_like(dy)
+    assert pkg.hip.lib().rt_hip_atan2_probe(dy.data_ptr(), dx.data_ptr(), out.data_ptr(), y.size, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    check_atan2_against_the_fixture(out.cpu().numpy(), y, x)

@@ -3,6 +3,7 @@
 /root/reference/raytracer/src/).  The oracle is test infrastructure; see oracle/rt_oracle.h."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -232,3 +233,33 @@ def test_texture_albedo(oracle, abi, host):
         x, y = int(math.floor(rot * 2048)), int(math.floor((1.0 - v) * 1023))
         want = px[y, x].astype(np.float32) / np.float32(255.0)
         assert list(out) == list(want)
+
+
+def check_atan2_against_the_fixture(got, y, x):
+    """got = the routine's results for tests/atan2_points.py's pairs: equal to the correctly rounded values whose low bytes
+    tests/golden/atan2_cr_low8.npz holds (mpmath, 200 bits).  A result that is within a few ulps of the platform's atan2
+    AND has the correctly rounded value's low byte IS that value (two doubles fewer than 128 ulps apart with equal low
+    bytes are equal)."""
+    import hashlib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "atan2_cr_low8.npz"))
+    assert hashlib.sha256(y.tobytes() + x.tobytes()).hexdigest() == str(g["args_sha256"]), "atan2_points.py no longer generates the fixture's arguments"
+    low = g["low8"]
+    assert low.size == y.size >= 1_000_000
+    lm = np.arctan2(y, x)
+    ulp = np.abs(got.view(np.int64) - lm.view(np.int64))
+    assert int(ulp.max()) <= 4, int(ulp.max())                       # (glibc itself is off by an ulp now and then)
+    bad = np.flatnonzero((got.view(np.uint64) & np.uint64(0xFF)).astype(np.uint8) != low)
+    assert bad.size == 0, (bad.size, [(y[i], x[i], got[i]) for i in bad[:5]])
+    return int((got != lm).sum())
+
+
+def test_shared_atan2_against_a_million_correctly_rounded_results(oracle, abi):
+    """Oracle and kernel share rt_atan2.h, so a common-mode error in it is invisible to every parity test: the independent
+    pin is mpmath.  1.1 M argument pairs — unit-vector components like sphere_uv's, the reduction's knots k/32 and the
+    halfway points where k changes (|z| = 1/64), octant seams, tiny ratios at both ends — every one correctly rounded."""
+    from atan2_points import points
+    y, x, names = points()
+    got = np.empty_like(y)
+    oracle.lib(abi).rt_oracle_atan2_v(y.ctypes.data, x.ctypes.data, got.ctypes.data, y.size)
+    differs = check_atan2_against_the_fixture(got, y, x)
+    assert differs <= 0.1 * y.size   # (numpy's vectorised arctan2 — not glibc's — is off by an ulp for ~6 % of these arguments; never more than a few)
