@@ -15,8 +15,10 @@ speed-up of this frame at 8 GPUs).
 Two hosts for N > 1, the line's config.parallelism says which ran:
   * `python bench.py --gpus N` (no torchrun): ONE process drives the PRODUCT path — the in-library group
     (rt_hip_group_*: host thread + stream per device, ncclCommInitAll, one ncclGather per frame, de-interleave
-    kernel), K blocking frames, each complete in HBM of the first device before the next starts; `value` from
-    wall time.  RT_GPUS_EMULATE=1 lets the ranks share devices (a 1-GPU box can run the whole path).
+    kernel), K frames pipelined two deep (rt_hip_group_submit / _collect: frame i's gather under frame i+1's kernels), each
+    assembled in HBM of the first device; `value` from wall time.  Then blocking frames one at a time: `frame_latency_ms`,
+    its non-kernel part and the host-clock stage table (`frame_latency_stages_us`).  RT_GPUS_EMULATE=1 lets the ranks share
+    devices (a 1-GPU box can run the whole path).
   * under torch.distributed.run (WORLD_SIZE set): one process per GPU, the same shards gathered by
     torch.distributed (RCCL), described next.
 Any failure prints ONE JSON line with an "error" key and exits non-zero — never a bare traceback.
@@ -170,7 +172,7 @@ def main():
 
 
 def run_group(args):
-    """--gpus N without torchrun: the in-library group (rt_hip_group_*), one process, blocking frames."""
+    """--gpus N without torchrun: the in-library group (rt_hip_group_*), one process: pipelined frames, then blocking ones."""
     import numpy as np
     import torch
 
@@ -216,13 +218,26 @@ def run_group(args):
     for _ in range(max(args.warmup, 2)):      # (two frames build the queue order, like the N = 1 path's warm-up)
         grp.render()
     sync_all()
-    lat, kern, gath = [], [], []
+    # ---- timed region: K frames PIPELINED two deep (rt_hip_group_submit / _collect): frame i's gather + de-interleave run
+    # under frame i+1's kernels; every frame ends assembled in HBM of the first device.  `value` is this throughput.
+    kern, gath = [], []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st = grp.render()                     # blocking: G launches -> ONE gather -> de-interleave; frame in HBM of the first device
-        lat.append(st["frame_ms"]); kern.append(st["kernel_ms"]); gath.append(st["gather_ms"])
+    grp.submit()
+    for _ in range(args.steps - 1):
+        grp.submit()
+        st = grp.collect()
+        kern.append(st["kernel_ms"]); gath.append(st["gather_ms"])
+    st = grp.collect()
+    kern.append(st["kernel_ms"]); gath.append(st["gather_ms"])
     sync_all()
     elapsed = time.perf_counter() - t0
+    # ---- ONE frame at a time, nothing overlapped (the north star's case: G launches -> ONE gather -> de-interleave -> frame
+    # on the first device): latency, and where its non-kernel time goes (RtStats.group_us: host clock since submit)
+    lat, lkern, lgath, stages = [], [], [], []
+    for _ in range(max(5, min(args.steps, 20))):
+        st = grp.render()
+        lat.append(st["frame_ms"]); lkern.append(st["kernel_ms"]); lgath.append(st["gather_ms"]); stages.append(st["group_us"])
+    sync_all()
     # the assembled frame against ONE launch of the whole frame on the first device (same process): must be byte-identical
     frame, _ = grp.render_to_host()
     one = hip.HipScene(sc.ptr, devs[0])
@@ -250,14 +265,21 @@ def run_group(args):
         "config": {"workload": f"{os.path.basename(args.scene)}: {W}x{H} spp {SPP} depth {sc.c.max_depth}, {N_SPH} spheres"
                                + (" (BASELINE configs[1])" if headline else " (NON-HEADLINE run)"),
                    "parallelism": f"single process, in-library group (rt_hip_group_*): {info['n_ranks']} ranks x interleaved {info['tile_rows']}-scanline tiles, "
-                                  f"one host thread + stream per rank, ONE {info['transport']} gather per frame, blocking frames (no overlap)"
+                                  f"one host thread + render stream + transfer stream per rank, ONE {info['transport']} gather per frame, frames pipelined two deep "
+                                  f"(rt_hip_group_submit / _collect; frame_latency_ms = one blocking frame)"
                                   + (" — RANKS SHARE DEVICES (RT_GPUS_EMULATE=1: a functional check, not a scaling number)" if info["emulated"] else ""),
                    "inputs": "scene tables resident in HBM of every device before the timed region; each timed frame ends assembled in HBM of the first device"},
-        "kernel_ms": round(med(kern), 4),                 # slowest rank's shard, median over the timed frames
-        "gather_ms": round(med(gath), 4),                 # rank 0's kernel end -> frame in scanline order (waiting for slower ranks + gather + de-interleave)
-        "frame_latency_ms": round(med(lat), 4),           # ONE frame, nothing overlapped (== a step here)
+        "value_note": "pipelined throughput (frame i's gather under frame i+1's kernels); frame_latency_ms is ONE blocking frame, speedup_vs_n1_latency the north star's figure",
+        "kernel_ms": round(med(kern), 4),                 # slowest rank's shard, median over the timed (pipelined) frames
+        "gather_ms": round(med(gath), 4),                 # device 0's clock: (rank 0's kernel start -> frame assembled) - slowest kernel
+        "frame_latency_ms": round(med(lat), 4),           # ONE blocking frame: submit -> assembled in HBM of the first device
+        "frame_latency_kernel_ms": round(med(lkern), 4),
+        "frame_latency_non_kernel_ms": round(med([a - b for a, b in zip(lat, lkern)]), 4),
+        "frame_latency_stages_us": {k: round(med([u[i] for u in stages]), 1) for i, k in enumerate(
+            ("last_rank_thread_running", "last_rank_enqueued", "submitter_knows", "gather_enqueued", "submit_returns", "assembled_seen", "frame_done", "stats_read"))},
         "n1_kernel_ms": round(n1_kernel_ms, 4),           # the whole frame in one launch on the first device, same process
         "speedup_vs_n1_latency": round(n1_kernel_ms / med(lat), 3),
+        "speedup_vs_n1_pipelined": round(n1_kernel_ms / ms_per_step, 3),
         "frame_identical_to_n1": identical,
         "rccl_ranks": info["rccl_comms"], "transport": info["transport"], "rank_devices": info["rank_devices"],
         "distinct_devices": info["n_devices"], "visible_gpus": visible, "setup_ms": round(setup_s * 1e3, 1),
@@ -439,7 +461,7 @@ def run_ranks(args):
             except Exception:
                 pass
             if pmc.get("hbm_bytes_per_launch") is not None:
-                alg_bytes = 3 * W * H + 32 * N_SPH * 2 + 8 * 4800   # framebuffer + one pass over geometry/material/cell tables
+                alg_bytes = 3 * W * H + gs.query("table_bytes") + gs.query("texel_bytes")   # framebuffer + one pass over geometry / material cores / cell table / item lists (+ texels)
                 roof["traffic"] = pmc["hbm_bytes_per_launch"]
                 roof["traffic_source"] = pmc.get("source")
                 roof["algorithmic_bytes"] = alg_bytes
@@ -487,18 +509,27 @@ def run_ranks(args):
             # `value` is the steady state of repeated frames of one view (the queue order learned from the previous frame,
             # DESIGN.md §4.1); a one-shot render (rt_render_rgb8, the reference's one frame per process) has no previous
             # frame: the same kernel with the fixed bottom-row-first order, best of 3
-            g1 = hip.HipScene(sc.ptr, local_rank)
-            g1.set_option("tile_order", 1)
-            if args.variant:
-                g1.set_option("variant", args.variant)
+            # a one-shot render (rt_render_rgb8, the reference's one frame per process) has no previous frame: its tiles
+            # are ordered by a SEED (projection of the spheres, tile_order 3; a 4-byte-per-tile upload + the sort are inside
+            # kernel_ms) — beside it the probe-launch seed and the plain bottom-row-first order of round 3, best of 3 each
             fb1 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
-            k1 = []
-            for _ in range(4):
-                g1.render(fb1.data_ptr(), 0, None, stream.cuda_stream)
-                k1.append(g1.wait()["kernel_ms"])
-            g1.close()
-            out["first_frame_kernel_ms"] = round(min(k1[1:]), 4)
-            out["value_note"] = "steady state: frame i uses the tile-queue order learned from frame i-1 of the same view; first_frame_kernel_ms = no learned order (a one-shot render)"
+            first = {}
+            for name, opts in (("seeded", {"tile_order": 3, "order_seed": 1}), ("probe", {"tile_order": 3, "order_seed": 2}), ("bottom_first", {"tile_order": 1})):
+                k1 = []
+                for _ in range(4):   # (a fresh scene every time: a seeded order is kept by the scene it was built for)
+                    g1 = hip.HipScene(sc.ptr, local_rank)
+                    for k_, v_ in opts.items():
+                        g1.set_option(k_, v_)
+                    if args.variant:
+                        g1.set_option("variant", args.variant)
+                    g1.render(fb1.data_ptr(), 0, None, stream.cuda_stream)
+                    k1.append(g1.wait()["kernel_ms"])
+                    g1.close()
+                first[name] = round(min(k1[1:]), 4)
+            out["first_frame_kernel_ms"] = first["seeded"]
+            out["first_frame_alternatives_ms"] = first
+            out["value_note"] = ("steady state: frame i uses the tile-queue order learned from frame i-1 of the same view; first_frame_kernel_ms = a scene's "
+                                 "FIRST frame (what a one-shot rt_render_rgb8 gets): order seeded from the spheres' projections, upload + sort included")
             out["git_head"] = _git_head()
         if world == 1 and headline and not args.no_other_configs:
             out["other_configs"] = other_configs(pkg, torch, dev, stream)

@@ -294,6 +294,11 @@ int rt_hip_quot_probe(const double* d_x, const double* d_y, double* d_quot, doub
  * default 0): how long a rank's idle host thread polls for the next frame before it sleeps.
  * Out-of-range values are RT_ERR_INVALID. */
 int rt_hip_set_option(RtHipScene*, const char* key, int64_t value);
+/* What a resident scene was built into (diagnostics): "n_spheres", "n_lights", "grid_cells" (padded cell table, 8 B each),
+ * "grid_items" (u16 each), "grid_large" (spheres every ray tests), "table_bytes" (geometry + material cores + cell table +
+ * item lists: what a workgroup stages into LDS once per launch), "texel_bytes" (textures + sky as 4-byte texels in HBM).
+ * -1 for an unknown key. */
+int64_t rt_hip_scene_query(const RtHipScene*, const char* key);
 /* Animation (the reference's `anim/frame_%03d.png` workflow, README.md:43-57, main.rs:17): move the
  * camera of a resident scene — the four vectors of camera.rs:52-63 — without touching its tables,
  * and render whole frames of it into a host buffer (internal device framebuffer, blocking). */

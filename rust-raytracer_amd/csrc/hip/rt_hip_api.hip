@@ -40,6 +40,7 @@ struct RtHipScene {
   bool has_lights = false, simple_colour = false;
   void* d_geom = nullptr; void* d_mat = nullptr; void* d_cull = nullptr; void* d_lights = nullptr;
   void* d_tex = nullptr; void* d_sky = nullptr; void* d_tex4 = nullptr; void* d_sky4 = nullptr;
+  size_t texel_bytes = 0;
   void* d_matc = nullptr; void* d_cell_word = nullptr; void* d_cell_items = nullptr; void* d_large = nullptr;
   void* d_all = nullptr;   // 0..n-1: the `large` list of the brute-force arm (variant 1)
   void* d_large_geom = nullptr;
@@ -202,6 +203,7 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   }
   // textures and sky: resident as 4-byte texels (rt_tables.h build_texels; one dword load per fetch); the caller's RGB8
   // bytes are uploaded too only if some record is outside that path's range (rt_core.h texels_fast)
+  s->texel_bytes = (t.tex4.size() + t.sky4.size()) * 4u;
   if ((rc = upload(&s->d_tex4, t.tex4)) != RT_OK) return bail(rc);
   if ((rc = upload(&s->d_sky4, t.sky4)) != RT_OK) return bail(rc);
   {
@@ -677,6 +679,19 @@ extern "C" int rt_hip_wait(RtHipScene* s, RtStats* stats) {
   s->in_flight = false;
   if (stats) fill_stats(s, s->last_slot(), stats);
   return RT_OK;
+}
+
+// what a resident scene was built into (diagnostics; bench.py prices the tables' bytes with it)
+extern "C" int64_t rt_hip_scene_query(const RtHipScene* s, const char* key) {
+  if (!s || !key) return -1;
+  if (!std::strcmp(key, "n_spheres")) return (int64_t)s->host.n_spheres;
+  if (!std::strcmp(key, "n_lights")) return (int64_t)s->dev.n_lights;
+  if (!std::strcmp(key, "grid_cells")) return (int64_t)s->grid.n_cells;       // padded cell table (8 B each)
+  if (!std::strcmp(key, "grid_items")) return (int64_t)s->grid.n_items;       // u16 each
+  if (!std::strcmp(key, "grid_large")) return (int64_t)s->grid.n_large;
+  if (!std::strcmp(key, "texel_bytes")) return (int64_t)s->texel_bytes;       // 4-byte texels of textures + sky resident in HBM
+  if (!std::strcmp(key, "table_bytes")) return (int64_t)((size_t)s->host.n_spheres * (sizeof(rtc::SphereGeom) + sizeof(rtc::MatCore)) + (size_t)s->grid.n_cells * 8u + (size_t)s->grid.n_items * 2u);
+  return -1;
 }
 
 extern "C" int rt_hip_set_camera(RtHipScene* s, const double origin[3], const double lower_left[3], const double horizontal[3],

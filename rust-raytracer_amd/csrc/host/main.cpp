@@ -12,12 +12,15 @@
 // [--orbit DEG]` renders N frames to `<output_prefix>_%03d.png` — the file naming main.rs:17
 // keeps commented out and README.md:43-57 / "Make animation" feed to ffmpeg — turning the camera
 // around look_at by DEG per frame (default 360/N).  The scene is uploaded once and stays in HBM;
-// the PNG of frame i is encoded on a host thread while the GPU renders frame i+1.
+// the PNG of frame i is encoded on a host thread while the GPU renders frame i+1.  With RT_GPUS=G every frame is sharded
+// over the G devices and frames are pipelined two deep (RT_ANIM=sharded, default), or the frames are distributed over the
+// devices, each rendering whole frames (RT_ANIM=frames); RT_STATS=1 prints frames per second to stderr.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -25,49 +28,145 @@
 #include "../../../include/rt_abi.h"
 
 namespace {
-int animate(RtSceneFile* sf, const char* prefix, int frames, double orbit_deg) {
+// camera of frame f: look_from turned about vup around look_at by orbit_deg * f (Rodrigues), then camera.rs:45-77
+void orbit_camera(const double cam[11], double orbit_deg, int f, double out[13]) {
+  const double *lf = cam, *la = cam + 3, *up = cam + 6;
+  double k[3];
+  const double kl = std::sqrt(up[0] * up[0] + up[1] * up[1] + up[2] * up[2]);
+  for (int i = 0; i < 3; ++i) k[i] = up[i] / kl;
+  const double th = orbit_deg * f * (3.14159265358979323846264338327950288 / 180.0), c = std::cos(th), s = std::sin(th);
+  const double v[3] = {lf[0] - la[0], lf[1] - la[1], lf[2] - la[2]};
+  const double kv = k[0] * v[0] + k[1] * v[1] + k[2] * v[2];
+  const double kx[3] = {k[1] * v[2] - k[2] * v[1], k[2] * v[0] - k[0] * v[2], k[0] * v[1] - k[1] * v[0]};
+  double from[3];
+  for (int i = 0; i < 3; ++i) from[i] = la[i] + v[i] * c + kx[i] * s + k[i] * kv * (1.0 - c);
+  rt_camera_derive(from, la, up, cam[9], cam[10], out);
+}
+std::string frame_name(const char* prefix, int f) {
+  char name[4096];
+  std::snprintf(name, sizeof name, "%s_%03d.png", prefix, f);  // main.rs:17
+  return name;
+}
+void report(const char* mode, int frames, unsigned gpus, double wall_s) {
+  if (std::getenv("RT_STATS"))
+    std::fprintf(stderr, "{\"animation\":\"%s\",\"frames\":%d,\"n_gpus\":%u,\"wall_s\":%.4f,\"frames_per_s\":%.3f}\n", mode, frames, gpus, wall_s,
+                 frames / wall_s);
+}
+
+// Every frame SHARDED over the RT_GPUS devices (rt_hip_group_*), frames pipelined two deep: frame f+1 is submitted before
+// frame f is collected, so f's gather + de-interleave + device-to-host copy run under f+1's kernels, and f's PNG is encoded
+// on a host thread meanwhile.  Three host buffers: two frames in flight + one being written.
+int animate_sharded(RtSceneFile* sf, const char* prefix, int frames, double orbit_deg) {
   RtScene* sc = rt_scene_get_mut(sf);
   RtHipGroup* hs = nullptr;  // the scene resident on RT_GPUS devices (default 1)
   int rc = rt_hip_group_create(sc, 0, &hs);
   if (rc != RT_OK) { std::fprintf(stderr, "render failed: %s: %s\n", rt_strerror(rc), rt_hip_last_error()); return 101; }
+  const auto t_begin = std::chrono::steady_clock::now();
   double cam[11];
   rt_scene_camera(sf, cam);
-  const double *lf = cam, *la = cam + 3, *up = cam + 6;
-  double k[3], kl = std::sqrt(up[0] * up[0] + up[1] * up[1] + up[2] * up[2]);
-  for (int i = 0; i < 3; ++i) k[i] = up[i] / kl;
   const size_t bytes = (size_t)sc->width * sc->height * 3;
-  std::vector<uint8_t> buf[2] = {std::vector<uint8_t>(bytes), std::vector<uint8_t>(bytes)};
+  std::vector<uint8_t> buf[3] = {std::vector<uint8_t>(bytes), std::vector<uint8_t>(bytes), std::vector<uint8_t>(bytes)};
   std::thread writer;
-  int write_rc = RT_OK;
-  int status = 0;
-  for (int f = 0; f < frames; ++f) {
-    // Rodrigues rotation of (look_from - look_at) about vup
-    const double th = orbit_deg * f * (3.14159265358979323846264338327950288 / 180.0), c = std::cos(th), s = std::sin(th);
-    const double v[3] = {lf[0] - la[0], lf[1] - la[1], lf[2] - la[2]};
-    const double kv = k[0] * v[0] + k[1] * v[1] + k[2] * v[2];
-    const double kx[3] = {k[1] * v[2] - k[2] * v[1], k[2] * v[0] - k[0] * v[2], k[0] * v[1] - k[1] * v[0]};
-    double from[3], out[13];
-    for (int i = 0; i < 3; ++i) from[i] = la[i] + v[i] * c + kx[i] * s + k[i] * kv * (1.0 - c);
-    rt_camera_derive(from, la, up, cam[9], cam[10], out);
-    rt_hip_group_set_camera(hs, out, out + 3, out + 6, out + 9);
-    char name[4096];
-    std::snprintf(name, sizeof name, "%s_%03d.png", prefix, f);  // main.rs:17
-    std::printf("\nRendering %s\n", name);
+  int write_rc = RT_OK, status = 0;
+  const uint32_t w = sc->width, h = sc->height;
+  auto finish = [&](int f) -> bool {  // collect frame f, print its two lines, hand its pixels to the PNG writer
     RtStats st{};
-    rc = rt_hip_group_render_to_host(hs, buf[f & 1].data(), &st);
-    if (rc != RT_OK) { std::fprintf(stderr, "render failed: %s: %s\n", rt_strerror(rc), rt_hip_last_error()); status = 101; break; }
-    std::printf("Frame time: %lldms\n", (long long)st.frame_ms);
+    const int rc = rt_hip_group_collect(hs, &st);
+    if (rc != RT_OK) { std::fprintf(stderr, "render failed: %s: %s\n", rt_strerror(rc), rt_hip_last_error()); status = 101; return false; }
+    const std::string fname = frame_name(prefix, f);
+    std::printf("\nRendering %s\nFrame time: %lldms\n", fname.c_str(), (long long)st.frame_ms);
     if (writer.joinable()) writer.join();
-    if (write_rc != RT_OK) break;
-    const std::string fname(name);
-    const uint8_t* px = buf[f & 1].data();
-    const uint32_t w = sc->width, h = sc->height;
+    if (write_rc != RT_OK) return false;
+    const uint8_t* px = buf[f % 3].data();
     writer = std::thread([fname, px, w, h, &write_rc]() { write_rc = rt_png_write_rgb8(fname.c_str(), px, w, h); });
+    return true;
+  };
+  int submitted = 0, collected = 0;
+  for (int f = 0; f < frames && status == 0 && write_rc == RT_OK; ++f) {
+    double out[13];
+    orbit_camera(cam, orbit_deg, f, out);
+    rt_hip_group_set_camera(hs, out, out + 3, out + 6, out + 9);
+    // (buf[f % 3] held frame f - 3, whose PNG is out: the writer of frame f - 2 was started after joining that of f - 3)
+    rc = rt_hip_group_submit(hs, buf[f % 3].data());
+    if (rc != RT_OK) { std::fprintf(stderr, "render failed: %s: %s\n", rt_strerror(rc), rt_hip_last_error()); status = 101; break; }
+    submitted++;
+    if (submitted - collected == 2) { if (!finish(collected)) break; collected++; }
   }
+  while (status == 0 && write_rc == RT_OK && collected < submitted) { if (!finish(collected)) break; collected++; }
   if (writer.joinable()) writer.join();
+  report("sharded", collected, rt_hip_group_size(hs), std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
   rt_hip_group_destroy(hs);
   if (write_rc != RT_OK) { std::fprintf(stderr, "error writing image: %s\n", rt_host_last_error()); status = 101; }
   return status;
+}
+
+// RT_ANIM=frames: the frames DISTRIBUTED over the devices — device g renders whole frames g, g + G, ... on its own resident
+// scene and host thread (README.md:43-57 renders an animation one process per frame; this is that, with the scene loaded
+// once per device).  No gather, no shard penalty, no per-frame synchronisation between devices; every frame is the bytes the
+// sharded mode produces (Philox is addressed by pixel).  Per device the PNG of a frame is encoded while the next one renders.
+int animate_frames(RtSceneFile* sf, const char* prefix, int frames, double orbit_deg, unsigned G) {
+  RtScene* sc = rt_scene_get_mut(sf);
+  const int ndev = rt_hip_device_count();
+  const char* emu = std::getenv("RT_GPUS_EMULATE");
+  if (ndev <= 0) { std::fprintf(stderr, "render failed: %s\n", rt_strerror(RT_ERR_NO_DEVICE)); return 101; }
+  if (G > (unsigned)ndev && !(emu && emu[0] == '1')) {
+    std::fprintf(stderr, "render failed: RT_GPUS = %u but only %d device(s) visible\n", G, ndev);
+    return 101;
+  }
+  double cam[11];
+  rt_scene_camera(sf, cam);
+  const size_t bytes = (size_t)sc->width * sc->height * 3;
+  const uint32_t w = sc->width, h = sc->height;
+  std::mutex out_mu;
+  std::vector<int> status(G, 0);
+  const auto t_begin = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for (unsigned g = 0; g < G; ++g)
+    th.emplace_back([&, g]() {
+      RtHipScene* hs = nullptr;
+      int rc = rt_hip_scene_create(sc, (int)(g % (unsigned)ndev), &hs);
+      if (rc != RT_OK) { std::lock_guard<std::mutex> lk(out_mu); std::fprintf(stderr, "render failed: %s: %s\n", rt_strerror(rc), rt_hip_last_error()); status[g] = 101; return; }
+      std::vector<uint8_t> buf[2] = {std::vector<uint8_t>(bytes), std::vector<uint8_t>(bytes)};
+      std::thread writer;
+      int write_rc = RT_OK, i = 0;
+      for (int f = (int)g; f < frames && write_rc == RT_OK; f += (int)G, ++i) {
+        double out[13];
+        orbit_camera(cam, orbit_deg, f, out);
+        rt_hip_set_camera(hs, out, out + 3, out + 6, out + 9);
+        RtStats st{};
+        rc = rt_hip_render_to_host(hs, buf[i & 1].data(), &st);
+        const std::string fname = frame_name(prefix, f);
+        {
+          std::lock_guard<std::mutex> lk(out_mu);
+          if (rc != RT_OK) { std::fprintf(stderr, "render failed: %s: %s\n", rt_strerror(rc), rt_hip_last_error()); status[g] = 101; }
+          else std::printf("\nRendering %s\nFrame time: %lldms\n", fname.c_str(), (long long)st.frame_ms);
+        }
+        if (rc != RT_OK) break;
+        if (writer.joinable()) writer.join();
+        const uint8_t* px = buf[i & 1].data();
+        writer = std::thread([fname, px, w, h, &write_rc]() { write_rc = rt_png_write_rgb8(fname.c_str(), px, w, h); });
+      }
+      if (writer.joinable()) writer.join();
+      if (write_rc != RT_OK) { std::lock_guard<std::mutex> lk(out_mu); std::fprintf(stderr, "error writing image: %s\n", rt_host_last_error()); status[g] = 101; }
+      rt_hip_scene_destroy(hs);
+    });
+  for (auto& t : th) t.join();
+  report("frames", frames, G, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+  for (int s : status) if (s) return s;
+  return 0;
+}
+
+int animate(RtSceneFile* sf, const char* prefix, int frames, double orbit_deg) {
+  const char* mode = std::getenv("RT_ANIM");
+  if (mode && !std::strcmp(mode, "frames")) {
+    const RtScene* sc = rt_scene_get(sf);
+    unsigned G = sc->n_gpus;
+    if (G == 0) { const char* e = std::getenv("RT_GPUS"); G = e ? (unsigned)std::strtoul(e, nullptr, 10) : 1u; }
+    if (G < 1 || G > 1024) { std::fprintf(stderr, "render failed: RT_GPUS must be a positive device count\n"); return 101; }
+    return animate_frames(sf, prefix, frames, orbit_deg, G);
+  }
+  if (mode && std::strcmp(mode, "sharded")) { std::fprintf(stderr, "RT_ANIM must be sharded (default) or frames\n"); return 101; }
+  return animate_sharded(sf, prefix, frames, orbit_deg);
 }
 }  // namespace
 

@@ -34,6 +34,8 @@ def lib():
         L.rt_hip_wait.argtypes = [C.c_void_p, C.POINTER(abi.RtStats)]
         L.rt_hip_debug_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.rt_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.rt_hip_scene_query.argtypes = [C.c_void_p, C.c_char_p]
+        L.rt_hip_scene_query.restype = C.c_int64
         L.rt_render_rgb8.argtypes = [C.POINTER(abi.RtScene), C.c_void_p, C.POINTER(abi.RtStats)]
         L.rt_hip_set_camera.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 4
         L.rt_hip_render_to_host.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.RtStats)]
@@ -93,6 +95,10 @@ class HipScene:
 
     def set_option(self, key, value):
         _check(lib().rt_hip_set_option(self._h, key.encode(), int(value)))
+
+    def query(self, key):
+        """rt_hip_scene_query: what the resident scene was built into ("grid_cells", "table_bytes", ...); -1 = unknown key"""
+        return int(lib().rt_hip_scene_query(self._h, key.encode()))
 
     def render(self, d_rgb8, d_linear=0, tiles=None, stream=0):
         """enqueue the megakernel; d_* are raw device pointers (ints), stream a hipStream_t"""

@@ -675,11 +675,20 @@ def test_cli_multi_gpu_env(tmp_path):
         assert stats["n_gpus"] == g and stats["setup_ms"] > 0 and stats["frame_ms"] >= stats["kernel_ms"]
         assert r.stdout.split("\n")[2].startswith("Frame time: ")
         imgs[g] = np.asarray(Image.open(out))
-        r = subprocess.run([exe, str(p), str(tmp_path / f"a{g}"), "--frames", "2", "--orbit", "30"], capture_output=True, text=True, cwd=ROOT, env=env)
-        assert r.returncode == 0, r.stderr
-        imgs[(g, "anim")] = [np.asarray(Image.open(tmp_path / f"a{g}_{f:03d}.png")) for f in range(2)]
+        # animations: 5 frames (the sharded mode pipelines them two deep over three host buffers), and — RT_ANIM=frames —
+        # the frames distributed over the devices, each rendering whole frames: the same PNG bytes every way
+        for mode in ("sharded", "frames"):
+            r = subprocess.run([exe, str(p), str(tmp_path / f"a{g}{mode}"), "--frames", "5", "--orbit", "30"], capture_output=True, text=True, cwd=ROOT,
+                               env=dict(env, RT_ANIM=mode))
+            assert r.returncode == 0, r.stderr
+            assert r.stdout.count("\nRendering ") == 5 and r.stdout.count("Frame time: ") == 5
+            rep = json.loads(r.stderr.strip().splitlines()[-1])
+            assert rep["animation"] == mode and rep["frames"] == 5 and rep["n_gpus"] == g and rep["frames_per_s"] > 0
+            imgs[(g, mode)] = [np.asarray(Image.open(tmp_path / f"a{g}{mode}_{f:03d}.png")) for f in range(5)]
     assert np.array_equal(imgs[1], imgs[4])
-    assert all(np.array_equal(a, b) for a, b in zip(imgs[(1, "anim")], imgs[(4, "anim")]))
+    for key in ((4, "sharded"), (1, "frames"), (4, "frames")):
+        assert all(np.array_equal(a, b) for a, b in zip(imgs[(1, "sharded")], imgs[key])), key
+    assert not np.array_equal(imgs[(1, "sharded")][0], imgs[(1, "sharded")][4])
     r = subprocess.run([exe, str(p), str(tmp_path / "x.png")], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, RT_GPUS="64"))
     assert r.returncode == 101 and "device" in r.stderr    # more GPUs than the box has: refused, like any render failure
 

@@ -89,6 +89,8 @@ def run(rounds, scene_path, only):
         L = bind(path, abi)
         hs = C.c_void_p()
         os.environ.update(env)
+        L.rt_abi_version.restype = C.c_uint32
+        sc.c.abi_version = L.rt_abi_version()   # (an arm built from an older checkout: RtScene's layout has not changed since v3)
         assert L.rt_hip_scene_create(sc.ptr, 0, C.byref(hs)) == 0, L.rt_hip_last_error()
         for k in env:
             del os.environ[k]
