@@ -236,6 +236,12 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   s->dev.matc = (const rtc::MatCore*)s->d_matc; s->dev.cell_word = (const uint32_t*)s->d_cell_word;
   s->dev.cell_items = (const uint16_t*)s->d_cell_items; s->dev.large = (const uint32_t*)s->d_large;
   s->dev.large_geom = (const rtc::SphereGeom*)s->d_large_geom;
+  // Everything above went through the NULL stream — and hipMemset / hipMemcpy from pageable memory return before the device
+  // has finished (they are asynchronous to the host: the fill / the DMA out of the staging buffer may still be queued).
+  // The frames run on the CALLER's streams, and a non-blocking stream does not order itself behind the NULL stream: a first
+  // frame launched right away could start before the tables had landed, or have its tile-queue cursor zeroed under it
+  // (round 4: the group launches rank 0 from the creating thread at once — 65 % of fresh 3-rank groups traced tiles twice).
+  if (hipDeviceSynchronize() != hipSuccess) return bail(fail(RT_ERR_HIP, "hipDeviceSynchronize failed"));
   *out = s;
   return RT_OK;
 }
