@@ -146,7 +146,11 @@ struct DevScene {
   uint32_t sky_mode, n_spheres, n_lights, n_pairs;
   uint32_t seed_lo, seed_hi;
   uint32_t light_pool_slots;  // lit scenes, pooled kernels: records in the workgroup's pool of light frames (LightState<true, true>)
-  uint32_t pad1;
+  uint32_t cam_fast;          // inv_wm1 and inv_hm1 are both usable (width, height > 1): divide through them
+  // raytracer.rs:92-100: a hit samples the lights when its draw exceeds 1 - n_lights * prob, prob = 0.1 (Glass: 0.05): the two
+  // thresholds, computed once on the host with those operations — a wave-uniform scalar operand instead of two f64
+  // constants the compiler hoisted into (and spilled from) vector registers of the path loop
+  double light_thr[2];        // [0] prob 0.1, [1] Glass
   double cam_origin[3], cam_ll[3], cam_h[3], cam_v[3];
   double wm1, hm1, inv_wm1, inv_hm1, height_d;  // (width-1), (height-1), their RN reciprocals (0: slow divide), height
   const SphereGeom* geom;
@@ -400,6 +404,22 @@ RT_HD double exact_root(V3 o, V3 d, double a, const SphereGeom& g, double t_min,
 }
 constexpr double T_MIN = 0.001;                     // raytracer.rs:83
 constexpr double T_MAX = 1.7976931348623157e308;    // f64::MAX
+// T_MAX for the per-iteration `closest = f64::MAX` of the path loop: two moves made where they are needed.  As a plain
+// constant the compiler hoists the pair out of the loop into registers that stay live across everything — and, in the lit
+// kernels, spills them and reloads them from scratch memory every iteration.
+RT_HD double t_max_fresh() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t lo, hi;
+  asm volatile("v_mov_b32 %0, -1" : "=v"(lo));
+  asm volatile("v_mov_b32 %0, 0x7fefffff" : "=v"(hi));
+  const unsigned long long b = ((unsigned long long)hi << 32) | lo;
+  double d;
+  __builtin_memcpy(&d, &b, 8);
+  return d;
+#else
+  return T_MAX;
+#endif
+}
 
 // Order-free form of the closest-hit scan (raytracer.rs:52-57).  The reference walks the
 // spheres in object order and accepts sphere i iff its first root f_i in (t_min, inf) is
@@ -1201,7 +1221,7 @@ RT_HD void lane_begin_sample_w(const DevScene& sc, LaneT& L, uint32_t px, uint32
   L.ra.sample = L.s;
   double un = (double)px + u01_53(w.x, w.y), vn = sc.height_d - ((double)py + u01_53(w.z, w.w));
   double u, v;  // raytracer.rs:199-200: un / (width - 1), vn / (height - 1)
-  if (sc.inv_wm1 != 0.0 && sc.inv_hm1 != 0.0) { u = div_by_recip(un, sc.wm1, sc.inv_wm1); v = div_by_recip(vn, sc.hm1, sc.inv_hm1); }
+  if (sc.cam_fast) { u = div_by_recip(un, sc.wm1, sc.inv_wm1); v = div_by_recip(vn, sc.hm1, sc.inv_hm1); }  // (a flag of its own: testing the reciprocals themselves kept one of them in a — spilled — vector register across the branch)
   else { u = un / sc.wm1; v = vn / sc.hm1; }
   V3 origin = v3(sc.cam_origin[0], sc.cam_origin[1], sc.cam_origin[2]);
   V3 llc = v3(sc.cam_ll[0], sc.cam_ll[1], sc.cam_ll[2]);
@@ -1377,10 +1397,12 @@ RT_HD bool lane_may_sample_lights(const DevScene& sc, const LaneT& L) {
   return false;
 }
 
-// Consume the closest hit (idx < 0: miss) of the lane's current ray.  Returns true when the
-// lane's current sample finished (its radiance is in L.val; the caller starts the next one).
+// Consume the closest hit (idx < 0: miss) of the lane's current ray.  Returns LANE_FINISHED when the
+// lane's current sample finished (its radiance is in L.val; the caller starts the next one), LANE_REPEAT when nothing was
+// consumed (pooled lit kernels: no light frame free — the same ray is traced again next iteration), else LANE_CONTINUE.
+enum { LANE_CONTINUE = 0, LANE_FINISHED = 1, LANE_REPEAT = 2 };
 template <class LaneT, class Tables>
-RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, double t, const V3* rnd_pre = nullptr,
+RT_HD int lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, double t, const V3* rnd_pre = nullptr,
                       const double* glass_u_pre = nullptr, const double* light_u_pre = nullptr) {
   constexpr bool HL = LaneT::kLights;
   const float zero3[3] = {0.0f, 0.0f, 0.0f};
@@ -1388,7 +1410,7 @@ RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, d
     (void)light_u_pre;
     if (idx < 0) {  // raytracer.rs:133-163
       lane_finish_sample(L, sky_color(sc, L.d, L.n_tex_oob));
-      return true;
+      return LANE_FINISHED;
     }
     const SphereGeom g = tb.geom((uint32_t)idx);
     const MatCore m = tb.mat((uint32_t)idx);
@@ -1396,9 +1418,9 @@ RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, d
     V3 out_dir = v3(0, 0, 0);
     float att[3];
     int st = scatter(sc, L.ra, L.node, L.d, h, g, m, (uint32_t)idx, out_dir, att, L.n_tex_oob, rnd_pre, glass_u_pre);
-    if (st == SCATTER_ABSORBED) { lane_finish_sample(L, rgb(0.f, 0.f, 0.f)); return true; }       // :127-131
-    if (st == SCATTER_EMIT) { lane_finish_sample(L, rgb(att[0], att[1], att[2])); return true; }  // :124
-    return lane_continue_main(sc, L, h.point, out_dir, zero3, att);
+    if (st == SCATTER_ABSORBED) { lane_finish_sample(L, rgb(0.f, 0.f, 0.f)); return LANE_FINISHED; }       // :127-131
+    if (st == SCATTER_EMIT) { lane_finish_sample(L, rgb(att[0], att[1], att[2])); return LANE_FINISHED; }  // :124
+    return lane_continue_main(sc, L, h.point, out_dir, zero3, att) ? LANE_FINISHED : LANE_CONTINUE;
   } else {
     // Lit scenes.  First decide what the hit MEANS for the lane; the heavy continuations — hand a colour back to the
     // activation that shot this light ray, start summing over the lights — then exist once each: in a wave some lane
@@ -1426,9 +1448,8 @@ RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, d
         // wrap); a light ray's own hit: the same test one level down, below the nesting cap
         bool sample = false;
         if (lane_may_sample_lights(sc, L)) {
-          const double prob = m.kind == RT_MAT_GLASS ? 0.05 : 0.1;
           const double lu = light_u_pre ? *light_u_pre : lane_light_draw(L);
-          sample = lu > (1.0 - (double)sc.n_lights * prob);
+          sample = lu > sc.light_thr[m.kind == RT_MAT_GLASS ? 1 : 0];  // 1.0 - n_lights as f64 * prob (fill_dev_scene)
         }
         if (sample) act = ACT_SAMPLE;
         else if (light_ray) {  // no light sampling: clamp(0 + albedo * black) (:117-122, the child is depth 0)
@@ -1440,8 +1461,9 @@ RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, d
     if (act == ACT_SAMPLE) {
       if (light_ray) light_frame_push(L.ls);  // suspend the activation whose light ray this is
       else {
-        // (pooled kernels: no record free -> nothing has changed yet: the same segment is traced again, and counted once)
-        if (!light_frame_acquire(L.ls, sc.light_pool_slots, L.ra.pixel + L.ra.sample)) { L.n_segments--; return false; }
+        // (pooled kernels: no record free -> nothing has changed yet: the same segment is traced again; the caller counts
+        //  the segment once — its exact tests and grid steps are the work actually done, and counted as such)
+        if (!light_frame_acquire(L.ls, sc.light_pool_slots, L.ra.pixel + L.ra.sample)) return LANE_REPEAT;
         L.ls.top = 0;
         light_frame(L.ls).saved_d = out_dir;
       }
@@ -1449,11 +1471,11 @@ RT_HD bool lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, d
       f.P = point; f.a[0] = att[0]; f.a[1] = att[1]; f.a[2] = att[2];
       f.acc[0] = f.acc[1] = f.acc[2] = 0.0f; f.j = 0; f.node = L.node;
       lane_aim_light(sc, tb, L);
-      return false;
+      return LANE_CONTINUE;
     }
-    if (act == ACT_RETURN) return lane_light_return(sc, tb, L, col);
-    if (act == ACT_FINISH) { lane_finish_sample(L, col); return true; }
-    return lane_continue_main(sc, L, point, out_dir, zero3, att);
+    if (act == ACT_RETURN) return lane_light_return(sc, tb, L, col) ? LANE_FINISHED : LANE_CONTINUE;
+    if (act == ACT_FINISH) { lane_finish_sample(L, col); return LANE_FINISHED; }
+    return lane_continue_main(sc, L, point, out_dir, zero3, att) ? LANE_FINISHED : LANE_CONTINUE;
   }
 }
 

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   LaneT L;
   L.s = 0; L.k = 0; L.node = 0; L.in_light = 0;
   L.val[0] = L.val[1] = L.val[2] = 0.0f;
-  L.n_segments = L.n_exact = L.n_tex_oob = 0;
+  L.n_segments = L.n_exact = L.n_tex_oob = 0;  // (hostsim's counters; of these the kernel only passes n_tex_oob on, and empties it after every use)
   L.ra.pixel = 0; L.ra.sample = 0; L.ra.k0 = sc.seed_lo; L.ra.k1 = sc.seed_hi;
   L.o = v3(0, 0, 0); L.d = v3(0, 0, 1);
   fwd_init(L.fwd);
@@ -397,7 +397,15 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   } else {
     lane_attach_light_state(L, light_stack, reinterpret_cast<LightParked*>(lds_raw + lay.park_off) + threadIdx.x);
   }
-  uint32_t n_exact = 0, n_steps = 0;  // per-lane counters (one exec-masked add each; the segments are counted in L.n_segments)
+  auto flush_oob = [&]() {  // (after every call that may count an out-of-range texel: L.n_tex_oob is 0 again, so nothing is carried)
+    if (L.n_tex_oob != 0u) { __hip_atomic_fetch_add(&wg_counters[2], (unsigned long long)L.n_tex_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); L.n_tex_oob = 0u; }
+  };
+  uint32_t n_exact = 0, n_steps = 0;  // per-lane counters (one exec-masked add each)
+  // Segments are counted per WAVE on the scalar unit (the lanes of the trace's lane mask: one s_bcnt1 per iteration), and
+  // out-of-range texel fetches — practically never — go straight to the workgroup's counter: two registers every lane
+  // carried across the walk loop (in the lit kernels exactly the pair that was spilled there: 15 scratch round trips per
+  // wave iteration, profiles/r03_codeobj.txt -> r04_codeobj.txt).
+  uint32_t w_segments = 0;
   uint32_t cnt_w_iter = 0, cnt_w_step = 0, cnt_w_test = 0, cnt_items = 0;  // wave trip counts (RT_PROFILE builds)
 
   RT_PROF(5);  // staging of the tables into LDS (+ item bookkeeping later)
@@ -717,9 +725,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     const uint32_t n_large = G.n_large;
     const bool has_grid = G.n[0] != 0u;
     const RayK rk = ray_consts(L.d);
-    closest = T_MAX;
+    closest = t_max_fresh();
     best = -1;
-    if (has_ray) L.n_segments++;
+    w_segments += (uint32_t)__builtin_popcountll(wave_ballot(has_ray));
     // (1) spheres outside the grid: every lane tests them.  The records are wave-uniform, so they
     // arrive by scalar loads as SGPR operands; the next record is fetched while this one is tested.
     if (n_large != 0u) {
@@ -860,7 +868,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 #if RT_SINGLE_SETTLE
   bool pending = false;  // per lane: its sample finished in the shade block of the previous iteration (radiance in L.val)
 #endif
-#if RT_FUSED_REFILL
+#if !RT_FUSED_REFILL
+#error "the unfused refill loop (round 1: a refill block of its own at the top of the iteration) was removed in round 4; its measurement: profiles/r02_run3_ab.log"
+#endif
   // Loop order: trace -> rays that left the scene finish at once (sky) -> every lane without a path takes its next
   // sample -> ONE Philox instruction stream serves the hits (unit-sphere point / Glass draw) and the new samples (camera
   // jitter) -> shade the hits -> start the new samples.  The refill used to be a block of its own at the top of the loop
@@ -872,7 +882,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 #endif
     RT_PROF_COUNT(cnt_w_iter);
     RT_PROF(0);
-    double closest = T_MAX;
+    double closest = t_max_fresh();
     int best = -1;
     if (wave_any(has_ray)) hit_world(closest, best);
     RT_PROF(3);
@@ -885,6 +895,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     if (wave_any(miss)) {
       if (miss) {
         lane_finish_sample(L, sky_color(fresh_args().sc, L.d, L.n_tex_oob));
+        flush_oob();
         has_ray = false;
       }
     }
@@ -897,6 +908,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     if (wave_any(miss)) {
       if (miss) {
         lane_finish_sample(L, sky_color(fresh_args().sc, L.d, L.n_tex_oob));
+        flush_oob();
         has_ray = false;
       }
       add_sample(miss);
@@ -927,7 +939,15 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 #endif
     // (d) shade the hits
     bool finished = false;
-    if (has_ray) finished = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u, HL ? &light_u : nullptr);
+    if (has_ray) {
+      const int status = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u, HL ? &light_u : nullptr);
+      flush_oob();
+      finished = status == LANE_FINISHED;
+      if constexpr (POOLED) {  // a segment repeated because the light-frame pool was exhausted is ONE segment of its path
+        const unsigned long long rep = wave_ballot(status == LANE_REPEAT);
+        if (rep) w_segments -= (uint32_t)__builtin_popcountll(rep);
+      }
+    }
     RT_PROF(2);
 #if RT_SINGLE_SETTLE
     if (finished) { has_ray = false; pending = true; }
@@ -954,54 +974,10 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       __builtin_amdgcn_s_sleep(32);
     } else idle_spins = 0;
   }
-#else
-  for (;;) {
-    // ------------------------------------------------------------ refill lanes that hold no path
-    {
-      uint32_t n_px = 0, n_py = 0;
-      const bool got = hand_out(!has_ray, n_px, n_py);
-      if (got) { lane_begin_sample(fresh_args().sc, L, n_px, n_py); has_ray = true; }
-    }
-    if (!wave_any(has_ray)) {
-      // nothing in flight.  Done when the frame has nothing left; otherwise (all tile slots are
-      // busy with other waves' long paths) wait a little and ask again — bounded, a wave may
-      // always retire: the samples it traced are already counted in their tiles.
-      if (q_done || ++idle_spins > (1u << 16)) break;
-      __builtin_amdgcn_s_sleep(32);
-      continue;
-    }
-
-    idle_spins = 0;
-#ifdef RT_PROFILE
-    if (q_done) { prof_tail_iters++; prof_tail_lanes += (uint32_t)__builtin_popcountll(wave_ballot(has_ray)); }
-#endif
-    RT_PROF_COUNT(cnt_w_iter);
-    RT_PROF(0);
-    double closest;
-    int best;
-    hit_world(closest, best);
-    RT_PROF(3);
-    // ---------------------------------------------------------- ray_color body
-    // the unit-sphere point most hits need is drawn by the whole wave together
-    const uint32_t hit_kind = has_ray && best >= 0 ? tb.mat((uint32_t)best).kind : 0xFFFFFFFFu;
-    double glass_u;
-    U4 cam_w;
-    double glass_lu;
-    const V3 rnd = coop_random_in_unit_sphere(hit_kind != 0xFFFFFFFFu && material_draws_unit_sphere(hit_kind), hit_kind == RT_MAT_GLASS, false,
-                                              L.ra, L.node, lane, coop_xch, glass_u, glass_lu, cam_w);
-    bool finished = false;
-    if (has_ray) finished = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u);
-    RT_PROF(2);
-    if (finished) has_ray = false;
-    add_sample(finished);
-    count_tiles(finished, my_k);
-    RT_PROF(4);
-  }
-#endif
 
   // counters: wave reduction, one atomic per wave
-  // (L.n_segments: a segment repeated because the light-frame pool was exhausted is one segment of the path, rt_core.h)
-  unsigned long long c0 = L.n_segments, c1 = n_exact, c2 = L.n_tex_oob, c3 = n_steps;
+  // (segments: per wave, on lane 0; out-of-range texels went to the workgroup's counter as they happened)
+  unsigned long long c0 = lane == 0 ? w_segments : 0u, c1 = n_exact, c2 = 0ull, c3 = n_steps;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     c0 += __shfl_down(c0, off); c1 += __shfl_down(c1, off); c2 += __shfl_down(c2, off); c3 += __shfl_down(c3, off);

@@ -334,6 +334,8 @@ inline void fill_dev_scene(const RtScene& sc, const HostTables& t, DevScene& d) 
   d.sky_mode = sc.sky_mode; d.n_spheres = sc.n_spheres; d.n_lights = (uint32_t)t.lights.size();
   d.n_pairs = t.n_pairs;
   d.seed_lo = (uint32_t)sc.seed; d.seed_hi = (uint32_t)(sc.seed >> 32);
+  d.light_thr[0] = 1.0 - (double)d.n_lights * 0.1;   // raytracer.rs:100, the reference's operations (no contraction: -ffp-contract=off)
+  d.light_thr[1] = 1.0 - (double)d.n_lights * 0.05;  // Glass (raytracer.rs:94-96)
   for (int i = 0; i < 3; ++i) {
     d.cam_origin[i] = sc.cam_origin[i]; d.cam_ll[i] = sc.cam_lower_left[i];
     d.cam_h[i] = sc.cam_horizontal[i]; d.cam_v[i] = sc.cam_vertical[i];
@@ -343,6 +345,7 @@ inline void fill_dev_scene(const RtScene& sc, const HostTables& t, DevScene& d) 
   d.sky_fast = t.sky_fast ? 1u : 0u;  // (build_texels must have run: callers set sky4 / tex4 next to it)
   d.wm1 = (double)sc.width - 1.0; d.hm1 = (double)sc.height - 1.0; d.height_d = (double)sc.height;
   d.inv_wm1 = sc.width > 1 ? 1.0 / d.wm1 : 0.0; d.inv_hm1 = sc.height > 1 ? 1.0 / d.hm1 : 0.0;
+  d.cam_fast = (d.inv_wm1 != 0.0 && d.inv_hm1 != 0.0) ? 1u : 0u;
   d.grid = t.grid;
 }
 

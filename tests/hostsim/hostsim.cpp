@@ -93,7 +93,7 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
         }
         if (cur_depth == 0 && best >= 0) first_kind = (int)tb.mat((uint32_t)best).kind;
         cur_depth++;
-        need_new = lane_shade(ds, tb, L, best, closest);
+        need_new = lane_shade(ds, tb, L, best, closest) == LANE_FINISHED;
         if (need_new && g_hist) {  // [128..191] path length, [192 + 64 * kind ..] path length by the first hit's material
           uint32_t dd = cur_depth > 63u ? 63u : cur_depth;
 #pragma omp atomic

@@ -304,7 +304,7 @@ int main(int argc, char** argv) {
           (cls ? hl1 : hl0)[std::min<uint32_t>(lg.rounds, 64)] += 1;
           a_ls += 1; a_lst += lg.steps; a_lt += lg.tests;
           kind_lanes[best < 0 ? 0 : 1 + std::min<uint32_t>(t.matc[best].kind, 4u)]++;
-          const bool fin = lane_shade(ds, tb, L[l], best, closest);
+          const bool fin = lane_shade(ds, tb, L[l], best, closest) == LANE_FINISHED;
           if (fin) has_ray[l] = take(l);
         }
         const uint32_t mr = std::max(max_r[0], max_r[1]);
