@@ -254,6 +254,10 @@ int rt_hip_wait(RtHipScene*, RtStats* stats);
  * wave of the last launch, on the chip-wide 100 MHz clock.  Returns the number of waves copied
  * (out holds 32 + 4 x max_waves uint64) or a negative RtStatus. */
 int rt_hip_debug_timeline(RtHipScene*, uint64_t* out, uint32_t max_waves);
+/* Diagnostics: the deepest camera path per pixel tile that the last MEASURING frame recorded (tile_order 2: the first two
+ * frames of a view) — what the queue order of later frames is sorted by.  out[tile], row-major over the launch's tile grid
+ * (*tiles_x tiles wide); returns the number of tiles copied (<= cap) or a negative RtStatus. */
+int rt_hip_debug_tile_depth(RtHipScene*, uint32_t* out, uint32_t cap, uint32_t* tiles_x);
 /* Device self-tests (device pointers; tests/test_gpu_parity.py): correctly rounded f64 sqrt / divide,
  * f32 sqrt and atan2 of n operands; Sphere::hit (sphere.rs:46-58) of n (ray, sphere) pairs through
  * the kernel's own hit test — rays = n x {origin[3], direction[3]}, spheres = n x {center[3], radius},
@@ -286,11 +290,10 @@ int rt_hip_quot_probe(const double* d_x, const double* d_y, double* d_quot, doub
  * back: half the HBM traffic, +0.5 % time), 0 = one queue, 2 = per-XCD queues on any frame of 8 or more runs (tests); "samples_per_pixel", "max_depth" (0 .. 2^32-1) and
  * "seed" override the scene's values; "tile_order" 0 = tiles leave the queue top row first, 1 = bottom row
  * first, 2 (default) = the tiles whose paths ran deepest in this scene's previous frame first (the frame ends on
- * its deepest paths; the image does not depend on the order) — a frame that has no previous one sorts its tiles by a SEED:
- * "order_seed" 1 (default) = a depth guess from the spheres' projections (Glass > Metal > other > bare ground / sky; host
- * arithmetic + a 4-byte-per-tile upload + the sort, inside kernel_ms), 2 = a probe launch (one sample per pixel, 8 segments
- * at most) measures it, 0 = none (bottom row first); "tile_order" 3 = the seeded order alone, nothing measured or sorted
- * for a next frame (what the one-shot rt_render_rgb8 uses).  rt_hip_group_set_option also takes "spin_us" (0 .. 10^6,
+ * its deepest paths; the image does not depend on the order) — a frame that has no previous one goes bottom row first;
+ * "order_seed" (default 0) = 1 sorts such a frame's tiles by a depth guess from the spheres' projections, 2 by a probe
+ * launch (one sample per pixel, 8 segments at most): round-4 experiments, both measured slower than no seed (DESIGN.md
+ * §4.1); "tile_order" 3 = a seeded order alone, nothing measured or sorted for a next frame.  rt_hip_group_set_option also takes "spin_us" (0 .. 10^6,
  * default 0): how long a rank's idle host thread polls for the next frame before it sleeps.
  * Out-of-range values are RT_ERR_INVALID. */
 int rt_hip_set_option(RtHipScene*, const char* key, int64_t value);

@@ -63,8 +63,9 @@ struct RtHipScene {
   int tile_affinity = 1;    // "tile_affinity" option: runs of tiles belong to one XCD's queue (framebuffer lines complete in one L2)
   int order_mode = 2;       // "tile_order" option: 0 top row first, 1 bottom row first, 2 deepest tiles of the previous frame first
                             // (a first frame: seeded, below), 3 the seeded order alone (a one-shot render: nothing measured or sorted for a next frame)
-  int order_seed = 1;       // "order_seed" option: 1 = a frame without a measured order sorts its tiles by what the spheres' projections
-                            // say about path depth (seed_tile_depths); 0 = bottom row first, as before round 4; 2 = a probe launch instead
+  int order_seed = 0;       // "order_seed" option (round-4 experiments, both measured SLOWER than no seed and off by default —
+                            // DESIGN.md §4.1): 1 = a frame without a measured order sorts its tiles by what the spheres' projections
+                            // say about path depth (seed_tile_depths); 2 = by a probe launch; 0 = bottom row first
   struct SeedSphere { double c[3], r; uint32_t kind; };
   std::vector<SeedSphere> seed_spheres;  // host copy of (centre, radius, material kind): what the seed projects
   std::vector<uint32_t> seed_depth;      // staging of the seeded depths (kept alive until the copy that reads it has run)
@@ -92,6 +93,7 @@ struct RtHipScene {
   hipStream_t last_stream = nullptr;
   bool in_flight = false;  // a launch has been enqueued and rt_hip_wait has not returned for it yet
   uint64_t last_waves = 0;
+  uint32_t last_tiles_x = 0;
   int variant = 0;
   Slot& last_slot() { return slot[(n_launches + 1) & 1]; }  // the slot of the most recent launch
 };
@@ -465,7 +467,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   ka.tile_log2 = tl;
   ka.tile_wl = tl + widen(tl); ka.tile_hl = tl - widen(tl);
   ka.t_slots = rtk::tile_slots(tl);
-  ka.tiles_x = tx;
+  ka.tiles_x = tx; s->last_tiles_x = tx;
   ka.n_tiles = tx * ty;
   // A tile's samples are handed out to the waves of its workgroup in chunks: an item's latency
   // is what the last wave of a frame waits for, but below ~128 samples per item the acquire /
@@ -596,14 +598,16 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
     return RT_OK;
   };
   RT_HIP_TRY(hipEventRecord(sl.ev_start, stream));  // (a seeded frame's upload / probe and sort are inside its kernel_ms)
-  // A frame without a measured order (the first of a scene, a one-shot render) would leave the queue bottom row first
-  // and end on whatever deep path started last: 13.40 instead of 12.85 ms on the headline frame, 2.0 instead of 1.75 ms
-  // on its 1/8 shards.  Seed the order instead:
-  //   order_seed 1: a depth GUESS per tile from the spheres' projections (seed_tile_depths: no GPU work but a 4-byte-per-
-  //                 tile upload and the 50 us sort);
-  //   order_seed 2: a PROBE — this kernel at one sample per pixel and 8 segments at most measures the tiles' depths
-  //                 (its pixels are overwritten by the frame that follows), then the sort.
-  // The image never depends on the order.
+  // A frame without a measured order (the first of a scene, a one-shot render) leaves the queue bottom row first and ends on
+  // whatever deep path started last: 13.3 instead of 12.85 ms on the headline frame, 2.09 instead of 1.75 ms on its 1/8 shards.
+  // Two ways to SEED an order were built and measured in round 4 (tools/first_frame.py, profiles/r04_run3_first_frame_orders.log):
+  //   order_seed 1: a depth GUESS per tile from the spheres' projections (seed_tile_depths: a 4-byte-per-tile upload + the sort):
+  //                 13.61 ms — worse than no seed;
+  //   order_seed 2: a PROBE — this kernel at one sample per pixel and 8 segments at most measures the tiles' depths, then
+  //                 the sort: 13.39 ms including itself — no better.
+  // Why neither can work: what the measured order knows is WHICH tiles hold one of the rare 50-segment paths (8.6 % of the
+  // tiles hold at least one among their 2048 samples, spread over the whole ground: tools/depth_map.py) — rare events that a
+  // replay of the same seeds predicts exactly and nothing cheaper predicts at all.  Both stay as options (off by default).
   if (seed_now) {
     if (s->order_seed == 2) {
       rtk::KArgs kp = ka;
@@ -630,6 +634,19 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
     s->order_ready = true;
   }
   return finish_launch(true);
+}
+
+// Diagnostics: the per-tile path depths the last measuring frame left behind (tile_order 2, first two frames of a view):
+// out[tile] = deepest camera path seen in the tile, tiles in row-major order of the launch's tile grid (*tiles_x wide).
+// Returns the number of tiles copied (at most cap), or a negative RtStatus.
+extern "C" int rt_hip_debug_tile_depth(RtHipScene* s, uint32_t* out, uint32_t cap, uint32_t* tiles_x) {
+  if (!s || !out) return fail(RT_ERR_INVALID, "null argument");
+  RT_HIP_TRY(hipSetDevice(s->device));
+  if (s->n_launches) RT_HIP_TRY(hipStreamSynchronize(s->last_stream));
+  const uint32_t n = s->order_key.n_tiles < cap ? s->order_key.n_tiles : cap;
+  if (n && s->d_tile_depth) RT_HIP_TRY(hipMemcpy(out, s->d_tile_depth, (size_t)n * 4, hipMemcpyDeviceToHost));
+  if (tiles_x) *tiles_x = s->last_tiles_x;
+  return (int)n;
 }
 
 extern "C" int rt_hip_debug_timeline(RtHipScene* s, uint64_t* out, uint32_t max_waves) {

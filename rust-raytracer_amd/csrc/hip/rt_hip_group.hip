@@ -534,8 +534,8 @@ extern "C" int rt_render_rgb8(const RtScene* scene, uint8_t* out_rgb8, RtStats* 
   int rc = rt_hip_group_create(scene, 0, &g);
   if (rc != RT_OK) return rc;
   // one frame per scene: no later frame could use a queue order learned from this one (tile_order 2 would measure
-  // the tile depths and run rt_order_tiles once more inside frame_ms for nothing) — the seeded order alone
-  (void)rt_hip_group_set_option(g, "tile_order", 3);
+  // the tile depths and run rt_order_tiles inside frame_ms for nothing) — bottom row first
+  (void)rt_hip_group_set_option(g, "tile_order", 1);
   const double setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   RtStats st;
   rc = rt_hip_group_render_to_host(g, out_rgb8, &st);

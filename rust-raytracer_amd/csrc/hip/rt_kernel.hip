@@ -397,14 +397,16 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   } else {
     lane_attach_light_state(L, light_stack, reinterpret_cast<LightParked*>(lds_raw + lay.park_off) + threadIdx.x);
   }
-  auto flush_oob = [&]() {  // (after every call that may count an out-of-range texel: L.n_tex_oob is 0 again, so nothing is carried)
+  auto flush_oob = [&]() {  // (lit kernels, after every call that may count an out-of-range texel: L.n_tex_oob is 0 again, so nothing is carried)
+    if constexpr (!HL) return;
     if (L.n_tex_oob != 0u) { __hip_atomic_fetch_add(&wg_counters[2], (unsigned long long)L.n_tex_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); L.n_tex_oob = 0u; }
   };
   uint32_t n_exact = 0, n_steps = 0;  // per-lane counters (one exec-masked add each)
-  // Segments are counted per WAVE on the scalar unit (the lanes of the trace's lane mask: one s_bcnt1 per iteration), and
-  // out-of-range texel fetches — practically never — go straight to the workgroup's counter: two registers every lane
-  // carried across the walk loop (in the lit kernels exactly the pair that was spilled there: 15 scratch round trips per
-  // wave iteration, profiles/r03_codeobj.txt -> r04_codeobj.txt).
+  // LIT kernels count segments per WAVE on the scalar unit (the lanes of the trace's lane mask: one s_bcnt1 per iteration)
+  // and send out-of-range texel fetches — practically never — straight to the workgroup's counter: two registers every
+  // lane carried across the walk loop, in the lit kernels exactly the pair that was spilled there (15 scratch round trips
+  // per wave iteration, profiles/r03_codeobj.txt -> r04_codeobj.txt).  The unlit kernels have the registers and keep the
+  // per-lane counters (the scalar form cost them 0.6 %, profiles/r04_run2_ab.log).
   uint32_t w_segments = 0;
   uint32_t cnt_w_iter = 0, cnt_w_step = 0, cnt_w_test = 0, cnt_items = 0;  // wave trip counts (RT_PROFILE builds)
 
@@ -727,7 +729,8 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     const RayK rk = ray_consts(L.d);
     closest = t_max_fresh();
     best = -1;
-    w_segments += (uint32_t)__builtin_popcountll(wave_ballot(has_ray));
+    if constexpr (HL) w_segments += (uint32_t)__builtin_popcountll(wave_ballot(has_ray));
+    else if (has_ray) L.n_segments++;
     // (1) spheres outside the grid: every lane tests them.  The records are wave-uniform, so they
     // arrive by scalar loads as SGPR operands; the next record is fetched while this one is tested.
     if (n_large != 0u) {
@@ -938,15 +941,15 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     RT_PROF(0);  // (the light draw alone: booked under "refill")
 #endif
     // (d) shade the hits
-    bool finished = false;
+    int status = LANE_CONTINUE;
     if (has_ray) {
-      const int status = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u, HL ? &light_u : nullptr);
+      status = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u, HL ? &light_u : nullptr);
       flush_oob();
-      finished = status == LANE_FINISHED;
-      if constexpr (POOLED) {  // a segment repeated because the light-frame pool was exhausted is ONE segment of its path
-        const unsigned long long rep = wave_ballot(status == LANE_REPEAT);
-        if (rep) w_segments -= (uint32_t)__builtin_popcountll(rep);
-      }
+    }
+    const bool finished = status == LANE_FINISHED;
+    if constexpr (POOLED) {  // a segment repeated because the light-frame pool was exhausted is ONE segment of its path (a wave-level count: outside the divergent region)
+      const unsigned long long rep = wave_ballot(status == LANE_REPEAT);
+      if (rep) w_segments -= (uint32_t)__builtin_popcountll(rep);
     }
     RT_PROF(2);
 #if RT_SINGLE_SETTLE
@@ -977,7 +980,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 
   // counters: wave reduction, one atomic per wave
   // (segments: per wave, on lane 0; out-of-range texels went to the workgroup's counter as they happened)
-  unsigned long long c0 = lane == 0 ? w_segments : 0u, c1 = n_exact, c2 = 0ull, c3 = n_steps;
+  unsigned long long c0 = HL ? (lane == 0 ? w_segments : 0u) : L.n_segments, c1 = n_exact, c2 = HL ? 0u : L.n_tex_oob, c3 = n_steps;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     c0 += __shfl_down(c0, off); c1 += __shfl_down(c1, off); c2 += __shfl_down(c2, off); c3 += __shfl_down(c3, off);

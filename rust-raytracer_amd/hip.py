@@ -46,6 +46,7 @@ def lib():
         L.rt_hip_render.argtypes = [C.c_void_p, C.POINTER(abi.RtRowTiles), C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_hip_wait.argtypes = [C.c_void_p, C.POINTER(abi.RtStats)]
         L.rt_hip_debug_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.rt_hip_debug_tile_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.rt_hip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.rt_hip_scene_query.argtypes = [C.c_void_p, C.c_char_p]
         L.rt_hip_scene_query.restype = C.c_int64
@@ -135,6 +136,16 @@ class HipScene:
         st = abi.RtStats()
         _check(lib().rt_hip_wait(self._h, C.byref(st)))
         return st.as_dict()
+
+    def debug_tile_depth(self, cap=1 << 22):
+        """deepest camera path per pixel tile of the last measuring frame, as a 2-D array [tile rows, tile columns]"""
+        import numpy as np
+        buf = np.zeros(cap, np.uint32)
+        tx = C.c_uint32(0)
+        n = lib().rt_hip_debug_tile_depth(self._h, buf.ctypes.data, cap, C.byref(tx))
+        if n < 0:
+            _check(n)
+        return buf[:n].reshape(-1, tx.value) if tx.value and n % tx.value == 0 else buf[:n]
 
     def debug_timeline(self, max_waves=8192):
         """{start, end, queue-empty time, tail iterations | lane-iterations << 32} of every wave of the last launch, 100 MHz ticks (RT_PROFILE builds of the library only)."""
