@@ -137,7 +137,8 @@ typedef struct RtStats {
    * kernel.segments == oracle.segments - oracle.segments_discarded, exactly. */
   uint64_t segments_discarded;
   uint32_t n_gpus_used; /* rt_render_rgb8: devices the frame was sharded over (1 elsewhere) */
-  uint32_t reserved0;
+  uint32_t segments_repeated; /* lit scenes whose light records are a pool: segments traced a second time because no record was
+                               * free (counted once in `segments`; their exact tests and grid steps are counted as done); saturates */
   double gather_ms; /* rt_hip_group_*: what the frame spent NOT rendering, on device 0's clock: (start of rank 0's kernel -> frame in
                      * scanline order on device 0) minus kernel_ms of the slowest rank = launch skew between the ranks + the gather +
                      * the de-interleave.  (Until ABI v3 it started at the END of rank 0's kernel and so held the load imbalance.) */

@@ -40,7 +40,7 @@ class RtStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("exact_tests", C.c_uint64), ("tex_oob", C.c_uint64),
                 ("kernel_ms", C.c_double), ("frame_ms", C.c_double), ("grid_steps", C.c_uint64), ("wave_iters", C.c_uint64 * 4), ("prof_cycles", C.c_uint64 * 12),
-                ("segments_discarded", C.c_uint64), ("n_gpus_used", C.c_uint32), ("reserved0", C.c_uint32),
+                ("segments_discarded", C.c_uint64), ("n_gpus_used", C.c_uint32), ("segments_repeated", C.c_uint32),
                 ("gather_ms", C.c_double), ("setup_ms", C.c_double), ("group_us", C.c_double * 8)]
 
     def as_dict(self):

@@ -766,7 +766,17 @@ RT_HD void fwd_init(FwdT<false>& f) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) { f.p[i] = 0.0f; f.q[i] = 1.0f; f.lo[i] = -3.4028234663852886e38f; f.hi[i] = 3.4028234663852886e38f; }
 }
-RT_HD void fwd_init(FwdT<true>& f) { f.q[0] = f.q[1] = f.q[2] = 1.0f; }
+RT_HD void fwd_init(FwdT<true>& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // three moves where a sample begins: as plain constants the compiler kept a (1.0f, 1.0f) register pair alive across the
+  // whole path loop for this — and, in the lit kernels, spilled and reloaded it every iteration
+  float one;
+  asm volatile("v_mov_b32 %0, 1.0" : "=v"(one));
+  f.q[0] = one; f.q[1] = one; f.q[2] = one;
+#else
+  f.q[0] = f.q[1] = f.q[2] = 1.0f;
+#endif
+}
 RT_HD float fwd_eval1(const FwdT<false>& f, int i, float x) {
   float y = f.p[i] + f.q[i] * x;
   y = y < f.lo[i] ? f.lo[i] : y;
@@ -1111,8 +1121,13 @@ static_assert(sizeof(LightParked) == 80, "parked light state is 80 B per lane");
 //     The pool sits at a FIXED offset of the kernel's dynamic LDS ([128-byte bitmap][records]; rt_kernel.hip's layout
 //     asserts it) and its size travels in DevScene.light_pool_slots, so a lane carries one dword for it: the LDS byte
 //     offset of its record, 0 while it holds none.
+#ifndef RT_BLOCK
+#define RT_BLOCK 1024  // threads of the megakernel's workgroup (rt_kernel.hip): the offset below depends on its wave count
+#endif
 constexpr uint32_t LIGHT_CENTRES_LDS_MAX = 32u;       // light centres staged in LDS (24 B each); further lights are read from HBM
-constexpr uint32_t LIGHT_POOL_LDS_OFF = 65824u + LIGHT_CENTRES_LDS_MAX * 24u;  // = rt_kernel.hip lds_layout().park_off of a lit scene
+// = rt_kernel.hip lds_layout().park_off of a lit scene (asserted there, for every RT_BLOCK): flag block, tile slots (3 KB per
+// wave), exchange slots of the cooperative draw (1 KB per wave), light centres
+constexpr uint32_t LIGHT_POOL_LDS_OFF = (32u + 32u * 8u) + (RT_BLOCK / 64u) * 3u * 1024u + (RT_BLOCK / 64u) * 64u * 16u + LIGHT_CENTRES_LDS_MAX * 24u;
 constexpr uint32_t LIGHT_POOL_BITMAP_BYTES = 128u;   // 1024 slots at most
 constexpr uint32_t LIGHT_POOL_MAX_SLOTS = 1024u;
 #if defined(__HIP_DEVICE_COMPILE__)

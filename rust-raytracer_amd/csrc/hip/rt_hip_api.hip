@@ -69,6 +69,7 @@ struct RtHipScene {
   struct SeedSphere { double c[3], r; uint32_t kind; };
   std::vector<SeedSphere> seed_spheres;  // host copy of (centre, radius, material kind): what the seed projects
   std::vector<uint32_t> seed_depth;      // staging of the seeded depths (kept alive until the copy that reads it has run)
+  int force_lit = 0;       // "force_lit" option (diagnostics)
   int light_pool_cap = 0;  // "light_pool" option: cap on the light-frame pool of lit scenes (0 = as many as fit; tests shrink it to force the fall-back)
   int chunk_spp = 0;       // 0 = automatic
   int tile_batch = 0;      // 0 = automatic; else tiles a workgroup takes from the queue per atomic, 1..64
@@ -97,7 +98,7 @@ struct RtHipScene {
   int variant = 0;
   Slot& last_slot() { return slot[(n_launches + 1) & 1]; }  // the slot of the most recent launch
 };
-constexpr uint32_t RT_SLOT_COUNTERS = 24;  // segments, exact tests, tex_oob, grid steps, 4 x wave trip counts, 8 x section cycles, profile clocks
+constexpr uint32_t RT_SLOT_COUNTERS = 32;  // segments, exact tests, tex_oob, grid steps, 4 x wave trip counts, 8 x section cycles, profile clocks, (the tile-queue cursors,) [28] repeated segments
 
 extern "C" const char* rt_hip_last_error(void) { return g_err.c_str(); }
 
@@ -262,6 +263,7 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
   if (!std::strcmp(key, "tile_order")) { if (value < 0 || value > 3) return fail(RT_ERR_INVALID, "tile_order must be 0, 1, 2 or 3"); s->order_mode = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
   if (!std::strcmp(key, "order_seed")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "order_seed must be 0 (off), 1 (projection) or 2 (probe launch)"); s->order_seed = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
   if (!std::strcmp(key, "light_pool")) { if (value < 0 || value > 1024 || (value != 0 && value < 32)) return fail(RT_ERR_INVALID, "light_pool must be 0 (automatic) or 32..1024"); s->light_pool_cap = (int)value; return RT_OK; }
+  if (!std::strcmp(key, "force_lit")) { if (value < 0 || value > 1) return fail(RT_ERR_INVALID, "force_lit must be 0 or 1"); s->force_lit = (int)value; return RT_OK; }  // (diagnostics: an unlit scene through the lit kernels — what their code costs the ordinary lanes, profiles/r04_run5_lit_sections.log)
   if (!std::strcmp(key, "tile_batch")) { if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "tile_batch must be 0..64"); s->tile_batch = (int)value; return RT_OK; }
   if (!std::strcmp(key, "chunk_spp")) { if (value < 0) return fail(RT_ERR_INVALID, "chunk_spp must be >= 0"); s->chunk_spp = (int)value; return RT_OK; }
   if (!std::strcmp(key, "samples_per_pixel") || !std::strcmp(key, "max_depth")) {
@@ -385,6 +387,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   const uint32_t local_rows = rt_tiles_local_rows(s->host.height, tiles);
   if (!d_rgb8 && local_rows != 0) return fail(RT_ERR_INVALID, "null framebuffer");
   hipStream_t stream = (hipStream_t)stream_;
+  const bool has_lights = s->has_lights || s->force_lit != 0;
   // one tile-queue cursor / counter block per scene: launches of a scene are ordered on ONE stream
   // (a caller that drained the first stream itself — hipStreamSynchronize, an event — need not call rt_hip_wait first:
   //  the scene asks its OWN event, recorded behind the last launch's counter copy — never the caller's stream handle,
@@ -509,10 +512,10 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   // finds the pool exhausted repeats its segment (rt_core.h), so an undersized pool is slow, never wrong.  Scenes whose
   // tables do not fit at all, or with too many lights for the pool, gather the tables from L2 (one frame per lane).
   const rtc::GridDesc& G = ka.sc.grid;
-  const rtk::LdsLayout with_tables = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, s->has_lights);
+  const rtk::LdsLayout with_tables = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, has_lights);
   bool lds_tables = with_tables.total <= rtk::LDS_TABLES_MAX_BYTES;
   uint32_t pool_slots = 0;
-  if (!lds_tables && s->has_lights) {
+  if (!lds_tables && has_lights) {
     const uint32_t bare = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, false).total + rtc::LIGHT_CENTRES_LDS_MAX * 24u;
     uint32_t fit = 0;
     while (fit + 32u <= rtc::LIGHT_POOL_MAX_SLOTS && bare + rtk::park_bytes(fit + 32u) <= rtk::LDS_TABLES_MAX_BYTES) fit += 32u;
@@ -522,8 +525,8 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
     if (fit >= 32u && (forced || (double)fit >= 1.5 * f * (double)rtk::BLOCK)) { pool_slots = fit; lds_tables = true; }
   }
   ka.sc.light_pool_slots = pool_slots;
-  const size_t lds_bytes = lds_tables ? rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, s->has_lights, pool_slots).total
-                                      : rtk::lds_layout(0, 0, 0, false, s->has_lights).total;
+  const size_t lds_bytes = lds_tables ? rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, has_lights, pool_slots).total
+                                      : rtk::lds_layout(0, 0, 0, false, has_lights).total;
 
   // queue order: bottom of the image first; from the second frame of a tile geometry on, the tiles whose samples ran
   // deepest in the previous frame first (their paths are what a frame ends on)
@@ -581,7 +584,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
     int rc;
 #define RT_GO(HL, SIMPLE, LDS, POOLED) rc = launch_grid_t<HL, SIMPLE, LDS, POOLED>(s, ka, lds_bytes, n_items, stream)
     const bool simple = s->simple_colour;
-    if (s->has_lights) {
+    if (has_lights) {
       if (pool_slots) { if (simple) RT_GO(true, true, true, true); else RT_GO(true, false, true, true); }
       else if (lds_tables) { if (simple) RT_GO(true, true, true, false); else RT_GO(true, false, true, false); }
       else { if (simple) RT_GO(true, true, false, false); else RT_GO(true, false, false, false); }
@@ -672,6 +675,7 @@ void fill_stats(const RtHipScene* s, const RtHipScene::Slot& sl, RtStats* stats)
   stats->exact_tests = c[1];
   stats->tex_oob = c[2];
   stats->grid_steps = c[3];
+  stats->segments_repeated = c[28] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c[28];
   for (int k = 0; k < 4; ++k) stats->wave_iters[k] = c[4 + k];
   for (int k = 0; k < 8; ++k) stats->prof_cycles[k] = c[8 + k];
   if (c[14] && sl.waves) {  // profile builds: longest / shortest wave, waves launched

@@ -130,7 +130,7 @@ __host__ __device__ constexpr uint32_t park_bytes(uint32_t pool_slots) {
   return pool_slots ? LIGHT_POOL_BITMAP_BYTES + pool_slots * (uint32_t)sizeof(LightParked) : (uint32_t)BLOCK * (uint32_t)sizeof(LightParked);
 }
 constexpr uint32_t LIGHT_CENTRES_LDS_OFF = LDS_FLAGS_BYTES + LDS_SLOT_BUDGET + WAVES * 64u * 16u;  // lit scenes: centres of the first 32 lights, 3 doubles each
-static_assert(LIGHT_CENTRES_LDS_OFF + LIGHT_CENTRES_LDS_MAX * 24u == LIGHT_POOL_LDS_OFF || BLOCK != 1024, "rt_core.h LIGHT_POOL_LDS_OFF = park_off of the layout below");
+static_assert(LIGHT_CENTRES_LDS_OFF + LIGHT_CENTRES_LDS_MAX * 24u == LIGHT_POOL_LDS_OFF, "rt_core.h LIGHT_POOL_LDS_OFF = park_off of the layout below (for this RT_BLOCK)");
 __host__ __device__ inline LdsLayout lds_layout(uint32_t n_spheres, uint32_t n_cells, uint32_t n_items, bool tables, bool lights, uint32_t pool_slots = 0) {
   LdsLayout l;
   uint32_t o = LDS_FLAGS_BYTES;
@@ -584,8 +584,10 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       // max_depth == 0: ray_color returns black before tracing anything (raytracer.rs:80-82)
       const uint32_t expected = sc.max_depth != 0u ? n_valid * sc.spp : 0u;
       unsigned long long* acc = tile_acc + k * acc_stride;
-      if (lane < npx) { acc[lane * 3u] = 0ull; acc[lane * 3u + 1u] = 0ull; acc[lane * 3u + 2u] = 0ull; }
-      if (lane < 3u) hdr[k].nan_mask[lane] = 0ull;
+      unsigned long long zero;  // (made here: as a plain constant the pair was hoisted out of the path loop and, in the lit kernels, spilled)
+      { uint32_t z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); zero = ((unsigned long long)z << 32) | z; }
+      if (lane < npx) { acc[lane * 3u] = zero; acc[lane * 3u + 1u] = zero; acc[lane * 3u + 2u] = zero; }
+      if (lane < 3u) hdr[k].nan_mask[lane] = zero;
       if (lane == 3u) hdr[k].max_depth = 0u;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) {  // publish: everything before next, next before state
@@ -949,7 +951,10 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     const bool finished = status == LANE_FINISHED;
     if constexpr (POOLED) {  // a segment repeated because the light-frame pool was exhausted is ONE segment of its path (a wave-level count: outside the divergent region)
       const unsigned long long rep = wave_ballot(status == LANE_REPEAT);
-      if (rep) w_segments -= (uint32_t)__builtin_popcountll(rep);
+      if (rep) {  // (rare: the repeats go straight to the workgroup's counter — RtStats.segments_repeated — no register carries them)
+        w_segments -= (uint32_t)__builtin_popcountll(rep);
+        if (lane == 0) __hip_atomic_fetch_add(&wg_counters[28], (unsigned long long)__builtin_popcountll(rep), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
     }
     RT_PROF(2);
 #if RT_SINGLE_SETTLE
@@ -1016,6 +1021,10 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         const unsigned long long v = __hip_atomic_load(&wg_counters[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (k == 15 || k == 17) { if (v) atomicMax(&ka.counters[k], v); }
         else if (v) atomicAdd(&ka.counters[k], v);
+      }
+      if constexpr (POOLED) {
+        const unsigned long long v = __hip_atomic_load(&wg_counters[28], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (v) atomicAdd(&ka.counters[28], v);
       }
     }
   }
