@@ -171,25 +171,11 @@ __device__ __forceinline__ const KArgs& fresh_args() {
 // post their three words, and each failing lane takes those of its lowest-numbered accepted
 // attempt.  Attempt a is Philox slot 1+a whoever computes it, so the result is bit-identical to
 // the sequential loop.  `xch`: this wave's 64 x uint4 exchange slots.
-#ifndef RT_FUSED_REFILL
-#define RT_FUSED_REFILL 1
-#endif
-#ifndef RT_STASH_SPIN
-#define RT_STASH_SPIN 0
-#endif
-#ifndef RT_DEDUPE_ON_LANDING
-#define RT_DEDUPE_ON_LANDING 0  // (A/B arm, profiles/r03_run36_ab_dedupe_on_landing.log: test rounds 5.23 -> 4.80, frame +1.9 %: not adopted)
-#endif
-#ifndef RT_START_CELL_PREFIX
-#define RT_START_CELL_PREFIX 0  // (A/B arm, profiles/r03_run34_ab_start_cell_prefix.log: rounds 5.8 / 5.2 -> 5.5 / 4.7, time +-0: not adopted)
-#endif
+// A/B arms that were measured and NOT adopted are not kept in this file: their code is in the history, their numbers under
+// profiles/ — unfused refill (r02_run3), stash spin (r03_run28), start-cell prefix (r03_run34), dedupe on landing (r03_run36),
+// direct hand-out (r02_run12), single settle (r03_run14), carried walks (r02_run7), cull on landing (r04_run6, with the patch),
+// light migration (r04_run5, with the patch).
 
-#ifndef RT_HANDOUT_DIRECT
-#define RT_HANDOUT_DIRECT 0
-#endif
-#ifndef RT_SINGLE_SETTLE
-#define RT_SINGLE_SETTLE 0  // 1: ONE add_sample / count_tiles block per iteration (samples that end in the shade block settle one iteration later): 13.76 -> 13.84 ms, not adopted (profiles/r03_run14_ab_single_settle.log)
-#endif
 #ifndef RT_DEEP_PATH
 #define RT_DEEP_PATH 2u  // camera paths at least this many segments long mark their tile (SlotHdr::max_depth); 2 / 3 / 4 / 6 / 8 / 16: 13.96 / 13.98 / 13.98 / 14.01 / 14.05 / 14.5 ms (profiles/r02_run10_ab.log)
 #endif
@@ -518,12 +504,6 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       if (lane == 0) {
         uint32_t g = 0xFFFFFFFFu;  // position in queue order; n_tiles: the frame has none left; ~0: a batch is on its way
         unsigned long long old = atomicAdd(wg_stash, 1ull);
-#if RT_STASH_SPIN  // (A/B arm: wait a few us for the batch another wave is fetching instead of idling the asking lanes for an iteration)
-        for (int spin = 0; spin < RT_STASH_SPIN && (uint32_t)old > (uint32_t)(old >> 32) && lds_load(&wg_flags[0]) == 0u; ++spin) {
-          __builtin_amdgcn_s_sleep(8);
-          old = atomicAdd(wg_stash, 1ull);
-        }
-#endif
         const uint32_t s_next = (uint32_t)old, s_end = (uint32_t)(old >> 32);
         if (s_next < s_end) g = s_next;
         else if (s_next == s_end) {
@@ -644,20 +624,8 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         it_next += asked < left ? asked : left;
         const uint32_t p = w & pmask;
         const uint32_t p_px = (it_bx << wl) + (p & (tw - 1u));
-#if RT_HANDOUT_DIRECT
-        // whole frames (no row tiles): the pixel slot's scanline is plain arithmetic — no lane shuffles
-        uint32_t p_py; int p_ok;
-        if (kr.tile_rows == 0u) {
-          p_py = (it_by << kr.tile_hl) + (p >> wl);
-          p_ok = p_px < sc.width && p_py < kr.local_rows;
-        } else {
-          p_py = (uint32_t)__shfl((int)py_slot, (int)p);
-          p_ok = __shfl((int)ok_slot, (int)p);
-        }
-#else
         const uint32_t p_py = (uint32_t)__shfl((int)py_slot, (int)p);
         const int p_ok = __shfl((int)ok_slot, (int)p);
-#endif
         if (want && w < it_total && p_ok) {  // (a slot outside the image consumes its index and asks again)
           cur_p = p; my_k = it_k; L.s = it_sbeg + (w >> pl); L.ra.pixel = p_py * sc.width + p_px; L.ra.sample = L.s;
           o_px = p_px; o_py = p_py;
@@ -779,19 +747,6 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       if (walk0) {
         const uint2 e = cell_word[lin];
         it = e.x & CELL_START_MASK; end = it + (e.x >> CELL_COUNT_SHIFT); pend = e.y;
-#if RT_START_CELL_PREFIX
-        // The cell a ray STARTS in holds 0.55 of its 1.46 candidates (a bounce ray's: the sphere it just left), and 70 % of
-        // all candidates cannot be hit.  The exact test's own prefix (sphere.rs:47-53: discriminant < 0, or the sphere behind
-        // the origin — exact_hit_any_order_t's first branch, same operations) drops such a first candidate HERE, once per ray,
-        // instead of in a test round of the lock-step loop below: 6.1 -> 5.2 rounds per wave iteration
-        // (tools/analysis/walk_sim.cpp mode 6, profiles/r03_walk_sim_cull.log).  A dropped candidate counts as the exact
-        // test it replaces; a surviving one is tested in full by the loop.
-        if (it < end) {
-          const uint32_t idx0 = pend & 0xFFFFu;
-          const HitPrefix hp = exact_hit_prefix(L.o, L.d, rk, tb.geom(idx0));
-          if (!hp.may_hit) { pend = (pend >> 16) | 0xFFFF0000u; it++; last = idx0; n_exact++; }
-        }
-#endif
       }
 #ifdef RT_EXP_WALK_CAP  // (timing experiment only — WRONG image: the walk stops after this many rounds, unfinished lanes keep what they have)
       uint32_t exp_round = 0;
@@ -840,11 +795,6 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
                 it = eB.x & CELL_START_MASK; end = it + (eB.x >> CELL_COUNT_SHIFT); pend = eB.y;
                 if (eB.x == CELL_EXIT) { it = 1; end = 0; }
               }
-#if RT_DEDUPE_ON_LANDING
-              // 2.7 cells list each sphere: a lane that lands in the next cell of the sphere it tested last would spend a test
-              // round on the `idx != last` skip below — drop that candidate here (walk_sim: rounds 5.59 / 5.08 -> 5.10 / 4.48)
-              if (it < end && (pend & 0xFFFFu) == last) { pend = (pend >> 16) | 0xFFFF0000u; it++; }
-#endif
             }
           }
         }
@@ -870,12 +820,6 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 
   RT_PROF(5);
   uint32_t idle_spins = 0;
-#if RT_SINGLE_SETTLE
-  bool pending = false;  // per lane: its sample finished in the shade block of the previous iteration (radiance in L.val)
-#endif
-#if !RT_FUSED_REFILL
-#error "the unfused refill loop (round 1: a refill block of its own at the top of the iteration) was removed in round 4; its measurement: profiles/r02_run3_ab.log"
-#endif
   // Loop order: trace -> rays that left the scene finish at once (sky) -> every lane without a path takes its next
   // sample -> ONE Philox instruction stream serves the hits (unit-sphere point / Glass draw) and the new samples (camera
   // jitter) -> shade the hits -> start the new samples.  The refill used to be a block of its own at the top of the loop
@@ -894,21 +838,6 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     // (a) a ray that left the scene ends its sample here (raytracer.rs:133-163); light rays return to their parent in (d)
     bool miss = has_ray && best < 0;
     if constexpr (HL) miss = miss && !(L.in_light & 1u);
-#if RT_SINGLE_SETTLE
-    // ONE settle block per iteration: the samples that ended in the sky now, and those that ended in last iteration's shade
-    // block (`pending`: absorbed, a Light hit, depth exhausted — a few % of the lanes, which sit out this trace)
-    if (wave_any(miss)) {
-      if (miss) {
-        lane_finish_sample(L, sky_color(fresh_args().sc, L.d, L.n_tex_oob));
-        flush_oob();
-        has_ray = false;
-      }
-    }
-    const bool settle = miss || pending;
-    if (wave_any(settle)) add_sample(settle);
-    count_tiles(settle, my_k);
-    pending = false;
-#else
     const uint32_t k_miss = my_k;
     if (wave_any(miss)) {
       if (miss) {
@@ -918,7 +847,6 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       }
       add_sample(miss);
     }
-#endif
     RT_PROF(4);
     // (b) every lane without a path takes its next sample
     uint32_t n_px = 0, n_py = 0;
@@ -957,24 +885,16 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       }
     }
     RT_PROF(2);
-#if RT_SINGLE_SETTLE
-    if (finished) { has_ray = false; pending = true; }
-#else
     if (wave_any(finished)) {
       if (finished) has_ray = false;
       add_sample(finished);
     }
     count_tiles(miss || finished, miss ? k_miss : my_k);
-#endif
     RT_PROF(4);
     // (e) the new samples start (raytracer.rs:199-201, camera.rs:79-84)
     if (fresh) { lane_begin_sample_w(fresh_args().sc, L, n_px, n_py, cam_w); has_ray = true; }
     RT_PROF(0);
-#if RT_SINGLE_SETTLE
-    if (!wave_any(has_ray || pending)) {
-#else
     if (!wave_any(has_ray)) {
-#endif
       // nothing in flight.  Done when the frame has nothing left; otherwise (all tile slots are busy with other waves'
       // long paths) wait a little and ask again — bounded, a wave may always retire: the samples it traced are already
       // counted in their tiles.
