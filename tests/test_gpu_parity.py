@@ -696,9 +696,9 @@ def test_cli_multi_gpu_env(tmp_path):
 def test_scene_is_not_reentrant_across_streams(pkg, load_scene, torch_cuda):
     """rt_abi.h: one tile queue / counter block per RtHipScene — a launch on a second stream before rt_hip_wait is refused"""
     torch = torch_cuda
-    sc = load_scene("cover", 64, 40, 2, 50)
+    sc = load_scene("cover", 600, 400, 64, 50)                 # (milliseconds of work per launch: the refusal below must not race the kernels' end)
     gs = pkg.hip.HipScene(sc.ptr, 0)
-    a = torch.zeros((40, 64, 3), dtype=torch.uint8, device="cuda:0")
+    a = torch.zeros((400, 600, 3), dtype=torch.uint8, device="cuda:0")
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     gs.render(a.data_ptr(), 0, None, s1.cuda_stream)
     gs.render(a.data_ptr(), 0, None, s1.cuda_stream)           # same stream, back to back: fine
