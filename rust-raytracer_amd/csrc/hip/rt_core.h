@@ -1145,14 +1145,24 @@ struct LightState<true, false> {
 template <>
 struct LightState<true, true> {
   LightStack<true>* stack;
-  uint32_t where;          // LDS byte offset of the lane's pool record while it is summing over the lights, else 0
-  int top;
+  // LDS byte offset of the lane's pool record while it is summing over the lights, else 0 — a multiple of 16 — with the
+  // nesting level (`top`, 0 .. RT_MAX_LIGHT_NEST - 1 < 16) in its low four bits: one register for both (the lit kernels
+  // sit on the 128-register edge, and `where` alone was the last value they spilled)
+  uint32_t wt;
 };
+static_assert(RT_MAX_LIGHT_NEST <= 16u && (LIGHT_POOL_LDS_OFF + LIGHT_POOL_BITMAP_BYTES) % 16u == 0u && sizeof(LightParked) % 16u == 0u,
+              "the nesting level shares a register with the record offset: offsets are multiples of 16");
+RT_HD uint32_t ls_where(const LightState<true, true>& ls) { return ls.wt & ~15u; }
+RT_HD int ls_top(const LightState<true, true>& ls) { return (int)(ls.wt & 15u); }
+RT_HD void ls_set_where(LightState<true, true>& ls, uint32_t where) { ls.wt = where | (ls.wt & 15u); }
+RT_HD void ls_set_top(LightState<true, true>& ls, int t) { ls.wt = (ls.wt & ~15u) | (uint32_t)t; }
+RT_HD int ls_top(const LightState<true, false>& ls) { return ls.top; }
+RT_HD void ls_set_top(LightState<true, false>& ls, int t) { ls.top = t; }
 RT_HD LightParked& light_frame(LightState<true, false>& ls) { return *ls.pk; }
 RT_HD bool light_frame_acquire(LightState<true, false>&, uint32_t, uint32_t) { return true; }
 RT_HD void light_frame_release(LightState<true, false>&) {}
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ LightParked& light_frame(LightState<true, true>& ls) { return *reinterpret_cast<LightParked*>(rt_lds_dyn + ls.where); }
+__device__ __forceinline__ LightParked& light_frame(LightState<true, true>& ls) { return *reinterpret_cast<LightParked*>(rt_lds_dyn + ls_where(ls)); }
 // a camera-path hit starts summing over the lights: take a pool record (n_slots of them, a multiple of 32); false: none free
 __device__ __forceinline__ bool light_frame_acquire(LightState<true, true>& ls, uint32_t n_slots, uint32_t seed) {
   uint32_t* const bitmap = reinterpret_cast<uint32_t*>(rt_lds_dyn + LIGHT_POOL_LDS_OFF);
@@ -1163,7 +1173,7 @@ __device__ __forceinline__ bool light_frame_acquire(LightState<true, true>& ls, 
     while (cur != 0xFFFFFFFFu) {
       const uint32_t b = (uint32_t)__builtin_ctz(~cur);
       const uint32_t old = __hip_atomic_fetch_or(&bitmap[w], 1u << b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (!((old >> b) & 1u)) { ls.where = LIGHT_POOL_LDS_OFF + LIGHT_POOL_BITMAP_BYTES + ((w << 5) + b) * (uint32_t)sizeof(LightParked); return true; }
+      if (!((old >> b) & 1u)) { ls_set_where(ls, LIGHT_POOL_LDS_OFF + LIGHT_POOL_BITMAP_BYTES + ((w << 5) + b) * (uint32_t)sizeof(LightParked)); return true; }
       cur = old | (1u << b);
     }
     w = w + 1u == words ? 0u : w + 1u;
@@ -1172,10 +1182,10 @@ __device__ __forceinline__ bool light_frame_acquire(LightState<true, true>& ls, 
 }
 // ... and that activation is back on the camera path: give the record back (after the last read of it)
 __device__ __forceinline__ void light_frame_release(LightState<true, true>& ls) {
-  const uint32_t slot = (ls.where - LIGHT_POOL_LDS_OFF - LIGHT_POOL_BITMAP_BYTES) / (uint32_t)sizeof(LightParked);
+  const uint32_t slot = (ls_where(ls) - LIGHT_POOL_LDS_OFF - LIGHT_POOL_BITMAP_BYTES) / (uint32_t)sizeof(LightParked);
   uint32_t* const bitmap = reinterpret_cast<uint32_t*>(rt_lds_dyn + LIGHT_POOL_LDS_OFF);
   __hip_atomic_fetch_and(&bitmap[slot >> 5], ~(1u << (slot & 31u)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  ls.where = 0u;
+  ls_set_where(ls, 0u);
 }
 #else  // (host passes: the pooled kernel exists on the device only; the host simulator runs the direct form)
 inline LightParked& light_frame(LightState<true, true>&) { static LightParked never; return never; }
@@ -1185,31 +1195,31 @@ inline void light_frame_release(LightState<true, true>&) {}
 
 template <bool P>
 RT_HD void light_frame_push(LightState<true, P>& ls) {  // stack[top] <- cur; ++top
-  const int t = ls.top;
+  const int t = ls_top(ls);
   LightStack<true>& k = *ls.stack;
   const LightFrame& c = light_frame(ls).cur;
   k.P[t][0] = c.P.x; k.P[t][1] = c.P.y; k.P[t][2] = c.P.z;
   k.a[t][0] = c.a[0]; k.a[t][1] = c.a[1]; k.a[t][2] = c.a[2];
   k.a[t][3] = c.acc[0]; k.a[t][4] = c.acc[1]; k.a[t][5] = c.acc[2];
   k.j[t][0] = c.j; k.j[t][1] = c.node;
-  ls.top = t + 1;
+  ls_set_top(ls, t + 1);
 }
 template <bool P>
 RT_HD void light_frame_pop(LightState<true, P>& ls) {  // --top; cur <- stack[top]
-  const int t = ls.top - 1;
+  const int t = ls_top(ls) - 1;
   const LightStack<true>& k = *ls.stack;
   LightFrame& c = light_frame(ls).cur;
   c.P.x = k.P[t][0]; c.P.y = k.P[t][1]; c.P.z = k.P[t][2];
   c.a[0] = k.a[t][0]; c.a[1] = k.a[t][1]; c.a[2] = k.a[t][2];
   c.acc[0] = k.a[t][3]; c.acc[1] = k.a[t][4]; c.acc[2] = k.a[t][5];
   c.j = k.j[t][0]; c.node = k.j[t][1];
-  ls.top = t;
+  ls_set_top(ls, t);
 }
 // Lane setup: `stk` and `*pk` must outlive the lane.
 template <class LaneT> RT_HD void lane_attach_light_state(LaneT&, LightStack<false>&, LightParked*) {}
 template <class LaneT> RT_HD void lane_attach_light_state(LaneT& L, LightStack<true>& stk, LightParked* pk) { L.ls.stack = &stk; L.ls.pk = pk; L.ls.top = 0; }
 template <class LaneT> RT_HD void lane_attach_light_pool(LaneT& L, LightStack<true>& stk) {
-  L.ls.stack = &stk; L.ls.where = 0u; L.ls.top = 0;
+  L.ls.stack = &stk; L.ls.wt = 0u;
 }
 
 template <bool HAS_LIGHTS, bool SIMPLE = false, bool POOLED = false>
@@ -1382,9 +1392,12 @@ RT_HD bool lane_light_return(const DevScene& sc, const Tables& tb, LaneT& L, Rgb
     f.acc[0] += f.a[0] * tc.r; f.acc[1] += f.a[1] * tc.g; f.acc[2] += f.a[2] * tc.b;
     f.j += 1;
     if (f.j < sc.n_lights) { lane_aim_light(sc, tb, L); return false; }
-    float nl = (float)sc.n_lights;
-    float light[3] = {f.acc[0] / nl, f.acc[1] / nl, f.acc[2] / nl};
-    if (L.ls.top == 0) {  // back on the camera path: clamp(light + albedo*child), child = scattered ray
+    float light[3] = {f.acc[0], f.acc[1], f.acc[2]};
+    if (sc.n_lights != 1u) {  // raytracer.rs:112-114 `/= lights.len() as f32`: x / 1.0 is x — one light (every shipped scene) skips three IEEE divisions (wave-uniform branch)
+      const float nl = (float)sc.n_lights;
+      light[0] = f.acc[0] / nl; light[1] = f.acc[1] / nl; light[2] = f.acc[2] / nl;
+    }
+    if (ls_top(L.ls) == 0) {  // back on the camera path: clamp(light + albedo*child), child = scattered ray
       const bool fin = lane_continue_main(sc, L, f.P, light_frame(L.ls).saved_d, light, f.a, true);
       light_frame_release(L.ls);  // (after the last read of the frame)
       return fin;
@@ -1407,7 +1420,7 @@ RT_HD double lane_light_draw(const LaneT& L) {
 template <class LaneT>
 RT_HD bool lane_may_sample_lights(const DevScene& sc, const LaneT& L) {
   if constexpr (LaneT::kLights) {
-    return (L.in_light & 1u) ? (uint32_t)L.ls.top + 1u < RT_MAX_LIGHT_NEST : (sc.max_depth >= 2 && L.k < 2);
+    return (L.in_light & 1u) ? (uint32_t)ls_top(L.ls) + 1u < RT_MAX_LIGHT_NEST : (sc.max_depth >= 2 && L.k < 2);
   }
   return false;
 }
@@ -1479,7 +1492,7 @@ RT_HD int lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, do
         // (pooled kernels: no record free -> nothing has changed yet: the same segment is traced again; the caller counts
         //  the segment once — its exact tests and grid steps are the work actually done, and counted as such)
         if (!light_frame_acquire(L.ls, sc.light_pool_slots, L.ra.pixel + L.ra.sample)) return LANE_REPEAT;
-        L.ls.top = 0;
+        ls_set_top(L.ls, 0);
         light_frame(L.ls).saved_d = out_dir;
       }
       LightFrame& f = light_frame(L.ls).cur;
