@@ -509,24 +509,20 @@ def run_ranks(args):
             # `value` is the steady state of repeated frames of one view (the queue order learned from the previous frame,
             # DESIGN.md §4.1); a one-shot render (rt_render_rgb8, the reference's one frame per process) has no previous
             # frame: the same kernel with the fixed bottom-row-first order, best of 3
-            # a one-shot render (rt_render_rgb8, the reference's one frame per process) has no previous frame: bottom row
-            # first — beside it the two seeded orders of round 4 (projection guess / probe launch; both slower, off by default)
+            # a one-shot render (rt_render_rgb8, the reference's one frame per process) has no previous frame: the same kernel
+            # with the fixed bottom-row-first order — the FIRST frame of a fresh scene, best of 3 (the seeded orders of round 4
+            # — projection guess, probe launch — are slower and off: tools/first_frame.py, profiles/r04_run3_first_frame_orders.log)
             fb1 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
-            first = {}
-            for name, opts in (("bottom_first", {"tile_order": 1}), ("seeded_by_projection", {"tile_order": 3, "order_seed": 1}), ("seeded_by_probe", {"tile_order": 3, "order_seed": 2})):
-                k1 = []
-                for _ in range(4):   # (a fresh scene every time: a seeded order is kept by the scene it was built for)
-                    g1 = hip.HipScene(sc.ptr, local_rank)
-                    for k_, v_ in opts.items():
-                        g1.set_option(k_, v_)
-                    if args.variant:
-                        g1.set_option("variant", args.variant)
-                    g1.render(fb1.data_ptr(), 0, None, stream.cuda_stream)
-                    k1.append(g1.wait()["kernel_ms"])
-                    g1.close()
-                first[name] = round(min(k1[1:]), 4)
-            out["first_frame_kernel_ms"] = first["bottom_first"]
-            out["first_frame_alternatives_ms"] = first
+            k1 = []
+            for _ in range(4):
+                g1 = hip.HipScene(sc.ptr, local_rank)
+                g1.set_option("tile_order", 1)
+                if args.variant:
+                    g1.set_option("variant", args.variant)
+                g1.render(fb1.data_ptr(), 0, None, stream.cuda_stream)
+                k1.append(g1.wait()["kernel_ms"])
+                g1.close()
+            out["first_frame_kernel_ms"] = round(min(k1[1:]), 4)
             out["value_note"] = ("steady state: frame i uses the tile-queue order learned from frame i-1 of the same view; first_frame_kernel_ms = a scene's "
                                  "FIRST frame (what a one-shot rt_render_rgb8 gets): bottom row first; the measured order knows which tiles hold this seed's rare 50-segment paths, which no seed predicts (DESIGN.md §4.1)")
             out["git_head"] = _git_head()
