@@ -1171,3 +1171,26 @@ def test_fresh_group_first_frame_is_never_traced_twice(pkg, load_scene):
         grp.close()
         want = want or st["segments"]
         assert st["segments"] == want, (world, st["segments"], want)
+
+
+def test_scene_query_and_tile_depth_diagnostics(pkg, load_scene, torch_cuda):
+    """rt_hip_scene_query (what bench.py prices the tables with) and rt_hip_debug_tile_depth (the per-tile path depths the
+    queue order is sorted by): the cover scene has its 484 spheres, a grid and a `large` list; the first (measuring) frame
+    leaves a depth per tile — 0 where no path bounces (sky), up to max_depth where glass is."""
+    torch = torch_cuda
+    sc = load_scene("cover", 240, 160, 8, 50)
+    gs = pkg.hip.HipScene(sc.ptr, 0)
+    assert gs.query("n_spheres") == 484 and gs.query("n_lights") == 0 and gs.query("no_such_key") == -1
+    cells, items, large = gs.query("grid_cells"), gs.query("grid_items"), gs.query("grid_large")
+    assert cells > 1000 and items >= 480 and 1 <= large <= 8
+    assert gs.query("table_bytes") == 484 * (32 + 48) + cells * 8 + items * 2 and gs.query("texel_bytes") == 0
+    fb = torch.zeros((160, 240, 3), dtype=torch.uint8, device="cuda:0")
+    gs.render(fb.data_ptr(), 0, None, torch.cuda.current_stream().cuda_stream)
+    gs.wait()
+    d = gs.debug_tile_depth()
+    assert d.ndim == 2 and d.size * (4 ** 0) >= 1 and int(d.max()) >= 10 and int(d.max()) <= 50 and (d == 0).any()
+    gs.close()
+    tex = load_scene("test", 64, 48, 1, 8)
+    gt = pkg.hip.HipScene(tex.ptr, 0)
+    assert gt.query("n_lights") == 1 and gt.query("texel_bytes") > 4 * 2048 * 1024 and gt.query("grid_cells") == 0
+    gt.close()
