@@ -712,9 +712,6 @@ RT_HD Rgb texel_fetch(const DevScene& sc, const SphereMat& m, uint64_t col, uint
   uint64_t base_pixel = 3 * (row * m.tex_w + col);
   if (m.tex_nbytes < 3) { tex_oob++; return rgb(0.f, 0.f, 0.f); }
   if (base_pixel > m.tex_nbytes - 3) { tex_oob++; base_pixel = (m.tex_nbytes / 3 - 1) * 3; }
-#ifdef RT_EXP_TEX_HOT  // (timing experiment only — WRONG image: every texel fetch hits the same few cache lines)
-  base_pixel &= 1023u;
-#endif
   const uint8_t* px = sc.tex + m.tex_off + base_pixel;
   return rgb(rt_div255f((float)px[0]), rt_div255f((float)px[1]), rt_div255f((float)px[2]));
 }
@@ -735,9 +732,6 @@ RT_HD Rgb texture_albedo(const DevScene& sc, const SphereMat& m, double u, doubl
     const unsigned long long pi = (unsigned long long)sat_u32(fv) * (unsigned long long)(uint32_t)m.tex_w + (unsigned long long)sat_u32(fu);
     uint32_t idx = (uint32_t)pi;
     if (pi > (unsigned long long)m.texel_last) { tex_oob++; idx = m.texel_last; }
-#ifdef RT_EXP_TEX_HOT  // (timing experiment only — WRONG image: every texel fetch hits the same few cache lines)
-    idx &= 255u;
-#endif
     return rgb_of_texel(sc.tex4[m.texel_off + idx]);
   }
   return texel_fetch(sc, m, sat_u64(fu), sat_u64(fv), tex_oob);
@@ -829,9 +823,6 @@ RT_HD Rgb sky_color(const DevScene& sc, V3 d, uint32_t& tex_oob) {
     const uint32_t last = (uint32_t)sc.sky_w * (uint32_t)sc.sky_h - 1u;
     uint32_t idx = (uint32_t)rt_mul24((int)y, (int)(uint32_t)sc.sky_w) + x;
     if (idx > last) { tex_oob++; idx = last; }
-#ifdef RT_EXP_SKY_HOT  // (timing experiment only — WRONG image: every sky fetch hits the same few cache lines)
-    idx &= 255u;
-#endif
     const uint32_t w = sc.sky4[idx];
     return rgb(rt_div255f(0.7f * (float)(w & 0xFFu)), rt_div255f(0.7f * (float)((w >> 8) & 0xFFu)), rt_div255f(0.7f * (float)((w >> 16) & 0xFFu)));
   }
@@ -839,9 +830,6 @@ RT_HD Rgb sky_color(const DevScene& sc, V3 d, uint32_t& tex_oob) {
   uint64_t y = sat_u64_f32(yf);
   uint64_t base = (y * sc.sky_w + x) * 3;
   if (base + 2 >= sc.sky_w * sc.sky_h * 3) { tex_oob++; base = (sc.sky_w * sc.sky_h - 1) * 3; }
-#ifdef RT_EXP_SKY_HOT  // (timing experiment only — WRONG image: every sky fetch hits the same few cache lines)
-  base &= 1023u;
-#endif
   const uint8_t* px = sc.sky + base;
   return rgb(rt_div255f(0.7f * (float)px[0]), rt_div255f(0.7f * (float)px[1]), rt_div255f(0.7f * (float)px[2]));
 }
@@ -1025,13 +1013,11 @@ RT_HD int scatter(const DevScene& sc, const RngAddr& ra, uint32_t node, V3 in_di
       if (near_zero(sd)) sd = h.normal;
       V3 target = add(h.point, sd);
       out_dir = sub(target, h.point);  // (p + d) - p, as the reference computes it
-#ifndef RT_EXP_NO_TEXEL  // (timing experiment only — WRONG image when defined: Texture spheres shade with their plain albedo)
       if (m.kind == RT_MAT_TEXTURE) {
         const UV uv = sphere_uv_for_texel(h.point, g, sc.mat, idx);
         Rgb a = texture_albedo(sc, sc.mat[idx], uv.u, uv.v, tex_oob);
         att[0] = a.r; att[1] = a.g; att[2] = a.b;
       }
-#endif
       return SCATTER_RAY;
     }
     case RT_MAT_METAL: {  // :115-129
@@ -1278,9 +1264,6 @@ RT_HD void lane_begin_sample(const DevScene& sc, LaneT& L, uint32_t px, uint32_t
 constexpr uint32_t LANE_HAS_BASE = 2u;
 template <class LaneT>
 RT_HD void lane_compose(LaneT& L, const float light[3], const float att[3], bool has_light) {
-#ifdef RT_EXP_NO_BASE  // (timing experiment only — WRONG image: what the memory-resident base costs)
-  has_light = false;
-#endif
   if constexpr (LaneT::kLights && LaneT::kSimple) {
     if (has_light) {  // level L.k (0 or 1) contributes `light`: create / update the base
       float* b = L.ls.stack->base;

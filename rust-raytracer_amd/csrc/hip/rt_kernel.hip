@@ -748,14 +748,8 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         const uint2 e = cell_word[lin];
         it = e.x & CELL_START_MASK; end = it + (e.x >> CELL_COUNT_SHIFT); pend = e.y;
       }
-#ifdef RT_EXP_WALK_CAP  // (timing experiment only — WRONG image: the walk stops after this many rounds, unfinished lanes keep what they have)
-      uint32_t exp_round = 0;
-#endif
       for (;;) {
         if (!wave_any(it <= end)) break;
-#ifdef RT_EXP_WALK_CAP
-        if (exp_round++ >= RT_EXP_WALK_CAP) break;
-#endif
         // (a) lanes whose cell is exhausted: finished, or on to the next non-empty cell.  The next
         // TWO cells along the ray are computed and fetched together (one LDS round trip), the
         // second one is used only if the first is empty.
