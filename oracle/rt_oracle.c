@@ -74,9 +74,12 @@ void rt_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint3
 
 /* RNG addressing: counter = (pixel, sample, node, slot), key = seed.
  *   node 0xFFFFFFFF, slot 0 : camera jitter xi1, xi2                 (raytracer.rs:199-200)
- *   node n, slot 0          : u01[0] = Glass reflectance draw        (materials.rs:189)
- *                             u01[1] = light-sampling draw           (raytracer.rs:100)
- *   node n, slot 1+a        : attempt a of random_in_unit_sphere     (point3d.rs:31-38)
+ *   node n, slot 0          : words 0,1 = Glass reflectance draw     (materials.rs:189)
+ *                             words 2,3 = light-sampling draw of a Glass hit (raytracer.rs:100);
+ *                             word 2 = the LOW word of every other hit's light-sampling draw
+ *   node n, slot 1+a        : words 0..2 = attempt a of random_in_unit_sphere (point3d.rs:31-38)
+ *   node n, slot 1          : word 3 = the HIGH word of the light-sampling draw of a hit that is not Glass
+ *                             (the word attempt 0 leaves over: one Philox call serves both draws of such a hit)
  * node = k for the k-th segment of the camera path, rt_child_node() for nested light rays. */
 #define NODE_CAMERA 0xFFFFFFFFu
 
@@ -363,8 +366,12 @@ static Rgb ray_color(Ctx* c, Ray ray, uint32_t max_depth, uint32_t depth, uint32
      * release builds (the README's `cargo run --release`) and the test is false. */
     int depth_ok = max_depth >= 2 && depth > max_depth - 2;
     if (c->n_lights > 0 && depth_ok && nest < RT_MAX_LIGHT_NEST) {
+      /* the draw's words: see "RNG addressing" above (a Glass hit's come from its slot-0 call, any other hit's high word
+       * is the fourth word of attempt 0's call) */
       uint32_t w[4]; rng_words(c, node, 0, w);
-      if (u01_53(w[2], w[3]) > (1.0 - (double)c->n_lights * prob)) {
+      uint32_t high = w[3];
+      if (sc->spheres[rec.idx].kind != RT_MAT_GLASS) { uint32_t a0[4]; rng_words(c, node, 1, a0); high = a0[3]; }
+      if (u01_53(w[2], high) > (1.0 - (double)c->n_lights * prob)) {
         if (st == SCATTER_EMIT) c->discarding++;  /* (counter only: :124 returns `albedo`, not the light sum) */
         for (uint32_t j = 0; j < c->n_lights; ++j) {                                    /* :103-110 */
           const RtSphere* light = &sc->spheres[c->lights[j]];

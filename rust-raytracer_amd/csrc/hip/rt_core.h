@@ -285,8 +285,11 @@ RT_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
 // RNG addressing: counter = (pixel, sample, node, slot), key = seed.
 //   node NODE_CAMERA, slot 0 : camera jitter                      (raytracer.rs:199-200)
 //   node n, slot 0           : .x.y Glass reflectance draw         (materials.rs:189)
-//                              .z.w light-sampling draw            (raytracer.rs:100)
-//   node n, slot 1+a         : attempt a of random_in_unit_sphere  (point3d.rs:31-38)
+//                              .z.w light-sampling draw of a Glass hit (raytracer.rs:100); .z = the LOW word of every other hit's
+//   node n, slot 1+a         : .x.y.z attempt a of random_in_unit_sphere (point3d.rs:31-38)
+//   node n, slot 1           : .w = the HIGH word of the light-sampling draw of a hit that is not Glass: the word attempt 0's
+//                              call leaves over, so a lit kernel decides `draw > threshold` without a second Philox stream —
+//                              the low word (slot 0) matters only when the high word alone leaves the comparison open (2^-32)
 constexpr uint32_t NODE_CAMERA = 0xFFFFFFFFu;
 RT_HD double u01_53(uint32_t lo, uint32_t hi) {  // rand 0.8 Standard f64: (u64 >> 11) * 2^-53
   // u >> 11 = h * 2^32 + l with h = hi >> 11 (21 bits), l = the 32 bits below: the value h * 2^-21 + l * 2^-53 is a 53-bit
@@ -1391,15 +1394,17 @@ RT_HD bool lane_light_return(const DevScene& sc, const Tables& tb, LaneT& L, Rgb
   }
 }
 
-// The light-sampling draw of the current node (raytracer.rs:100: slot 0, words z w), and whether a hit of this lane's
+// The light-sampling draw of the current node (raytracer.rs:100; addressing above), and whether a hit of this lane's
 // current ray could need it at all: a camera-path hit of the first two levels, or a light ray's hit below the nesting cap.
-// The kernel draws it for all such lanes in ONE instruction stream before lane_shade (light_u_pre) — two Philox streams
-// inlined in two branches that a few lanes take cost every wave iteration ~160 instructions.
+// The kernel hands it in (light_u_pre) from the words its one Philox stream of the iteration has already made — two Philox
+// streams inlined in two branches that a few lanes take cost every wave iteration ~160 instructions, one stream of its own ~4 %.
 template <class LaneT>
-RT_HD double lane_light_draw(const LaneT& L) {
+RT_HD double lane_light_draw(const LaneT& L, bool glass) {
   const U4 w = rng(L.ra, L.node, 0);
-  return u01_53(w.z, w.w);
+  return u01_53(w.z, glass ? w.w : rng(L.ra, L.node, 1).w);
 }
+// The low word of a light-sampling draw whose high word alone does not decide it (a real call: 2^-32 of the draws)
+RT_HD_COLD uint32_t light_draw_low_word(RngAddr ra, uint32_t node) { return rng(ra, node, 0).z; }
 template <class LaneT>
 RT_HD bool lane_may_sample_lights(const DevScene& sc, const LaneT& L) {
   if constexpr (LaneT::kLights) {
@@ -1459,7 +1464,7 @@ RT_HD int lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, do
         // wrap); a light ray's own hit: the same test one level down, below the nesting cap
         bool sample = false;
         if (lane_may_sample_lights(sc, L)) {
-          const double lu = light_u_pre ? *light_u_pre : lane_light_draw(L);
+          const double lu = light_u_pre ? *light_u_pre : lane_light_draw(L, m.kind == RT_MAT_GLASS);
           sample = lu > sc.light_thr[m.kind == RT_MAT_GLASS ? 1 : 0];  // 1.0 - n_lights as f64 * prob (fill_dev_scene)
         }
         if (sample) act = ACT_SAMPLE;

@@ -192,7 +192,8 @@ __device__ __constant__ const uint32_t kCeil65536Over[65] = {
     0, 65536, 32768, 21846, 16384, 13108, 10923, 9363, 8192, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4096, 3856, 3641, 3450, 3277, 3121,
     2979, 2850, 2731, 2622, 2521, 2428, 2341, 2260, 2185, 2115, 2048, 1986, 1928, 1873, 1821, 1772, 1725, 1681, 1639, 1599, 1561, 1525,
     1490, 1457, 1425, 1395, 1366, 1338, 1311, 1286, 1261, 1237, 1214, 1192, 1171, 1150, 1130, 1111, 1093, 1075, 1058, 1041, 1024};
-// Glass lanes also get the light-sampling draw of their node back (same Philox call, words z w: raytracer.rs:100) in `glass_lu`.
+// Glass lanes also get the light-sampling draw of their node back (same Philox call, words z w: raytracer.rs:100) in `glass_lu`;
+// every other lane's attempt-0 call leaves its fourth word in `cam_w.w`: the high word of ITS light-sampling draw.
 __device__ __forceinline__ V3 coop_random_in_unit_sphere(bool need, bool glass, bool fresh, const RngAddr& ra, uint32_t node, uint32_t lane,
                                                          uint4* xch, double& glass_u, double& glass_lu, U4& cam_w) {
   auto point = [](uint32_t x, uint32_t y, uint32_t z) { return v3(range_m1_1(x), range_m1_1(y), range_m1_1(z)); };
@@ -855,10 +856,16 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 #ifdef RT_PROF_SPLIT  // (experiment builds: the random draws are booked under "item", lane_shade proper stays under "lane_shade")
     RT_PROF(5);
 #endif
-    if constexpr (HL) {  // the light-sampling draw (raytracer.rs:100) of every hit that may need it: one instruction stream
-      const bool want = hit_kind != 0xFFFFFFFFu && hit_kind != RT_MAT_GLASS && hit_kind != RT_MAT_LIGHT && lane_may_sample_lights(fresh_args().sc, L);
-      if (wave_any(want)) {
-        if (want) light_u = lane_light_draw(L);
+    if constexpr (HL) {
+      // The light-sampling draw (raytracer.rs:100) of a hit that is not Glass: its HIGH word is the word attempt 0's Philox call
+      // left over (slot 1, .w — rt_core.h, RNG addressing), so `draw > threshold` is decided here without a Philox stream of its
+      // own (rounds 3/4 ran one in every wave iteration: ~4 % of a lit frame) unless the high word alone leaves it open: 2^-32
+      // of the draws fetch their low word through a real call.  (Glass hits: `light_u` came back from their slot-0 call.)
+      if (hit_kind != RT_MAT_GLASS) {  // (lanes without a hit compute it too and never read it)
+        const double thr = fresh_args().sc.light_thr[0];
+        const double u_lo = u01_53(0u, cam_w.w), u_hi = u01_53(0xFFFFFFFFu, cam_w.w);
+        light_u = u_lo;
+        if (hit_kind != 0xFFFFFFFFu && (u_lo > thr) != (u_hi > thr)) light_u = u01_53(light_draw_low_word(L.ra, L.node), cam_w.w);
       }
     }
 #ifdef RT_PROF_SPLIT

@@ -525,3 +525,30 @@ def test_texel_paths_agree_with_the_oracle(what, changes, hostsim, oracle, abi, 
     assert st["segments"] == o_st["segments"] - o_st["segments_discarded"]
     if changes.get("tex_h") == 5000:
         assert st["tex_oob"] > 0
+
+
+def test_light_draw_words_and_the_open_high_word(hostsim, oracle, abi, host):
+    """The light-sampling draw's 53 bits (raytracer.rs:100): a Glass hit takes words 2,3 of its slot-0 call, every other hit the
+    HIGH word from word 3 of attempt 0's call (slot 1) and the low word from slot 0 word 2 (oracle/rt_oracle.c, "RNG addressing").
+    tests/light_draw_cases.py holds seeds whose pixel-0 draw has the one high word in 2^32 that does not decide the comparison:
+    (1) the fixture is what it says (through the oracle's own Philox), (2) the low word decides as recorded, (3) kernel logic
+    (CPU build: both words always drawn) and oracle trace the same paths there.  The kernel's own decision from the high word, and
+    its call for the low one, is the GPU test of the same name."""
+    import ctypes as C
+    import light_draw_cases as ldc
+    L = oracle.lib(abi)
+    assert ldc.OPEN_HIGH_WORD == 3865470566 and 0 < ldc.LOW_PART_BOUND < (1 << 21)
+    for seed, samples in ldc.OPEN_SEEDS.items():
+        u01, rg = (C.c_double * 2)(), (C.c_double * 3)()
+        L.rt_oracle_draws(seed, 0, 0, 0, 1, u01, rg)
+        assert int(u01[1] * 2.0 ** 32) == ldc.OPEN_HIGH_WORD                  # slot 1, word 3
+        L.rt_oracle_draws(seed, 0, 0, 0, 0, u01, rg)
+        low_part = int(u01[1] * 2.0 ** 53) & 0x1FFFFF                         # slot 0, word 2 >> 11
+        assert (low_part >= ldc.LOW_PART_BOUND) == samples
+        sc = host.Scene.loads(ldc.scene_json())
+        sc.c.seed = seed
+        o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+        rgb, lin, st = hostsim.render(sc.ptr, None, 3)
+        assert_parity(rgb, lin, o_rgb, o_lin, f"seed {seed}")
+        assert st["segments"] == o_st["segments"] - o_st["segments_discarded"]
+    assert len(set(ldc.OPEN_SEEDS.values())) == 2

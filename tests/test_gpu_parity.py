@@ -291,6 +291,23 @@ def test_many_lights_nested_sampling(gpu_render, oracle, abi, host):
         assert o_st["segments_discarded"] > 0 and st["segments"] == o_st["segments"] - o_st["segments_discarded"]
 
 
+def test_light_draw_words_and_the_open_high_word(gpu_render, oracle, abi, host):
+    """A lit kernel decides the light-sampling draw (raytracer.rs:100) of a hit that is not Glass from its HIGH word — the word
+    attempt 0's Philox call leaves over — and calls for the low word only when that leaves `draw > threshold` open: one high word
+    in 2^32.  tests/light_draw_cases.py holds seeds (found offline) that put pixel 0's first hit there, with the low word deciding
+    either way: the kernel must trace the oracle's paths — a decision taken from the high word alone misses or adds the light
+    ray of pixel 0, and the segment identity fails.  Also at a size where other lanes of the wave take the ordinary route."""
+    import light_draw_cases as ldc
+    for seed, samples in ldc.OPEN_SEEDS.items():
+        for w, h, spp in ((2, 2, 1), (40, 24, 4)):
+            sc = host.Scene.loads(ldc.scene_json(width=w, height=h, spp=spp))
+            sc.c.seed = seed
+            o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+            rgb, lin, st = gpu_render(sc)
+            assert_parity(rgb, lin, o_rgb, o_lin, f"seed {seed} {w}x{h}", atol=pooled_atol(spp))
+            assert st["segments"] == o_st["segments"] - o_st["segments_discarded"], (seed, samples, w, h)
+
+
 def test_lit_cover_scene_light_frame_pool(gpu_render, oracle, abi, host):
     """A lit scene of cover size: 1024 per-lane light frames (80 KB) would push the tables out of LDS, so the workgroup
     shares a POOL of frames (rt_core.h LightState<true, true>; one light: 160 records for ~66 in use).  A lane that
