@@ -10,7 +10,7 @@ OPEN_HIGH_WORD, LOW_PART_BOUND = K >> 21, K & 0x1FFFFF
 OPEN_SEEDS = {5583768346: False, 8527335827: False, 23477444557: True, 29160843763: True, 23630226129: False}
 
 
-def scene_json(seed_unused=None, width=2, height=2, spp=1, max_depth=4):
+def scene_json(width=2, height=2, spp=1, max_depth=4):
     """One Lambertian sphere that fills the view (so pixel 0's camera ray hits it at node 0) and one light beside the camera."""
     return ('{"width":%d,"height":%d,"samples_per_pixel":%d,"max_depth":%d,"sky":{"texture":""},'
             '"camera":{"look_from":{"x":0.0,"y":0.0,"z":0.0},"look_at":{"x":0.0,"y":0.0,"z":-1.0},"vup":{"x":0.0,"y":1.0,"z":0.0},"vfov":60.0,"aspect":1.0},'
