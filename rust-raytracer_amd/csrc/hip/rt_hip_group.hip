@@ -475,6 +475,7 @@ int group_collect(RtHipGroup* g, RtStats* stats) {
       if (rc != RT_OK) return rc;
       total.samples += st.samples; total.segments += st.segments; total.sphere_tests += st.sphere_tests;
       total.exact_tests += st.exact_tests; total.tex_oob += st.tex_oob; total.grid_steps += st.grid_steps;
+      total.segments_repeated = (uint32_t)std::min<uint64_t>((uint64_t)total.segments_repeated + st.segments_repeated, 0xFFFFFFFFull);
       for (int k = 0; k < 4; ++k) total.wave_iters[k] += st.wave_iters[k];
       for (int k = 0; k < 12; ++k) total.prof_cycles[k] += st.prof_cycles[k];
       if (st.kernel_ms > total.kernel_ms) total.kernel_ms = st.kernel_ms;  // the slowest rank
