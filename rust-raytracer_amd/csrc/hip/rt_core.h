@@ -145,7 +145,7 @@ struct DevScene {
   uint32_t width, height, spp, max_depth;
   uint32_t sky_mode, n_spheres, n_lights, n_pairs;
   uint32_t seed_lo, seed_hi;
-  uint32_t light_pool_slots;  // lit scenes, pooled kernels: records in the workgroup's pool of light frames (LightState<true, true>)
+  uint32_t light_pool_slots;  // lit scenes: records in the workgroup's pool of light frames (LightState<true, true>)
   uint32_t cam_fast;          // inv_wm1 and inv_hm1 are both usable (width, height > 1): divide through them
   // raytracer.rs:92-100: a hit samples the lights when its draw exceeds 1 - n_lights * prob, prob = 0.1 (Glass: 0.05): the two
   // thresholds, computed once on the host with those operations — a wave-uniform scalar operand instead of two f64
@@ -164,13 +164,19 @@ struct DevScene {
   const uint32_t* sky4;
   uint32_t sky_fast;       // sky_w, sky_h <= 2^24 and sky_w * sky_h < 2^31: 24-bit index arithmetic on sky4
   float sky_wm1_f, sky_hm1_f;  // (float)(sky_w - 1), (float)(sky_h - 1) (raytracer.rs:149-150), converted once
-  uint32_t pad2;
+  uint32_t light_base_slots;   // lit scenes with the short colour map: records in the workgroup's pool of colour-map bases (24 B each)
   GridDesc grid;
   const uint32_t* cell_word;   // [n_cells][2]: {first item | count << 20, first two item indices (u16 | u16 << 16, 0xFFFF = none)}
   const uint16_t* cell_items;  // [n_items] sphere indices, object order inside a cell
   const uint32_t* large;       // [n_large] sphere indices, object order
   const SphereGeom* large_geom;  // [n_large] their geometry, packed in the same order (streamed by scalar loads)
   const MatCore* matc;         // [n_spheres]
+  // lit scenes: where a SUSPENDED light activation goes when the workgroup's pool has no record for the nested one that
+  // suspends it (80 B x (RT_MAX_LIGHT_NEST - 1) per lane of the launch, in HBM; practically never touched): the guarantee
+  // that a lane holding records never waits for one (rt_core.h light_frame_push)
+  unsigned char* light_overflow;
+  uint32_t light_nest_pool;    // 1 (default): nested activations take pool records; 0: always the overflow ("light_nest_pool" option, tests)
+  uint32_t pad3;
 };
 
 // ------------------------------------------------------------------ f64 square root
@@ -1072,44 +1078,48 @@ struct LightFrame {  // one ray_color activation that is summing over the lights
   uint32_t j;        // next light
   uint32_t node;     // its RNG node (children are child_node(node, j))
 };
-// The suspended outer activations of a lane (nesting levels below the active one).  They are indexed by a per-lane
-// depth and therefore live in scratch memory; a SEPARATE object from the Lane on purpose: one variable-index access
-// into any part of an object keeps the WHOLE object in memory (the compiler cannot split it), and with this array inside
-// Lane every lane field went through scratch in the lit kernels (720 B per lane, 197 MB per launch, L2-thrashing: lit
-// scenes ran 2.5x slower per segment than unlit ones).  Fields apart, so that no block copy touches `cur` either.
+// Where the light state of a lane lives.
+//
+// HOST form (LightState<true, false>: tests/hostsim, the CPU build of this header): one LightParked per lane (`pk`, a local
+// of the simulator) for the activation that is summing over the lights right now, a LightStack for the suspended outer
+// activations (nesting levels below the active one) and for the base of the short colour map (lane_compose).
+//
+// DEVICE form (LightState<true, true>: every lit kernel): nothing of it is a per-lane object in memory.  Until round 5 the
+// stack and the base were one — 416 B per lane, indexed by the nesting level and so in SCRATCH: 480 – 528 B per lane, a write
+// to HBM whenever some lane of a wave returned from its light loop (27 – 38 x the framebuffer's bytes per frame,
+// profiles/r04_run20_pmc_litcover.json).  Now the workgroup shares two POOLS in LDS, each a bitmap + records:
+//   * FRAMES (LightParked, 80 B): the activation summing over the lights — hit point, albedo, sum, next light, RNG node —
+//     and the camera path's pending direction.  Taken (one LDS atomic) when a camera-path hit starts sampling the lights,
+//     given back when that activation returns to the camera path: ~6 % of the lanes hold one at any moment (one light).
+//     A NESTED activation (a light ray's own hit samples the lights again, probability 0.1 n_lights) takes a record of
+//     its own and LINKS it to the suspended one's (the link overlays `saved_d`, which only a camera-path activation
+//     needs): nothing is copied, push and pop are one word each.
+//   * BASES (24 B): p[3], h[3] of the short colour map once a light contributed (lane_compose) — taken together with the
+//     sample's first frame, given back when the SAMPLE ends (~20 % of the lanes of a one-light scene).  The lane carries
+//     its record's offset in the spare high half of `in_light`.
+// A camera-path hit that finds either pool exhausted does NOT shade its hit: it leaves its ray as it is and traces the
+// same segment again in the next iteration (LANE_REPEAT; every draw is addressed by counter, so the repeat decides the
+// same).  For that to end, a lane that HOLDS records must never wait for one: a nested activation that finds the frame
+// pool exhausted does not wait — the suspended record is copied out to the lane's own overflow slot in HBM
+// (DevScene::light_overflow, 80 B x 7 levels per lane, written practically never) and its LDS record is reused for the
+// nested activation; the pop copies it back.  The host sizes the pools for 1.2 x the expected demand or keeps the tables
+// out of LDS to make room (rt_hip_api.hip), so a repeat is rare and an overflow rarer still; tests force both.
+// The pools sit at a FIXED offset of the kernel's dynamic LDS ([frame bitmap][base bitmap][frames][bases]; rt_kernel.hip's
+// layout asserts it); their sizes travel in DevScene.light_pool_slots / light_base_slots.
 template <bool HAS_LIGHTS>
 struct LightStack {};
 template <>
-struct LightStack<true> {
+struct LightStack<true> {  // (host form only)
   double P[RT_MAX_LIGHT_NEST - 1][3];
   float a[RT_MAX_LIGHT_NEST - 1][6];  // a[0..2], acc[0..2]
   uint32_t j[RT_MAX_LIGHT_NEST - 1][2];  // j, node
   float base[6];  // lit scenes with every albedo in [0, 1]: p[3], h[3] of the sample's colour map once a light contributed (lane_compose)
 };
-// The activation summing over the lights right now (nesting level `top`; 0 = the camera-path hit), and the camera
-// path's scattered direction to resume with.  Touched a few times per light-sampling hit (about 4 % of the segments of
-// a one-light scene) but alive across every walk in between: 20 registers per lane that the 128-VGPR kernel does not
-// have (117 spills, each a scratch round trip the wave waits for).  So it is "parked": the kernel points `pk` at a
-// per-lane record in LDS, the host simulator at a local.
 struct LightParked {
   LightFrame cur;
-  V3 saved_d;
+  V3 saved_d;  // camera-path activations: the scattered direction the camera path resumes with; nested ones: the link (first word)
 };
-static_assert(sizeof(LightParked) == 80, "parked light state is 80 B per lane");
-// Where a lane's active frame lives:
-//   direct (POOLED = false): `pk`, one record per lane — the host simulator's local; the kernel's per-lane LDS record
-//     when the workgroup's LDS has room for 1024 of them beside the scene tables (small scenes: the reference's test_scene);
-//   pooled: 80 KB of per-lane records would push a cover-sized scene's tables out of LDS (gathers from L2 instead: 5.9
-//     instead of 8.9 Gsamples/s) although only the ~6 % of lanes that are summing over the lights at any moment use
-//     theirs.  So the workgroup shares a POOL of records in LDS (as many as fit beside the tables): a record is taken
-//     (bitmap, one LDS atomic) when a camera-path hit starts sampling the lights and given back when that activation
-//     returns to the camera path.  A lane that finds the pool exhausted does NOT shade its hit: it leaves its ray as it
-//     is and traces the same segment again in the next iteration (every draw is addressed by counter, so the repeat
-//     decides the same; the holders of records never wait, so records keep coming back).  The host only picks this form
-//     when the pool is 1.5 x the expected demand (rt_hip_api.hip), so a repeat is rare.
-//     The pool sits at a FIXED offset of the kernel's dynamic LDS ([128-byte bitmap][records]; rt_kernel.hip's layout
-//     asserts it) and its size travels in DevScene.light_pool_slots, so a lane carries one dword for it: the LDS byte
-//     offset of its record, 0 while it holds none.
+static_assert(sizeof(LightFrame) == 56 && sizeof(LightParked) == 80, "a light frame record is 80 B, its link sits behind the 56 B frame");
 #ifndef RT_BLOCK
 #define RT_BLOCK 1024  // threads of the megakernel's workgroup (rt_kernel.hip): the offset below depends on its wave count
 #endif
@@ -1117,8 +1127,14 @@ constexpr uint32_t LIGHT_CENTRES_LDS_MAX = 32u;       // light centres staged in
 // = rt_kernel.hip lds_layout().park_off of a lit scene (asserted there, for every RT_BLOCK): flag block, tile slots (3 KB per
 // wave), exchange slots of the cooperative draw (1 KB per wave), light centres
 constexpr uint32_t LIGHT_POOL_LDS_OFF = (32u + 32u * 8u) + (RT_BLOCK / 64u) * 3u * 1024u + (RT_BLOCK / 64u) * 64u * 16u + LIGHT_CENTRES_LDS_MAX * 24u;
-constexpr uint32_t LIGHT_POOL_BITMAP_BYTES = 128u;   // 1024 slots at most
+constexpr uint32_t LIGHT_POOL_BITMAP_BYTES = 128u;   // 1024 slots at most, per pool
 constexpr uint32_t LIGHT_POOL_MAX_SLOTS = 1024u;
+constexpr uint32_t LIGHT_BASE_BYTES = 24u;
+constexpr uint32_t LIGHT_BASE_BITMAP_LDS_OFF = LIGHT_POOL_LDS_OFF + LIGHT_POOL_BITMAP_BYTES;
+constexpr uint32_t LIGHT_FRAMES_LDS_OFF = LIGHT_POOL_LDS_OFF + 2u * LIGHT_POOL_BITMAP_BYTES;
+RT_HD uint32_t light_bases_lds_off(uint32_t frame_slots) { return LIGHT_FRAMES_LDS_OFF + frame_slots * (uint32_t)sizeof(LightParked); }
+constexpr uint32_t LIGHT_LINK_OVERFLOW = 1u;  // link of a record whose suspended parent is in the HBM overflow (record offsets are multiples of 16)
+constexpr uint32_t LIGHT_OVERFLOW_BYTES_PER_LANE = (RT_MAX_LIGHT_NEST - 1u) * (uint32_t)sizeof(LightParked);
 #if defined(__HIP_DEVICE_COMPILE__)
 extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds_dyn[];  // the kernel's dynamic LDS (aliases its own declaration)
 #endif
@@ -1133,28 +1149,26 @@ struct LightState<true, false> {
 };
 template <>
 struct LightState<true, true> {
-  LightStack<true>* stack;
-  // LDS byte offset of the lane's pool record while it is summing over the lights, else 0 — a multiple of 16 — with the
+  // LDS byte offset of the record of the activation that is summing over the lights, else 0 — a multiple of 16 — with the
   // nesting level (`top`, 0 .. RT_MAX_LIGHT_NEST - 1 < 16) in its low four bits: one register for both (the lit kernels
-  // sit on the 128-register edge, and `where` alone was the last value they spilled)
+  // sit on the 128-register edge)
   uint32_t wt;
 };
-static_assert(RT_MAX_LIGHT_NEST <= 16u && (LIGHT_POOL_LDS_OFF + LIGHT_POOL_BITMAP_BYTES) % 16u == 0u && sizeof(LightParked) % 16u == 0u,
-              "the nesting level shares a register with the record offset: offsets are multiples of 16");
+static_assert(RT_MAX_LIGHT_NEST <= 16u && LIGHT_FRAMES_LDS_OFF % 16u == 0u && sizeof(LightParked) % 16u == 0u && LIGHT_BASE_BYTES % 8u == 0u,
+              "the nesting level shares a register with the record offset: offsets are multiples of 16; base offsets travel as offset / 8");
 RT_HD uint32_t ls_where(const LightState<true, true>& ls) { return ls.wt & ~15u; }
 RT_HD int ls_top(const LightState<true, true>& ls) { return (int)(ls.wt & 15u); }
-RT_HD void ls_set_where(LightState<true, true>& ls, uint32_t where) { ls.wt = where | (ls.wt & 15u); }
 RT_HD void ls_set_top(LightState<true, true>& ls, int t) { ls.wt = (ls.wt & ~15u) | (uint32_t)t; }
 RT_HD int ls_top(const LightState<true, false>& ls) { return ls.top; }
 RT_HD void ls_set_top(LightState<true, false>& ls, int t) { ls.top = t; }
 RT_HD LightParked& light_frame(LightState<true, false>& ls) { return *ls.pk; }
-RT_HD bool light_frame_acquire(LightState<true, false>&, uint32_t, uint32_t) { return true; }
 RT_HD void light_frame_release(LightState<true, false>&) {}
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ LightParked& light_frame(LightState<true, true>& ls) { return *reinterpret_cast<LightParked*>(rt_lds_dyn + ls_where(ls)); }
-// a camera-path hit starts summing over the lights: take a pool record (n_slots of them, a multiple of 32); false: none free
-__device__ __forceinline__ bool light_frame_acquire(LightState<true, true>& ls, uint32_t n_slots, uint32_t seed) {
-  uint32_t* const bitmap = reinterpret_cast<uint32_t*>(rt_lds_dyn + LIGHT_POOL_LDS_OFF);
+__device__ __forceinline__ uint32_t& light_link(uint32_t where) { return *reinterpret_cast<uint32_t*>(rt_lds_dyn + where + (uint32_t)sizeof(LightFrame)); }
+// take a record of the pool whose bitmap sits at `bitmap_off` (n_slots of them, a multiple of 32): its index, or ~0: none free
+__device__ __forceinline__ uint32_t light_pool_take(uint32_t bitmap_off, uint32_t n_slots, uint32_t seed) {
+  uint32_t* const bitmap = reinterpret_cast<uint32_t*>(rt_lds_dyn + bitmap_off);
   const uint32_t words = n_slots >> 5;
   uint32_t w = ((seed * 2654435761u) >> 16) % words;
   for (uint32_t tries = 0; tries < words; ++tries) {
@@ -1162,28 +1176,72 @@ __device__ __forceinline__ bool light_frame_acquire(LightState<true, true>& ls, 
     while (cur != 0xFFFFFFFFu) {
       const uint32_t b = (uint32_t)__builtin_ctz(~cur);
       const uint32_t old = __hip_atomic_fetch_or(&bitmap[w], 1u << b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (!((old >> b) & 1u)) { ls_set_where(ls, LIGHT_POOL_LDS_OFF + LIGHT_POOL_BITMAP_BYTES + ((w << 5) + b) * (uint32_t)sizeof(LightParked)); return true; }
+      if (!((old >> b) & 1u)) return (w << 5) + b;
       cur = old | (1u << b);
     }
     w = w + 1u == words ? 0u : w + 1u;
   }
-  return false;
+  return 0xFFFFFFFFu;
 }
-// ... and that activation is back on the camera path: give the record back (after the last read of it)
-__device__ __forceinline__ void light_frame_release(LightState<true, true>& ls) {
-  const uint32_t slot = (ls_where(ls) - LIGHT_POOL_LDS_OFF - LIGHT_POOL_BITMAP_BYTES) / (uint32_t)sizeof(LightParked);
-  uint32_t* const bitmap = reinterpret_cast<uint32_t*>(rt_lds_dyn + LIGHT_POOL_LDS_OFF);
+__device__ __forceinline__ void light_pool_give(uint32_t bitmap_off, uint32_t slot) {  // (after the last read of the record)
+  uint32_t* const bitmap = reinterpret_cast<uint32_t*>(rt_lds_dyn + bitmap_off);
   __hip_atomic_fetch_and(&bitmap[slot >> 5], ~(1u << (slot & 31u)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  ls_set_where(ls, 0u);
 }
-#else  // (host passes: the pooled kernel exists on the device only; the host simulator runs the direct form)
+// the camera-path activation is back on the camera path: give its frame record back
+__device__ __forceinline__ void light_frame_release(LightState<true, true>& ls) {
+  light_pool_give(LIGHT_POOL_LDS_OFF, (ls_where(ls) - LIGHT_FRAMES_LDS_OFF) / (uint32_t)sizeof(LightParked));
+  ls.wt = 0u;
+}
+__device__ __forceinline__ unsigned char* light_overflow_slot(const DevScene& sc, int level) {
+  // (the lane's index is made HERE: as a plain expression of blockIdx / threadIdx the compiler hoists lane * 7 out of the path
+  //  loop into a register pair that stays live across everything — for a path taken practically never)
+  uint32_t tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  return sc.light_overflow + ((size_t)(blockIdx.x * (uint32_t)RT_BLOCK + tid) * (RT_MAX_LIGHT_NEST - 1u) + (uint32_t)level) * sizeof(LightParked);
+}
+// a light ray's own hit starts sampling the lights: the activation whose light ray it is gets suspended (level t), a
+// record for the nested one (level t + 1) becomes current
+__device__ __forceinline__ void light_frame_push(const DevScene& sc, LightState<true, true>& ls, uint32_t seed) {
+  const int t = ls_top(ls);
+  const uint32_t cur = ls_where(ls);
+  const uint32_t slot = sc.light_nest_pool ? light_pool_take(LIGHT_POOL_LDS_OFF, sc.light_pool_slots, seed) : 0xFFFFFFFFu;
+  if (slot != 0xFFFFFFFFu) {
+    const uint32_t nw = LIGHT_FRAMES_LDS_OFF + slot * (uint32_t)sizeof(LightParked);
+    light_link(nw) = cur;
+    ls.wt = nw | (uint32_t)(t + 1);
+  } else {  // no record free: a holder never waits — the suspended activation moves out to HBM, its record serves the nested one
+    const uint4* src = reinterpret_cast<const uint4*>(rt_lds_dyn + cur);
+    uint4* dst = reinterpret_cast<uint4*>(light_overflow_slot(sc, t));
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(LightParked) / 16u); ++i) dst[i] = src[i];
+    light_link(cur) = LIGHT_LINK_OVERFLOW;
+    ls.wt = cur | (uint32_t)(t + 1);
+  }
+}
+// ... and that nested activation has returned its colour: the suspended one is current again
+__device__ __forceinline__ void light_frame_pop(const DevScene& sc, LightState<true, true>& ls) {
+  const int t = ls_top(ls) - 1;
+  const uint32_t cur = ls_where(ls);
+  const uint32_t link = light_link(cur);
+  if (link != LIGHT_LINK_OVERFLOW) {
+    light_pool_give(LIGHT_POOL_LDS_OFF, (cur - LIGHT_FRAMES_LDS_OFF) / (uint32_t)sizeof(LightParked));
+    ls.wt = link | (uint32_t)t;
+  } else {
+    const uint4* src = reinterpret_cast<const uint4*>(light_overflow_slot(sc, t));
+    uint4* dst = reinterpret_cast<uint4*>(rt_lds_dyn + cur);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(LightParked) / 16u); ++i) dst[i] = src[i];
+    ls.wt = cur | (uint32_t)t;
+  }
+}
+#else  // (host passes: the pooled form exists on the device only; the host simulator runs the direct form)
 inline LightParked& light_frame(LightState<true, true>&) { static LightParked never; return never; }
-inline bool light_frame_acquire(LightState<true, true>&, uint32_t, uint32_t) { return true; }
 inline void light_frame_release(LightState<true, true>&) {}
+inline void light_frame_push(const DevScene&, LightState<true, true>&, uint32_t) {}
+inline void light_frame_pop(const DevScene&, LightState<true, true>&) {}
 #endif
 
-template <bool P>
-RT_HD void light_frame_push(LightState<true, P>& ls) {  // stack[top] <- cur; ++top
+RT_HD void light_frame_push(const DevScene&, LightState<true, false>& ls, uint32_t) {  // stack[top] <- cur; ++top
   const int t = ls_top(ls);
   LightStack<true>& k = *ls.stack;
   const LightFrame& c = light_frame(ls).cur;
@@ -1193,8 +1251,7 @@ RT_HD void light_frame_push(LightState<true, P>& ls) {  // stack[top] <- cur; ++
   k.j[t][0] = c.j; k.j[t][1] = c.node;
   ls_set_top(ls, t + 1);
 }
-template <bool P>
-RT_HD void light_frame_pop(LightState<true, P>& ls) {  // --top; cur <- stack[top]
+RT_HD void light_frame_pop(const DevScene&, LightState<true, false>& ls) {  // --top; cur <- stack[top]
   const int t = ls_top(ls) - 1;
   const LightStack<true>& k = *ls.stack;
   LightFrame& c = light_frame(ls).cur;
@@ -1204,22 +1261,21 @@ RT_HD void light_frame_pop(LightState<true, P>& ls) {  // --top; cur <- stack[to
   c.j = k.j[t][0]; c.node = k.j[t][1];
   ls_set_top(ls, t);
 }
-// Lane setup: `stk` and `*pk` must outlive the lane.
+// Lane setup (host form): `stk` and `*pk` must outlive the lane.
 template <class LaneT> RT_HD void lane_attach_light_state(LaneT&, LightStack<false>&, LightParked*) {}
 template <class LaneT> RT_HD void lane_attach_light_state(LaneT& L, LightStack<true>& stk, LightParked* pk) { L.ls.stack = &stk; L.ls.pk = pk; L.ls.top = 0; }
-template <class LaneT> RT_HD void lane_attach_light_pool(LaneT& L, LightStack<true>& stk) {
-  L.ls.stack = &stk; L.ls.wt = 0u;
-}
 
 template <bool HAS_LIGHTS, bool SIMPLE = false, bool POOLED = false>
 struct Lane {
   static constexpr bool kLights = HAS_LIGHTS;
   static constexpr bool kSimple = SIMPLE;
+  static constexpr bool kPooled = POOLED;
   V3 o, d;        // current ray
   uint32_t node;  // RNG node of the current ray
   uint32_t k;     // camera-path segment index of the current (or suspended) camera ray
   uint32_t s;     // current sample
-  uint32_t in_light;  // bit 0: the current ray is a nested light ray; bit 1 (LANE_HAS_BASE): the sample's colour map has a base (lane_compose)
+  uint32_t in_light;  // bit 0: the current ray is a nested light ray; bit 1 (LANE_HAS_BASE): the sample's colour map has a base (lane_compose);
+                      // bits 16..31 (device): LDS byte offset / 8 of the sample's base record while it holds one, else 0
   FwdT<SIMPLE> fwd;
   float val[3];   // radiance of the sample that just finished (valid when lane_shade returned true)
   RngAddr ra;
@@ -1261,15 +1317,70 @@ RT_HD void lane_begin_sample(const DevScene& sc, LaneT& L, uint32_t px, uint32_t
 //   * once a light contributed, (p, h) — the BASE — are final after level 1: later levels only multiply q (p + q*0 = p,
 //     and their h-terms fl(p + q_j) >= fl(p + fl(q x)) cannot bind).
 // So the lane keeps q[3] in registers like an unlit lane, and the base — written at most twice per sample and read once
-// when the sample ends, for ~20 % of the samples of a one-light scene — lives in memory (LightStack::base), not in nine
-// registers the 128-register kernel does not have (the general map cost the lit kernels 30 spilled registers, some
-// reloaded inside the walk loop).  Bit-identical to FwdT<false> (tests/test_core_cpu.py).
+// when the sample ends, for ~20 % of the samples of a one-light scene — lives in memory (the device: a pool record in LDS,
+// lane_base; the host form: LightStack::base), not in nine registers the 128-register kernel does not have (the general
+// map cost the lit kernels 30 spilled registers, some reloaded inside the walk loop).  Bit-identical to FwdT<false>
+// (tests/test_core_cpu.py).
 constexpr uint32_t LANE_HAS_BASE = 2u;
+template <class LaneT>
+RT_HD float* lane_base(LaneT& L) {
+  if constexpr (LaneT::kPooled) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return reinterpret_cast<float*>(rt_lds_dyn + ((L.in_light >> 16) << 3));
+#else
+    (void)L;
+    return nullptr;  // (host pass of the kernel's instantiations: never run)
+#endif
+  } else return L.ls.stack->base;
+}
+// The sample's light records when a camera-path hit starts summing over the lights: its frame, and — short colour map —
+// its base unless an earlier level of the sample took one already.  Both or nothing: false = a pool is exhausted and
+// nothing has changed (the caller repeats the segment).
+template <class LaneT>
+RT_HD bool lane_light_acquire(const DevScene& sc, LaneT& L) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (LaneT::kPooled) {
+    const uint32_t seed = L.ra.pixel + L.ra.sample;
+    uint32_t base_slot = 0xFFFFFFFFu;
+    if constexpr (LaneT::kSimple) {
+      if ((L.in_light >> 16) == 0u) {
+        base_slot = light_pool_take(LIGHT_BASE_BITMAP_LDS_OFF, sc.light_base_slots, seed);
+        if (base_slot == 0xFFFFFFFFu) return false;
+      }
+    }
+    const uint32_t slot = light_pool_take(LIGHT_POOL_LDS_OFF, sc.light_pool_slots, seed);
+    if (slot == 0xFFFFFFFFu) {
+      if (base_slot != 0xFFFFFFFFu) light_pool_give(LIGHT_BASE_BITMAP_LDS_OFF, base_slot);
+      return false;
+    }
+    if (base_slot != 0xFFFFFFFFu) L.in_light |= ((light_bases_lds_off(sc.light_pool_slots) + base_slot * LIGHT_BASE_BYTES) >> 3) << 16;
+    L.ls.wt = LIGHT_FRAMES_LDS_OFF + slot * (uint32_t)sizeof(LightParked);  // (nesting level 0)
+    return true;
+  }
+#endif
+  (void)sc;
+  ls_set_top(L.ls, 0);
+  return true;
+}
+// ... and when the sample ends: its base record goes back (device form; after the last read of it)
+template <class LaneT>
+RT_HD void lane_base_release(const DevScene& sc, LaneT& L) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (LaneT::kPooled && LaneT::kSimple) {
+    const uint32_t off = (L.in_light >> 16) << 3;
+    if (off != 0u) {
+      light_pool_give(LIGHT_BASE_BITMAP_LDS_OFF, (off - light_bases_lds_off(sc.light_pool_slots)) / LIGHT_BASE_BYTES);
+      L.in_light &= 0xFFFFu;
+    }
+  }
+#endif
+  (void)sc; (void)L;
+}
 template <class LaneT>
 RT_HD void lane_compose(LaneT& L, const float light[3], const float att[3], bool has_light) {
   if constexpr (LaneT::kLights && LaneT::kSimple) {
     if (has_light) {  // level L.k (0 or 1) contributes `light`: create / update the base
-      float* b = L.ls.stack->base;
+      float* b = lane_base(L);
       float p[3], h[3];
       if (L.in_light & LANE_HAS_BASE) { p[0] = b[0]; p[1] = b[1]; p[2] = b[2]; h[0] = b[3]; h[1] = b[4]; h[2] = b[5]; }
       else { p[0] = p[1] = p[2] = 0.0f; h[0] = h[1] = h[2] = 3.4028234663852886e38f; }  // (a level 0 without light before this one: its h-term 0 + 1 >= q)
@@ -1293,20 +1404,22 @@ RT_HD void lane_compose(LaneT& L, const float light[3], const float att[3], bool
 // the sample's radiance is known: fold the leaf colour through the forward map.  The caller
 // adds L.val to the pixel (raytracer.rs:203-205) and picks the lane's next sample.
 template <class LaneT>
-RT_HD void lane_finish_sample(LaneT& L, Rgb leaf) {
+RT_HD void lane_finish_sample(const DevScene& sc, LaneT& L, Rgb leaf) {
   const float x[3] = {leaf.r, leaf.g, leaf.b};
   if constexpr (LaneT::kLights && LaneT::kSimple) {
     if (L.in_light & LANE_HAS_BASE) {
-      const float* b = L.ls.stack->base;
+      const float* b = lane_base(L);
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         float y = b[i] + L.fwd.q[i] * x[i];
         y = y > b[3 + i] ? b[3 + i] : y;
         L.val[i] = y;
       }
+      lane_base_release(sc, L);
       return;
     }
   }
+  (void)sc;
   L.val[0] = fwd_eval1(L.fwd, 0, x[0]);
   L.val[1] = fwd_eval1(L.fwd, 1, x[1]);
   L.val[2] = fwd_eval1(L.fwd, 2, x[2]);
@@ -1356,7 +1469,7 @@ template <class LaneT>
 RT_HD bool lane_continue_main(const DevScene& sc, LaneT& L, V3 point, V3 out_dir, const float light[3], const float att[3], bool has_light = false) {
   lane_compose(L, light, att, has_light);
   L.k += 1;
-  if (L.k >= sc.max_depth) { lane_finish_sample(L, rgb(0.0f, 0.0f, 0.0f)); return true; }
+  if (L.k >= sc.max_depth) { lane_finish_sample(sc, L, rgb(0.0f, 0.0f, 0.0f)); return true; }
   L.o = point; L.d = out_dir; L.node = L.k; L.in_light &= ~1u;
   return false;
 }
@@ -1390,7 +1503,7 @@ RT_HD bool lane_light_return(const DevScene& sc, const Tables& tb, LaneT& L, Rgb
     }
     // a nested activation (max_depth 2, depth 1): its own child is depth 0 = black (:117-122)
     tc = rgb(clamp01(light[0] + f.a[0] * 0.0f), clamp01(light[1] + f.a[1] * 0.0f), clamp01(light[2] + f.a[2] * 0.0f));
-    light_frame_pop(L.ls);  // the activation that shot the light ray goes on
+    light_frame_pop(sc, L.ls);  // the activation that shot the light ray goes on
   }
 }
 
@@ -1425,7 +1538,7 @@ RT_HD int lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, do
   if constexpr (!HL) {
     (void)light_u_pre;
     if (idx < 0) {  // raytracer.rs:133-163
-      lane_finish_sample(L, sky_color(sc, L.d, L.n_tex_oob));
+      lane_finish_sample(sc, L, sky_color(sc, L.d, L.n_tex_oob));
       return LANE_FINISHED;
     }
     const SphereGeom g = tb.geom((uint32_t)idx);
@@ -1434,8 +1547,8 @@ RT_HD int lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, do
     V3 out_dir = v3(0, 0, 0);
     float att[3];
     int st = scatter(sc, L.ra, L.node, L.d, h, g, m, (uint32_t)idx, out_dir, att, L.n_tex_oob, rnd_pre, glass_u_pre);
-    if (st == SCATTER_ABSORBED) { lane_finish_sample(L, rgb(0.f, 0.f, 0.f)); return LANE_FINISHED; }       // :127-131
-    if (st == SCATTER_EMIT) { lane_finish_sample(L, rgb(att[0], att[1], att[2])); return LANE_FINISHED; }  // :124
+    if (st == SCATTER_ABSORBED) { lane_finish_sample(sc, L, rgb(0.f, 0.f, 0.f)); return LANE_FINISHED; }       // :127-131
+    if (st == SCATTER_EMIT) { lane_finish_sample(sc, L, rgb(att[0], att[1], att[2])); return LANE_FINISHED; }  // :124
     return lane_continue_main(sc, L, h.point, out_dir, zero3, att) ? LANE_FINISHED : LANE_CONTINUE;
   } else {
     // Lit scenes.  First decide what the hit MEANS for the lane; the heavy continuations — hand a colour back to the
@@ -1475,12 +1588,11 @@ RT_HD int lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, do
       }
     }
     if (act == ACT_SAMPLE) {
-      if (light_ray) light_frame_push(L.ls);  // suspend the activation whose light ray this is
+      if (light_ray) light_frame_push(sc, L.ls, L.ra.pixel + L.ra.sample + L.node);  // suspend the activation whose light ray this is
       else {
-        // (pooled kernels: no record free -> nothing has changed yet: the same segment is traced again; the caller counts
+        // (the device's pools: no record free -> nothing has changed yet: the same segment is traced again; the caller counts
         //  the segment once — its exact tests and grid steps are the work actually done, and counted as such)
-        if (!light_frame_acquire(L.ls, sc.light_pool_slots, L.ra.pixel + L.ra.sample)) return LANE_REPEAT;
-        ls_set_top(L.ls, 0);
+        if (!lane_light_acquire(sc, L)) return LANE_REPEAT;
         light_frame(L.ls).saved_d = out_dir;
       }
       LightFrame& f = light_frame(L.ls).cur;
@@ -1490,7 +1602,7 @@ RT_HD int lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, do
       return LANE_CONTINUE;
     }
     if (act == ACT_RETURN) return lane_light_return(sc, tb, L, col) ? LANE_FINISHED : LANE_CONTINUE;
-    if (act == ACT_FINISH) { lane_finish_sample(L, col); return LANE_FINISHED; }
+    if (act == ACT_FINISH) { lane_finish_sample(sc, L, col); return LANE_FINISHED; }
     return lane_continue_main(sc, L, point, out_dir, zero3, att) ? LANE_FINISHED : LANE_CONTINUE;
   }
 }

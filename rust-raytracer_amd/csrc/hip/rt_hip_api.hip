@@ -70,7 +70,12 @@ struct RtHipScene {
   std::vector<SeedSphere> seed_spheres;  // host copy of (centre, radius, material kind): what the seed projects
   std::vector<uint32_t> seed_depth;      // staging of the seeded depths (kept alive until the copy that reads it has run)
   int force_lit = 0;       // "force_lit" option (diagnostics)
-  int light_pool_cap = 0;  // "light_pool" option: cap on the light-frame pool of lit scenes (0 = as many as fit; tests shrink it to force the fall-back)
+  int light_pool_cap = 0;  // "light_pool" option: cap on the light-frame pool of lit scenes (0 = automatic; tests shrink it to force repeats and overflows)
+  int light_base_cap = 0;  // "light_base_pool" option: the same for the pool of colour-map bases
+  int light_nest_pool = 1; // "light_nest_pool" option: 0 = nested light activations always go through the HBM overflow (tests)
+  void* d_light_overflow = nullptr; size_t light_overflow_bytes = 0;  // lit scenes: 560 B per lane of the largest launch so far (rt_core.h light_frame_push)
+  size_t lds_cap = 0;      // dynamic LDS a workgroup may ask for on this device
+  uint32_t last_pool_slots = 0, last_base_slots = 0; size_t last_lds_bytes = 0; bool last_lds_tables = false;  // of the last launch (rt_hip_scene_query)
   int chunk_spp = 0;       // 0 = automatic
   int tile_batch = 0;      // 0 = automatic; else tiles a workgroup takes from the queue per atomic, 1..64
   int tile_log2 = -1;      // -1 = automatic; else tiles of 4^k pixels, k = 0..3
@@ -140,7 +145,7 @@ extern "C" void rt_hip_scene_destroy(RtHipScene* s) {
   (void)hipSetDevice(s->device);
   for (void* p : {s->d_geom, s->d_mat, s->d_cull, s->d_lights, s->d_tex, s->d_sky, s->d_tex4, s->d_sky4, (void*)s->d_counters, s->d_matc,
                   s->d_cell_word, s->d_cell_items, s->d_large, s->d_all, s->d_large_geom, s->d_frame, (void*)s->d_tile_depth,
-                  (void*)s->d_tile_order})
+                  (void*)s->d_tile_order, s->d_light_overflow})
     if (p) (void)hipFree(p);
   for (auto& sl : s->slot) {
     for (hipEvent_t e : {sl.ev_start, sl.ev_stop, sl.ev_copied}) if (e) (void)hipEventDestroy(e);
@@ -187,6 +192,10 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
     hipDeviceProp_t prop;
     RT_HIP_TRY(hipGetDeviceProperties(&prop, device));
     s->num_cus = prop.multiProcessorCount;
+    // 160 KB of LDS per CU on gfx950; the unlit layouts stay below LDS_TABLES_MAX_BYTES (156 KB) as before, the light pools may
+    // take what the device says is left
+    const size_t dev_lds = prop.sharedMemPerBlock > prop.maxSharedMemoryPerMultiProcessor ? prop.sharedMemPerBlock : prop.maxSharedMemoryPerMultiProcessor;
+    s->lds_cap = std::max<size_t>(rtk::LDS_TABLES_MAX_BYTES, std::min<size_t>(dev_lds, 160u * 1024u));
   }
   int rc;
   auto bail = [&](int code) { rt_hip_scene_destroy(s); return code; };
@@ -263,6 +272,8 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
   if (!std::strcmp(key, "tile_order")) { if (value < 0 || value > 3) return fail(RT_ERR_INVALID, "tile_order must be 0, 1, 2 or 3"); s->order_mode = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
   if (!std::strcmp(key, "order_seed")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "order_seed must be 0 (off), 1 (projection) or 2 (probe launch)"); s->order_seed = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
   if (!std::strcmp(key, "light_pool")) { if (value < 0 || value > 1024 || (value != 0 && value < 32)) return fail(RT_ERR_INVALID, "light_pool must be 0 (automatic) or 32..1024"); s->light_pool_cap = (int)value; return RT_OK; }
+  if (!std::strcmp(key, "light_base_pool")) { if (value < 0 || value > 1024 || (value != 0 && value < 32)) return fail(RT_ERR_INVALID, "light_base_pool must be 0 (automatic) or 32..1024"); s->light_base_cap = (int)value; return RT_OK; }
+  if (!std::strcmp(key, "light_nest_pool")) { if (value < 0 || value > 1) return fail(RT_ERR_INVALID, "light_nest_pool must be 0 or 1"); s->light_nest_pool = (int)value; return RT_OK; }
   if (!std::strcmp(key, "force_lit")) { if (value < 0 || value > 1) return fail(RT_ERR_INVALID, "force_lit must be 0 or 1"); s->force_lit = (int)value; return RT_OK; }  // (diagnostics: an unlit scene through the lit kernels — what their code costs the ordinary lanes, profiles/r04_run5_lit_sections.log)
   if (!std::strcmp(key, "tile_batch")) { if (value < 0 || value > 64) return fail(RT_ERR_INVALID, "tile_batch must be 0..64"); s->tile_batch = (int)value; return RT_OK; }
   if (!std::strcmp(key, "chunk_spp")) { if (value < 0) return fail(RT_ERR_INVALID, "chunk_spp must be >= 0"); s->chunk_spp = (int)value; return RT_OK; }
@@ -302,11 +313,11 @@ int launch_scan(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb8, void* d_li
 }
 #endif  // RT_WITH_SCAN_KERNEL
 
-template <bool HL, bool SIMPLE, bool LDS, bool POOLED = false>
-int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka, size_t lds_bytes, uint32_t n_items, hipStream_t stream) {
-  auto kern = rtk::rt_megakernel<HL, SIMPLE, LDS, POOLED>;
+template <bool HL, bool SIMPLE, bool LDS>
+int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka_in, size_t lds_bytes, uint32_t n_items, hipStream_t stream) {
+  auto kern = rtk::rt_megakernel<HL, SIMPLE, LDS>;
   // the launch configuration of this scene's kernel is worked out once (it costs two runtime calls a frame otherwise)
-  const int key = (POOLED ? 8 : 0) | (HL ? 4 : 0) | (SIMPLE ? 2 : 0) | (LDS ? 1 : 0);
+  const int key = (HL ? 4 : 0) | (SIMPLE ? 2 : 0) | (LDS ? 1 : 0);
   if (s->cfg_key != key || s->cfg_lds != lds_bytes) {
     if (lds_bytes > 48 * 1024) RT_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     int per_cu_q = 0;
@@ -320,6 +331,18 @@ int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka, size_t lds_bytes, uint32_
   const uint32_t need = (n_items + rtk::WAVES - 1) / rtk::WAVES;
   if (wgs > need) wgs = need;
   s->last_waves = (uint64_t)wgs * rtk::WAVES;
+  rtk::KArgs ka = ka_in;
+  if (HL) {  // the lanes' overflow slots for suspended light activations (rt_core.h light_frame_push): sized for this launch, kept
+    const size_t need_bytes = (size_t)wgs * rtk::BLOCK * rtc::LIGHT_OVERFLOW_BYTES_PER_LANE;
+    if (need_bytes > s->light_overflow_bytes) {
+      // (an earlier launch of this scene may still be running on this stream with the old buffer: drain it first — once per scene
+      //  and launch size, never in a frame loop)
+      if (s->d_light_overflow) { RT_HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(s->d_light_overflow); s->d_light_overflow = nullptr; s->light_overflow_bytes = 0; }
+      RT_HIP_TRY(hipMalloc(&s->d_light_overflow, need_bytes));
+      s->light_overflow_bytes = need_bytes;
+    }
+    ka.sc.light_overflow = (unsigned char*)s->d_light_overflow;
+  }
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(rtk::BLOCK), lds_bytes, stream, ka);
   return RT_OK;
 }
@@ -507,29 +530,58 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
 #ifdef RT_DEV_KNOBS
   if (const char* e = std::getenv("RT_BATCH_SHARE")) { const int v = std::atoi(e); if (v >= 1 && v <= 1024) ka.batch_share = (uint32_t)v; }
 #endif
-  // LDS budget.  Tables + tile slots + (lit scenes) one light frame per lane: everything in LDS.  A lit scene whose tables do
-  // not fit beside 1024 light frames (80 KB) keeps its TABLES in LDS and shares a pool of as many frames as still fit —
-  // if that covers 1.5 x the expected demand: a camera path starts summing over the n lights with probability ~0.1 n at
-  // each of its first two hits (raytracer.rs:92-102) and then shoots n light rays, so about f = 0.2 n^2 / (2.9 + 0.2 n^2)
-  // of the lanes hold a frame at any moment (n = 1: 6.5 % = 66 of 1024 lanes; n = 2: 22 %; n = 3: 38 %).  A lane that
-  // finds the pool exhausted repeats its segment (rt_core.h), so an undersized pool is slow, never wrong.  Scenes whose
-  // tables do not fit at all, or with too many lights for the pool, gather the tables from L2 (one frame per lane).
+  // LDS budget.  Tables + tile slots + (lit scenes) the two pools of light records (rt_core.h): frames — held by a lane while
+  // it sums over the lights — and, with the short colour map, bases — held from a sample's first light sampling to its end.
+  // Expected demand: a camera path starts summing over the n lights with probability ~0.1 n at each of its first two hits
+  // (raytracer.rs:92-102) and then shoots n light rays, so about f = 0.2 n^2 / (2.9 + 0.2 n^2) of the lanes hold a frame at
+  // any moment (n = 1: 6.5 % = 66 of 1024 lanes; n = 2: 22 %; n = 3: 38 %) and about b = 0.2 n (n + 2) / (2.9 + 0.2 n^2) a
+  // base (n = 1: 19 %).  A lane that finds a pool exhausted repeats its segment, so undersized pools are slow, never wrong
+  // (forced pools of 64 / 32 frames on the lit cover scene: +1 % / +64 %, profiles/r03_run*_lit.log).  The pools get what is
+  // left beside the tables, in the proportion of their demands, up to one record per lane; if that is less than 1.2 x the
+  // demand the TABLES stay in L2 instead and the pools take their room.
   const rtc::GridDesc& G = ka.sc.grid;
-  const rtk::LdsLayout with_tables = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, has_lights);
-  bool lds_tables = with_tables.total <= rtk::LDS_TABLES_MAX_BYTES;
-  uint32_t pool_slots = 0;
-  if (!lds_tables && has_lights) {
-    const uint32_t bare = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, false).total + rtc::LIGHT_CENTRES_LDS_MAX * 24u;
-    uint32_t fit = 0;
-    while (fit + 32u <= rtc::LIGHT_POOL_MAX_SLOTS && bare + rtk::park_bytes(fit + 32u) <= rtk::LDS_TABLES_MAX_BYTES) fit += 32u;
-    const double n = (double)s->dev.n_lights, f = 0.2 * n * n / (2.9 + 0.2 * n * n);
-    const bool forced = s->light_pool_cap > 0;  // ("light_pool" option, tests: any pool of >= 32 records that fits)
-    if (forced && fit > (uint32_t)s->light_pool_cap) fit = (uint32_t)s->light_pool_cap & ~31u;
-    if (fit >= 32u && (forced || (double)fit >= 1.5 * f * (double)rtk::BLOCK)) { pool_slots = fit; lds_tables = true; }
+  const bool short_map = has_lights && s->simple_colour;
+  uint32_t pool_slots = 0, base_slots = 0;
+  auto size_pools = [&](size_t avail, double* margin) {  // largest x with frames = x f 1024, bases = x b 1024 (multiples of 32, 32 .. 1024) inside `avail`
+    const double n = (double)s->dev.n_lights, den = 2.9 + 0.2 * n * n;
+    const double f = std::max(0.2 * n * n / den, 1.0 / 64.0), b = short_map ? std::min(1.0, std::max(0.2 * n * (n + 2.0) / den, 1.0 / 64.0)) : 0.0;
+    auto slots = [&](double x, double share) -> uint32_t {
+      if (share == 0.0) return 0u;
+      const double v = x * share * (double)rtk::BLOCK;
+      const uint32_t q = v >= (double)rtc::LIGHT_POOL_MAX_SLOTS ? rtc::LIGHT_POOL_MAX_SLOTS : ((uint32_t)v & ~31u);
+      return q < 32u ? 32u : q;
+    };
+    auto bytes = [&](double x) { return (size_t)((rtk::park_bytes(slots(x, f), slots(x, b)) + 15u) & ~15u); };
+    double lo = 0.0, hi = 1.0 / std::min(f, b > 0.0 ? b : f) + 1.0;  // at `hi` both pools hold one record per lane
+    if (bytes(hi) <= avail) lo = hi;
+    else for (int it = 0; it < 40; ++it) { const double mid = 0.5 * (lo + hi); if (bytes(mid) <= avail) lo = mid; else hi = mid; }
+    pool_slots = slots(lo, f); base_slots = slots(lo, b);
+    const bool forced_f = s->light_pool_cap > 0, forced_b = s->light_base_cap > 0;  // (tests: small pools on purpose)
+    if (forced_f && pool_slots > (uint32_t)s->light_pool_cap) pool_slots = (uint32_t)s->light_pool_cap & ~31u;
+    if (forced_b && base_slots > (uint32_t)s->light_base_cap) base_slots = (uint32_t)s->light_base_cap & ~31u;
+    if (margin) *margin = (forced_f || forced_b) ? 1e9 : std::min((double)pool_slots / (f * rtk::BLOCK), b > 0.0 ? (double)base_slots / (b * rtk::BLOCK) : 1e9);
+    return bytes(0.0) <= avail;  // (the smallest pools fit)
+  };
+  const rtk::LdsLayout no_pools = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, false);
+  bool lds_tables = no_pools.total <= rtk::LDS_TABLES_MAX_BYTES;
+  if (has_lights) {
+    const size_t fixed = rtc::LIGHT_CENTRES_LDS_MAX * 24u;
+    double margin = 0.0;
+    bool ok = lds_tables && no_pools.total + fixed < s->lds_cap && size_pools(s->lds_cap - no_pools.total - fixed, &margin) && margin >= 1.2;
+    if (!ok) {
+      lds_tables = false;
+      const size_t bare = rtk::lds_layout(0, 0, 0, false, false).total + fixed;
+      if (!size_pools(s->lds_cap - bare, nullptr)) return fail(RT_ERR_UNSUPPORTED, "no room for the light pools in LDS");
+    }
   }
   ka.sc.light_pool_slots = pool_slots;
-  const size_t lds_bytes = lds_tables ? rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, has_lights, pool_slots).total
-                                      : rtk::lds_layout(0, 0, 0, false, has_lights).total;
+  ka.sc.light_base_slots = base_slots;
+  ka.sc.light_nest_pool = (uint32_t)s->light_nest_pool;
+  ka.sc.light_overflow = nullptr;  // (launch_grid_t fills it in for the lit kernels)
+  s->last_pool_slots = pool_slots; s->last_base_slots = base_slots; s->last_lds_tables = lds_tables;
+  const size_t lds_bytes = lds_tables ? rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, has_lights, pool_slots, base_slots).total
+                                      : rtk::lds_layout(0, 0, 0, false, has_lights, pool_slots, base_slots).total;
+  s->last_lds_bytes = lds_bytes;
 
   // queue order: bottom of the image first; from the second frame of a tile geometry on, the tiles whose samples ran
   // deepest in the previous frame first (their paths are what a frame ends on)
@@ -582,17 +634,16 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   }
 
   int rc;
-  // instantiation = (lights, every albedo in [0, 1], tables in LDS, light-frame pool)
+  // instantiation = (lights, every albedo in [0, 1], tables in LDS)
   auto launch = [&](const rtk::KArgs& ka, uint32_t n_items) -> int {
     int rc;
-#define RT_GO(HL, SIMPLE, LDS, POOLED) rc = launch_grid_t<HL, SIMPLE, LDS, POOLED>(s, ka, lds_bytes, n_items, stream)
+#define RT_GO(HL, SIMPLE, LDS) rc = launch_grid_t<HL, SIMPLE, LDS>(s, ka, lds_bytes, n_items, stream)
     const bool simple = s->simple_colour;
     if (has_lights) {
-      if (pool_slots) { if (simple) RT_GO(true, true, true, true); else RT_GO(true, false, true, true); }
-      else if (lds_tables) { if (simple) RT_GO(true, true, true, false); else RT_GO(true, false, true, false); }
-      else { if (simple) RT_GO(true, true, false, false); else RT_GO(true, false, false, false); }
-    } else if (lds_tables) { if (simple) RT_GO(false, true, true, false); else RT_GO(false, false, true, false); }
-    else { if (simple) RT_GO(false, true, false, false); else RT_GO(false, false, false, false); }
+      if (lds_tables) { if (simple) RT_GO(true, true, true); else RT_GO(true, false, true); }
+      else { if (simple) RT_GO(true, true, false); else RT_GO(true, false, false); }
+    } else if (lds_tables) { if (simple) RT_GO(false, true, true); else RT_GO(false, false, true); }
+    else { if (simple) RT_GO(false, true, false); else RT_GO(false, false, false); }
 #undef RT_GO
     if (rc != RT_OK) return rc;
     RT_HIP_TRY(hipGetLastError());
@@ -720,6 +771,10 @@ extern "C" int64_t rt_hip_scene_query(const RtHipScene* s, const char* key) {
   if (!std::strcmp(key, "grid_items")) return (int64_t)s->grid.n_items;       // u16 each
   if (!std::strcmp(key, "grid_large")) return (int64_t)s->grid.n_large;
   if (!std::strcmp(key, "texel_bytes")) return (int64_t)s->texel_bytes;       // 4-byte texels of textures + sky resident in HBM
+  if (!std::strcmp(key, "light_pool_slots")) return (int64_t)s->last_pool_slots;  // of the last launch: records in the pools of light frames /
+  if (!std::strcmp(key, "light_base_slots")) return (int64_t)s->last_base_slots;  // colour-map bases, the kernel's dynamic LDS, tables staged in LDS
+  if (!std::strcmp(key, "lds_bytes")) return (int64_t)s->last_lds_bytes;
+  if (!std::strcmp(key, "lds_tables")) return (int64_t)s->last_lds_tables;
   if (!std::strcmp(key, "table_bytes")) return (int64_t)((size_t)s->host.n_spheres * (sizeof(rtc::SphereGeom) + sizeof(rtc::MatCore)) + (size_t)s->grid.n_cells * 8u + (size_t)s->grid.n_items * 2u);
   return -1;
 }

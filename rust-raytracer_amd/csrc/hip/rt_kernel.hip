@@ -125,19 +125,20 @@ __host__ __device__ inline uint32_t tile_slots(uint32_t tile_log2) {
 struct LdsLayout {
   uint32_t hdr_off, coop_off, light_off, park_off, geom_off, matc_off, cell_off, item_off, total;
 };
-// light frames (lit scenes): one LightParked per lane (pool_slots == 0), or [bitmap][pool of pool_slots records] (rt_core.h)
-__host__ __device__ constexpr uint32_t park_bytes(uint32_t pool_slots) {
-  return pool_slots ? LIGHT_POOL_BITMAP_BYTES + pool_slots * (uint32_t)sizeof(LightParked) : (uint32_t)BLOCK * (uint32_t)sizeof(LightParked);
+// light records (lit scenes): [frame bitmap][base bitmap][pool of frame_slots LightParked][pool of base_slots colour-map bases] (rt_core.h)
+__host__ __device__ constexpr uint32_t park_bytes(uint32_t frame_slots, uint32_t base_slots) {
+  return 2u * LIGHT_POOL_BITMAP_BYTES + frame_slots * (uint32_t)sizeof(LightParked) + base_slots * LIGHT_BASE_BYTES;
 }
 constexpr uint32_t LIGHT_CENTRES_LDS_OFF = LDS_FLAGS_BYTES + LDS_SLOT_BUDGET + WAVES * 64u * 16u;  // lit scenes: centres of the first 32 lights, 3 doubles each
 static_assert(LIGHT_CENTRES_LDS_OFF + LIGHT_CENTRES_LDS_MAX * 24u == LIGHT_POOL_LDS_OFF, "rt_core.h LIGHT_POOL_LDS_OFF = park_off of the layout below (for this RT_BLOCK)");
-__host__ __device__ inline LdsLayout lds_layout(uint32_t n_spheres, uint32_t n_cells, uint32_t n_items, bool tables, bool lights, uint32_t pool_slots = 0) {
+__host__ __device__ inline LdsLayout lds_layout(uint32_t n_spheres, uint32_t n_cells, uint32_t n_items, bool tables, bool lights, uint32_t frame_slots = 0,
+                                                uint32_t base_slots = 0) {
   LdsLayout l;
   uint32_t o = LDS_FLAGS_BYTES;
   l.hdr_off = o; o += LDS_SLOT_BUDGET;  // [t_slots headers][t_slots x npx x 3 u64 sums], sized by tile_slots()
   l.coop_off = o; o += WAVES * 64u * 16u;  // per wave: 64 x 16 B exchange slots of coop_random_in_unit_sphere
   l.light_off = o; if (lights) o += LIGHT_CENTRES_LDS_MAX * 24u;
-  l.park_off = o; if (lights) o += park_bytes(pool_slots);  // rt_core.h LightParked: [bitmap][records] of a pool, or one record per lane
+  l.park_off = o; if (lights) o += (park_bytes(frame_slots, base_slots) + 15u) & ~15u;  // rt_core.h: the pools of light frames and colour-map bases
   l.geom_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(SphereGeom);
   l.matc_off = o; if (tables) o += n_spheres * (uint32_t)sizeof(MatCore);
   l.cell_off = o; if (tables) o += n_cells * 8u;
@@ -292,15 +293,14 @@ struct LdsTables {  // per-lane gathers from the workgroup's LDS copies
   __device__ __forceinline__ MatCore mat(uint32_t i) const { return m[i]; }
 };
 
-template <bool HL, bool SIMPLE, bool LDS_TABLES, bool POOLED = false>
+template <bool HL, bool SIMPLE, bool LDS_TABLES>
 __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs ka) {
-  static_assert(!POOLED || (HL && LDS_TABLES), "the light-frame pool exists to keep a lit scene's tables in LDS");
   const DevScene& sc = ka.sc;
   const GridDesc& G = sc.grid;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   RT_PROF_DECL
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const LdsLayout lay = lds_layout(sc.n_spheres, G.n_cells, G.n_items, LDS_TABLES, HL, POOLED ? sc.light_pool_slots : 0u);
+  const LdsLayout lay = lds_layout(sc.n_spheres, G.n_cells, G.n_items, LDS_TABLES, HL, sc.light_pool_slots, sc.light_base_slots);
   uint32_t* const wg_flags = reinterpret_cast<uint32_t*>(lds_raw);  // [0] the frame's tile queue is empty, [1] slot opened last
   SlotHdr* const hdr = reinterpret_cast<SlotHdr*>(lds_raw + lay.hdr_off);
   const uint32_t T = ka.t_slots, acc_stride = 3u << (2u * ka.tile_log2);  // u64 words of pixel sums per slot
@@ -323,8 +323,8 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   const uint32_t my_xcd = (uint32_t)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;
   unsigned long long* const wg_counters = reinterpret_cast<unsigned long long*>(lds_raw + 32);
   if (threadIdx.x < 32u) wg_counters[threadIdx.x] = 0ull;
-  if constexpr (POOLED) {  // every slot of the light-frame pool is free
-    if (threadIdx.x < LIGHT_POOL_BITMAP_BYTES / 4u) reinterpret_cast<uint32_t*>(lds_raw + LIGHT_POOL_LDS_OFF)[threadIdx.x] = 0u;
+  if constexpr (HL) {  // every record of the two light pools is free
+    if (threadIdx.x < 2u * LIGHT_POOL_BITMAP_BYTES / 4u) reinterpret_cast<uint32_t*>(lds_raw + LIGHT_POOL_LDS_OFF)[threadIdx.x] = 0u;
   }
   if constexpr (!LDS_TABLES) __syncthreads();
 
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     cell_word = reinterpret_cast<const uint2*>(sc.cell_word); cell_items = sc.cell_items;
   }
 
-  typedef Lane<HL, SIMPLE, POOLED> LaneT;
+  typedef Lane<HL, SIMPLE, HL> LaneT;  // (lit lanes keep their light records in the workgroup's LDS pools)
   LaneT L;
   L.s = 0; L.k = 0; L.node = 0; L.in_light = 0;
   L.val[0] = L.val[1] = L.val[2] = 0.0f;
@@ -378,12 +378,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
   L.ra.pixel = 0; L.ra.sample = 0; L.ra.k0 = sc.seed_lo; L.ra.k1 = sc.seed_hi;
   L.o = v3(0, 0, 0); L.d = v3(0, 0, 1);
   fwd_init(L.fwd);
-  LightStack<HL> light_stack;
-  if constexpr (POOLED) {
-    lane_attach_light_pool(L, light_stack);
-  } else {
-    lane_attach_light_state(L, light_stack, reinterpret_cast<LightParked*>(lds_raw + lay.park_off) + threadIdx.x);
-  }
+  if constexpr (HL) L.ls.wt = 0u;  // no light record held
   auto flush_oob = [&]() {  // (lit kernels, after every call that may count an out-of-range texel: L.n_tex_oob is 0 again, so nothing is carried)
     if constexpr (!HL) return;
     if (L.n_tex_oob != 0u) { __hip_atomic_fetch_add(&wg_counters[2], (unsigned long long)L.n_tex_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); L.n_tex_oob = 0u; }
@@ -446,7 +441,8 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     const bool packed = wl >= 2u && (sc.width & 3u) == 0u && (reinterpret_cast<uintptr_t>(ka.out_rgb8) & 3u) == 0u;
     if (packed) {
       const uint32_t nxt = (uint32_t)__shfl_down((int)rgb, 1);
-      const uint32_t i = lane & 3u;
+      uint32_t i = lane & 3u;
+      asm volatile("" : "+v"(i));  // (made here: hoisted out of the path loop, i, 8 i, 24 - 8 i and a zero-extended copy held four registers for good — spilled in the lit kernels)
       if (valid && i < 3u) *reinterpret_cast<uint32_t*>(ka.out_rgb8 + o + i) = (rgb >> (8u * i)) | (nxt << (24u - 8u * i));
     } else if (valid) {
       ka.out_rgb8[o] = (uint8_t)rgb; ka.out_rgb8[o + 1] = (uint8_t)(rgb >> 8); ka.out_rgb8[o + 2] = (uint8_t)(rgb >> 16);
@@ -836,7 +832,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     const uint32_t k_miss = my_k;
     if (wave_any(miss)) {
       if (miss) {
-        lane_finish_sample(L, sky_color(fresh_args().sc, L.d, L.n_tex_oob));
+        { const DevScene& scf = fresh_args().sc; lane_finish_sample(scf, L, sky_color(scf, L.d, L.n_tex_oob)); }
         flush_oob();
         has_ray = false;
       }
@@ -878,7 +874,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       flush_oob();
     }
     const bool finished = status == LANE_FINISHED;
-    if constexpr (POOLED) {  // a segment repeated because the light-frame pool was exhausted is ONE segment of its path (a wave-level count: outside the divergent region)
+    if constexpr (HL) {  // a segment repeated because a light pool was exhausted is ONE segment of its path (a wave-level count: outside the divergent region)
       const unsigned long long rep = wave_ballot(status == LANE_REPEAT);
       if (rep) {  // (rare: the repeats go straight to the workgroup's counter — RtStats.segments_repeated — no register carries them)
         w_segments -= (uint32_t)__builtin_popcountll(rep);
@@ -943,7 +939,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         if (k == 15 || k == 17) { if (v) atomicMax(&ka.counters[k], v); }
         else if (v) atomicAdd(&ka.counters[k], v);
       }
-      if constexpr (POOLED) {
+      if constexpr (HL) {
         const unsigned long long v = __hip_atomic_load(&wg_counters[28], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (v) atomicAdd(&ka.counters[28], v);
       }

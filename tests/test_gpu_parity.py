@@ -335,6 +335,57 @@ def test_lit_cover_scene_light_frame_pool(gpu_render, oracle, abi, host):
             print(f"lit cover {len(sc.lights())} light(s) pool {pool}: kernel {st['kernel_ms']:.3f} ms")
 
 
+def test_light_pools_repeats_and_the_hbm_overflow(pkg, gpu_render, oracle, abi, host, torch_cuda):
+    """The light records of a lit kernel live in two LDS pools of the workgroup (frames, colour-map bases; rt_core.h) — no
+    per-lane scratch object.  Three lights and occluders: a third of the light rays' own hits start sampling the lights
+    again (nested activations, linked pool records).  The frame must not depend on where a record came from: tiny frame
+    pool (camera-path hits repeat their segment, nested ones overflow to HBM), tiny base pool (repeats), nested
+    activations ALWAYS through the HBM overflow, and all of it at once give the automatic pools' frame bit for bit, the
+    oracle's image and exactly the oracle's path count."""
+    objs = ['{"center":{"x":0.0,"y":-100.5,"z":-1.0},"radius":100.0,"material":{"Lambertian":{"albedo":[0.7,0.7,0.7]}}}']
+    for i, x in enumerate((-2.0, 0.0, 2.0)):
+        objs.append('{"center":{"x":%f,"y":2.5,"z":-2.0},"radius":0.5,"material":{"Light":{}}}' % x)
+        objs.append('{"center":{"x":%f,"y":0.0,"z":-1.5},"radius":0.5,"material":{"%s}}' %
+                    (x, ['Lambertian":{"albedo":[0.9,0.2,0.2]}', 'Glass":{"index_of_refraction":1.5}', 'Metal":{"albedo":[0.8,0.8,0.9],"fuzz":0.2}'][i]))
+        objs.append('{"center":{"x":%f,"y":1.2,"z":-1.8},"radius":0.3,"material":{"Lambertian":{"albedo":[0.3,0.9,0.4]}}}' % x)
+    text = ('{"width":200,"height":120,"samples_per_pixel":16,"max_depth":6,"sky":null,"camera":{"look_from":{"x":0.0,"y":1.0,"z":3.0},'
+            '"look_at":{"x":0.0,"y":0.5,"z":-1.0},"vup":{"x":0.0,"y":1.0,"z":0.0},"vfov":60.0,"aspect":1.6},"objects":[' + ",".join(objs) + "]}")
+    for general_map in (False, True):
+        sc = host.Scene.loads(text.replace("[0.9,0.2,0.2]", "[1.4,0.2,0.2]") if general_map else text)   # an albedo above 1: the general colour map (no bases)
+        o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+        first = None
+        for opts in ({}, {"light_pool": 32}, {"light_base_pool": 32}, {"light_nest_pool": 0}, {"light_pool": 32, "light_base_pool": 32, "light_nest_pool": 0},
+                     {"light_pool": 64, "chunk_spp": 4, "tile_log2": 1}):
+            rgb, lin, st = gpu_render(sc, opts=opts)
+            assert_parity(rgb, lin, o_rgb, o_lin, f"3 lights, general map {general_map}, {opts}", atol=pooled_atol(16))
+            assert st["segments"] == o_st["segments"] - o_st["segments_discarded"], (opts, st["segments"])
+            first = first if first is not None else (rgb, lin)
+            assert np.array_equal(rgb, first[0]) and np.array_equal(lin, first[1]), opts
+            if opts.get("light_pool") == 32 or (opts.get("light_base_pool") == 32 and not general_map):
+                assert st["segments_repeated"] > 0, (opts, st["segments_repeated"])    # the exhausted pool was really met
+            print(f"3 lights general_map={general_map} {opts}: kernel {st['kernel_ms']:.3f} ms, repeated {st['segments_repeated']}")
+    # what the automatic sizing gives: the reference's test scene (7 spheres, one light) has room for a base per lane and 896 frames;
+    # the cover scene + one light keeps its tables in LDS beside pools of at least 1.2 x the expected demand
+    import json as _json
+    gs = pkg.hip.HipScene(host.Scene.load(os.path.join(ROOT, "scenes", "cfg1_test_800x600_spp16.json")).ptr, 0)
+    fb = torch_cuda.zeros((600, 800, 3), dtype=torch_cuda.uint8, device="cuda:0")
+    gs.render(fb.data_ptr(), 0, None, torch_cuda.cuda.current_stream().cuda_stream); gs.wait()
+    assert gs.query("lds_tables") == 1 and gs.query("light_pool_slots") >= 512 and gs.query("light_base_slots") == 1024, (gs.query("light_pool_slots"), gs.query("light_base_slots"))
+    assert gs.query("lds_bytes") <= 160 * 1024
+    gs.close()
+    cfg = _json.load(open(os.path.join(ROOT, "scenes", "cfg2_cover_1200x800_spp128.json")))
+    cfg.update(width=96, height=64, samples_per_pixel=2)
+    cfg["objects"].append({"center": {"x": 0.0, "y": 30.0, "z": 10.0}, "radius": 8.0, "material": {"Light": {}}})
+    sc = host.Scene.loads(_json.dumps(cfg))
+    gs = pkg.hip.HipScene(sc.ptr, 0)
+    fb = torch_cuda.zeros((64, 96, 3), dtype=torch_cuda.uint8, device="cuda:0")
+    gs.render(fb.data_ptr(), 0, None, torch_cuda.cuda.current_stream().cuda_stream); st = gs.wait()
+    print("lit cover pools:", gs.query("light_pool_slots"), gs.query("light_base_slots"), "lds", gs.query("lds_bytes"))
+    assert gs.query("lds_tables") == 1 and gs.query("light_pool_slots") >= 1.2 * 66 and gs.query("light_base_slots") >= 1.2 * 0.19 * 1024
+    assert st["segments_repeated"] == 0
+    gs.close()
+
+
 def test_lit_cover_scene_tables_beside_the_parked_light_state(gpu_render, oracle, abi, host):
     """lights in a gridded scene, two of them: every fifth hit of depth 0/1 samples them (with two lights the pool of
     light frames would be too small: one frame per lane, tables through L2).  Same frame as the oracle's, grid or brute
