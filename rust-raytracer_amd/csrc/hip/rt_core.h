@@ -173,7 +173,7 @@ struct DevScene {
   const MatCore* matc;         // [n_spheres]
   // lit scenes: where a SUSPENDED light activation goes when the workgroup's pool has no record for the nested one that
   // suspends it (80 B x (RT_MAX_LIGHT_NEST - 1) per lane of the launch, in HBM; practically never touched): the guarantee
-  // that a lane holding records never waits for one (rt_core.h light_frame_push)
+  // that a lane holding records never waits for one (lane_light_begin)
   unsigned char* light_overflow;
   uint32_t light_nest_pool;    // 1 (default): nested activations take pool records; 0: always the overflow ("light_nest_pool" option, tests)
   uint32_t pad3;
@@ -1129,10 +1129,10 @@ constexpr uint32_t LIGHT_CENTRES_LDS_MAX = 32u;       // light centres staged in
 constexpr uint32_t LIGHT_POOL_LDS_OFF = (32u + 32u * 8u) + (RT_BLOCK / 64u) * 3u * 1024u + (RT_BLOCK / 64u) * 64u * 16u + LIGHT_CENTRES_LDS_MAX * 24u;
 constexpr uint32_t LIGHT_POOL_BITMAP_BYTES = 128u;   // 1024 slots at most, per pool
 constexpr uint32_t LIGHT_POOL_MAX_SLOTS = 1024u;
-constexpr uint32_t LIGHT_BASE_BYTES = 24u;
+constexpr uint32_t LIGHT_BASE_BYTES = 32u;  // p[3], h[3] + 8 B of padding: a base is addressed by its INDEX (a shift), not by a byte offset
 constexpr uint32_t LIGHT_BASE_BITMAP_LDS_OFF = LIGHT_POOL_LDS_OFF + LIGHT_POOL_BITMAP_BYTES;
-constexpr uint32_t LIGHT_FRAMES_LDS_OFF = LIGHT_POOL_LDS_OFF + 2u * LIGHT_POOL_BITMAP_BYTES;
-RT_HD uint32_t light_bases_lds_off(uint32_t frame_slots) { return LIGHT_FRAMES_LDS_OFF + frame_slots * (uint32_t)sizeof(LightParked); }
+constexpr uint32_t LIGHT_BASES_LDS_OFF = LIGHT_POOL_LDS_OFF + 2u * LIGHT_POOL_BITMAP_BYTES;  // the bases first (fixed offset), the frames behind them
+RT_HD uint32_t light_frames_lds_off(uint32_t base_slots) { return LIGHT_BASES_LDS_OFF + base_slots * LIGHT_BASE_BYTES; }
 constexpr uint32_t LIGHT_LINK_OVERFLOW = 1u;  // link of a record whose suspended parent is in the HBM overflow (record offsets are multiples of 16)
 constexpr uint32_t LIGHT_OVERFLOW_BYTES_PER_LANE = (RT_MAX_LIGHT_NEST - 1u) * (uint32_t)sizeof(LightParked);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1154,42 +1154,52 @@ struct LightState<true, true> {
   // sit on the 128-register edge)
   uint32_t wt;
 };
-static_assert(RT_MAX_LIGHT_NEST <= 16u && LIGHT_FRAMES_LDS_OFF % 16u == 0u && sizeof(LightParked) % 16u == 0u && LIGHT_BASE_BYTES % 8u == 0u,
-              "the nesting level shares a register with the record offset: offsets are multiples of 16; base offsets travel as offset / 8");
+static_assert(RT_MAX_LIGHT_NEST <= 16u && LIGHT_BASES_LDS_OFF % 16u == 0u && sizeof(LightParked) % 16u == 0u && LIGHT_BASE_BYTES % 16u == 0u,
+              "the nesting level shares a register with the record offset: offsets are multiples of 16");
 RT_HD uint32_t ls_where(const LightState<true, true>& ls) { return ls.wt & ~15u; }
 RT_HD int ls_top(const LightState<true, true>& ls) { return (int)(ls.wt & 15u); }
 RT_HD void ls_set_top(LightState<true, true>& ls, int t) { ls.wt = (ls.wt & ~15u) | (uint32_t)t; }
 RT_HD int ls_top(const LightState<true, false>& ls) { return ls.top; }
 RT_HD void ls_set_top(LightState<true, false>& ls, int t) { ls.top = t; }
 RT_HD LightParked& light_frame(LightState<true, false>& ls) { return *ls.pk; }
-RT_HD void light_frame_release(LightState<true, false>&) {}
+RT_HD void light_frame_release(const DevScene&, LightState<true, false>&) {}
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ LightParked& light_frame(LightState<true, true>& ls) { return *reinterpret_cast<LightParked*>(rt_lds_dyn + ls_where(ls)); }
 __device__ __forceinline__ uint32_t& light_link(uint32_t where) { return *reinterpret_cast<uint32_t*>(rt_lds_dyn + where + (uint32_t)sizeof(LightFrame)); }
-// take a record of the pool whose bitmap sits at `bitmap_off` (n_slots of them, a multiple of 32): its index, or ~0: none free
+// Take a record of the pool whose bitmap sits at `bitmap_off` (n_slots of them, a multiple of 32): its index, or ~0: none
+// free.  Everything here is full-rate arithmetic: the start word is a 16-bit multiplicative hash of the seed scaled to the
+// word count by a 24-bit multiply (the round-4 form took `hash % words` — ~20 instructions of emulated division, five of
+// them quarter-rate multiplies — in a branch some lane of nearly every wave iteration takes), and one flat loop.
 __device__ __forceinline__ uint32_t light_pool_take(uint32_t bitmap_off, uint32_t n_slots, uint32_t seed) {
   uint32_t* const bitmap = reinterpret_cast<uint32_t*>(rt_lds_dyn + bitmap_off);
   const uint32_t words = n_slots >> 5;
-  uint32_t w = ((seed * 2654435761u) >> 16) % words;
-  for (uint32_t tries = 0; tries < words; ++tries) {
-    uint32_t cur = __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (cur != 0xFFFFFFFFu) {
-      const uint32_t b = (uint32_t)__builtin_ctz(~cur);
-      const uint32_t old = __hip_atomic_fetch_or(&bitmap[w], 1u << b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (!((old >> b) & 1u)) return (w << 5) + b;
-      cur = old | (1u << b);
+  uint32_t w = __umul24(__umul24(seed & 0xFFFFu, 0x9E3Bu) & 0xFFFFu, words) >> 16, full = 0;
+  uint32_t cur = __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (;;) {
+    if (cur == 0xFFFFFFFFu) {  // this word is full (as far as this lane has seen): the next one, all of them once
+      if (++full >= words) return 0xFFFFFFFFu;
+      w = w + 1u == words ? 0u : w + 1u;
+      cur = __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      continue;
     }
-    w = w + 1u == words ? 0u : w + 1u;
+    const uint32_t b = (uint32_t)__builtin_ctz(~cur);
+    const uint32_t old = __hip_atomic_fetch_or(&bitmap[w], 1u << b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (!((old >> b) & 1u)) return (w << 5) + b;
+    cur = old | (1u << b);
   }
-  return 0xFFFFFFFFu;
 }
 __device__ __forceinline__ void light_pool_give(uint32_t bitmap_off, uint32_t slot) {  // (after the last read of the record)
   uint32_t* const bitmap = reinterpret_cast<uint32_t*>(rt_lds_dyn + bitmap_off);
   __hip_atomic_fetch_and(&bitmap[slot >> 5], ~(1u << (slot & 31u)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// index of the frame record at LDS offset `where`: (where - first record) / 80 without a division — offsets are multiples
+// of 16, y / 5 = (y * ceil(2^16 / 5)) >> 16 exactly for y < 2^14 (an LDS offset / 16)
+__device__ __forceinline__ uint32_t light_frame_slot(const DevScene& sc, uint32_t where) {
+  return __umul24((where - light_frames_lds_off(sc.light_base_slots)) >> 4, 13108u) >> 16;
+}
 // the camera-path activation is back on the camera path: give its frame record back
-__device__ __forceinline__ void light_frame_release(LightState<true, true>& ls) {
-  light_pool_give(LIGHT_POOL_LDS_OFF, (ls_where(ls) - LIGHT_FRAMES_LDS_OFF) / (uint32_t)sizeof(LightParked));
+__device__ __forceinline__ void light_frame_release(const DevScene& sc, LightState<true, true>& ls) {
+  light_pool_give(LIGHT_POOL_LDS_OFF, light_frame_slot(sc, ls_where(ls)));
   ls.wt = 0u;
 }
 __device__ __forceinline__ unsigned char* light_overflow_slot(const DevScene& sc, int level) {
@@ -1199,32 +1209,13 @@ __device__ __forceinline__ unsigned char* light_overflow_slot(const DevScene& sc
   asm volatile("" : "+v"(tid));
   return sc.light_overflow + ((size_t)(blockIdx.x * (uint32_t)RT_BLOCK + tid) * (RT_MAX_LIGHT_NEST - 1u) + (uint32_t)level) * sizeof(LightParked);
 }
-// a light ray's own hit starts sampling the lights: the activation whose light ray it is gets suspended (level t), a
-// record for the nested one (level t + 1) becomes current
-__device__ __forceinline__ void light_frame_push(const DevScene& sc, LightState<true, true>& ls, uint32_t seed) {
-  const int t = ls_top(ls);
-  const uint32_t cur = ls_where(ls);
-  const uint32_t slot = sc.light_nest_pool ? light_pool_take(LIGHT_POOL_LDS_OFF, sc.light_pool_slots, seed) : 0xFFFFFFFFu;
-  if (slot != 0xFFFFFFFFu) {
-    const uint32_t nw = LIGHT_FRAMES_LDS_OFF + slot * (uint32_t)sizeof(LightParked);
-    light_link(nw) = cur;
-    ls.wt = nw | (uint32_t)(t + 1);
-  } else {  // no record free: a holder never waits — the suspended activation moves out to HBM, its record serves the nested one
-    const uint4* src = reinterpret_cast<const uint4*>(rt_lds_dyn + cur);
-    uint4* dst = reinterpret_cast<uint4*>(light_overflow_slot(sc, t));
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(LightParked) / 16u); ++i) dst[i] = src[i];
-    light_link(cur) = LIGHT_LINK_OVERFLOW;
-    ls.wt = cur | (uint32_t)(t + 1);
-  }
-}
-// ... and that nested activation has returned its colour: the suspended one is current again
+// ... and a nested activation has returned its colour: the suspended one is current again
 __device__ __forceinline__ void light_frame_pop(const DevScene& sc, LightState<true, true>& ls) {
   const int t = ls_top(ls) - 1;
   const uint32_t cur = ls_where(ls);
   const uint32_t link = light_link(cur);
   if (link != LIGHT_LINK_OVERFLOW) {
-    light_pool_give(LIGHT_POOL_LDS_OFF, (cur - LIGHT_FRAMES_LDS_OFF) / (uint32_t)sizeof(LightParked));
+    light_pool_give(LIGHT_POOL_LDS_OFF, light_frame_slot(sc, cur));
     ls.wt = link | (uint32_t)t;
   } else {
     const uint4* src = reinterpret_cast<const uint4*>(light_overflow_slot(sc, t));
@@ -1236,8 +1227,7 @@ __device__ __forceinline__ void light_frame_pop(const DevScene& sc, LightState<t
 }
 #else  // (host passes: the pooled form exists on the device only; the host simulator runs the direct form)
 inline LightParked& light_frame(LightState<true, true>&) { static LightParked never; return never; }
-inline void light_frame_release(LightState<true, true>&) {}
-inline void light_frame_push(const DevScene&, LightState<true, true>&, uint32_t) {}
+inline void light_frame_release(const DevScene&, LightState<true, true>&) {}
 inline void light_frame_pop(const DevScene&, LightState<true, true>&) {}
 #endif
 
@@ -1275,7 +1265,7 @@ struct Lane {
   uint32_t k;     // camera-path segment index of the current (or suspended) camera ray
   uint32_t s;     // current sample
   uint32_t in_light;  // bit 0: the current ray is a nested light ray; bit 1 (LANE_HAS_BASE): the sample's colour map has a base (lane_compose);
-                      // bits 16..31 (device): LDS byte offset / 8 of the sample's base record while it holds one, else 0
+                      // bits 16..31 (device): index + 1 of the sample's base record in the workgroup's pool while it holds one, else 0
   FwdT<SIMPLE> fwd;
   float val[3];   // radiance of the sample that just finished (valid when lane_shade returned true)
   RngAddr ra;
@@ -1326,50 +1316,76 @@ template <class LaneT>
 RT_HD float* lane_base(LaneT& L) {
   if constexpr (LaneT::kPooled) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return reinterpret_cast<float*>(rt_lds_dyn + ((L.in_light >> 16) << 3));
+    return reinterpret_cast<float*>(rt_lds_dyn + (LIGHT_BASES_LDS_OFF - LIGHT_BASE_BYTES) + (L.in_light >> 16) * LIGHT_BASE_BYTES);  // (index + 1 in the high half)
 #else
     (void)L;
     return nullptr;  // (host pass of the kernel's instantiations: never run)
 #endif
   } else return L.ls.stack->base;
 }
-// The sample's light records when a camera-path hit starts summing over the lights: its frame, and — short colour map —
-// its base unless an earlier level of the sample took one already.  Both or nothing: false = a pool is exhausted and
-// nothing has changed (the caller repeats the segment).
+// A hit starts summing over the lights (raytracer.rs:99-111): make room for its activation.
+//   camera path (light_ray false): its frame and — short colour map — the sample's base unless an earlier level took one
+//     already.  Both or nothing: false = a pool is exhausted and NOTHING has changed (the caller repeats the segment).
+//   a light ray's own hit (light_ray true): the activation whose light ray it is gets suspended (level t), a record for
+//     the nested one (level t + 1) becomes current — from the pool, or by moving the suspended one out to the lane's HBM
+//     overflow slot and reusing its record: never false (a lane that holds records does not wait for one).
+// ONE take of each pool in the instruction stream (a wave runs every inlined copy some lane reaches).
 template <class LaneT>
-RT_HD bool lane_light_acquire(const DevScene& sc, LaneT& L) {
+RT_HD bool lane_light_begin(const DevScene& sc, LaneT& L, bool light_ray) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (LaneT::kPooled) {
-    const uint32_t seed = L.ra.pixel + L.ra.sample;
+    const uint32_t seed = L.ra.pixel + L.ra.sample + L.node;
     uint32_t base_slot = 0xFFFFFFFFu;
     if constexpr (LaneT::kSimple) {
-      if ((L.in_light >> 16) == 0u) {
+      if (!light_ray && (L.in_light >> 16) == 0u) {
         base_slot = light_pool_take(LIGHT_BASE_BITMAP_LDS_OFF, sc.light_base_slots, seed);
         if (base_slot == 0xFFFFFFFFu) return false;
       }
     }
-    const uint32_t slot = light_pool_take(LIGHT_POOL_LDS_OFF, sc.light_pool_slots, seed);
-    if (slot == 0xFFFFFFFFu) {
-      if (base_slot != 0xFFFFFFFFu) light_pool_give(LIGHT_BASE_BITMAP_LDS_OFF, base_slot);
-      return false;
+    const uint32_t slot = (!light_ray || sc.light_nest_pool != 0u) ? light_pool_take(LIGHT_POOL_LDS_OFF, sc.light_pool_slots, seed) : 0xFFFFFFFFu;
+    const uint32_t nw = light_frames_lds_off(sc.light_base_slots) + __umul24(slot, (uint32_t)sizeof(LightParked));
+    if (!light_ray) {
+      if (slot == 0xFFFFFFFFu) {
+        if (base_slot != 0xFFFFFFFFu) light_pool_give(LIGHT_BASE_BITMAP_LDS_OFF, base_slot);
+        return false;
+      }
+      if (base_slot != 0xFFFFFFFFu) L.in_light |= (base_slot + 1u) << 16;
+      L.ls.wt = nw;  // (nesting level 0)
+      return true;
     }
-    if (base_slot != 0xFFFFFFFFu) L.in_light |= ((light_bases_lds_off(sc.light_pool_slots) + base_slot * LIGHT_BASE_BYTES) >> 3) << 16;
-    L.ls.wt = LIGHT_FRAMES_LDS_OFF + slot * (uint32_t)sizeof(LightParked);  // (nesting level 0)
+    const int t = ls_top(L.ls);
+    const uint32_t cur = ls_where(L.ls);
+    if (slot != 0xFFFFFFFFu) {
+      light_link(nw) = cur;
+      L.ls.wt = nw | (uint32_t)(t + 1);
+    } else {  // no record free: the suspended activation moves out to HBM, its record serves the nested one
+      const uint4* src = reinterpret_cast<const uint4*>(rt_lds_dyn + cur);
+      uint4* dst = reinterpret_cast<uint4*>(light_overflow_slot(sc, t));
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(LightParked) / 16u); ++i) dst[i] = src[i];
+      light_link(cur) = LIGHT_LINK_OVERFLOW;
+      L.ls.wt = cur | (uint32_t)(t + 1);
+    }
+    return true;
+  } else
+#endif
+  {
+    if constexpr (!LaneT::kPooled) {
+      if (light_ray) light_frame_push(sc, L.ls, 0u);
+      else ls_set_top(L.ls, 0);
+    }
+    (void)sc; (void)light_ray;
     return true;
   }
-#endif
-  (void)sc;
-  ls_set_top(L.ls, 0);
-  return true;
 }
 // ... and when the sample ends: its base record goes back (device form; after the last read of it)
 template <class LaneT>
 RT_HD void lane_base_release(const DevScene& sc, LaneT& L) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (LaneT::kPooled && LaneT::kSimple) {
-    const uint32_t off = (L.in_light >> 16) << 3;
-    if (off != 0u) {
-      light_pool_give(LIGHT_BASE_BITMAP_LDS_OFF, (off - light_bases_lds_off(sc.light_pool_slots)) / LIGHT_BASE_BYTES);
+    const uint32_t held = L.in_light >> 16;  // index + 1
+    if (held != 0u) {
+      light_pool_give(LIGHT_BASE_BITMAP_LDS_OFF, held - 1u);
       L.in_light &= 0xFFFFu;
     }
   }
@@ -1498,7 +1514,7 @@ RT_HD bool lane_light_return(const DevScene& sc, const Tables& tb, LaneT& L, Rgb
     }
     if (ls_top(L.ls) == 0) {  // back on the camera path: clamp(light + albedo*child), child = scattered ray
       const bool fin = lane_continue_main(sc, L, f.P, light_frame(L.ls).saved_d, light, f.a, true);
-      light_frame_release(L.ls);  // (after the last read of the frame)
+      light_frame_release(sc, L.ls);  // (after the last read of the frame)
       return fin;
     }
     // a nested activation (max_depth 2, depth 1): its own child is depth 0 = black (:117-122)
@@ -1588,13 +1604,11 @@ RT_HD int lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, do
       }
     }
     if (act == ACT_SAMPLE) {
-      if (light_ray) light_frame_push(sc, L.ls, L.ra.pixel + L.ra.sample + L.node);  // suspend the activation whose light ray this is
-      else {
-        // (the device's pools: no record free -> nothing has changed yet: the same segment is traced again; the caller counts
-        //  the segment once — its exact tests and grid steps are the work actually done, and counted as such)
-        if (!lane_light_acquire(sc, L)) return LANE_REPEAT;
-        light_frame(L.ls).saved_d = out_dir;
-      }
+      // (a light ray's hit suspends the activation whose light ray it is; a camera-path hit that finds a pool of the device
+      //  form exhausted has changed nothing yet: the same segment is traced again; the caller counts the segment once — its
+      //  exact tests and grid steps are the work actually done, and counted as such)
+      if (!lane_light_begin(sc, L, light_ray)) return LANE_REPEAT;
+      if (!light_ray) light_frame(L.ls).saved_d = out_dir;
       LightFrame& f = light_frame(L.ls).cur;
       f.P = point; f.a[0] = att[0]; f.a[1] = att[1]; f.a[2] = att[2];
       f.acc[0] = f.acc[1] = f.acc[2] = 0.0f; f.j = 0; f.node = L.node;

@@ -73,7 +73,7 @@ struct RtHipScene {
   int light_pool_cap = 0;  // "light_pool" option: cap on the light-frame pool of lit scenes (0 = automatic; tests shrink it to force repeats and overflows)
   int light_base_cap = 0;  // "light_base_pool" option: the same for the pool of colour-map bases
   int light_nest_pool = 1; // "light_nest_pool" option: 0 = nested light activations always go through the HBM overflow (tests)
-  void* d_light_overflow = nullptr; size_t light_overflow_bytes = 0;  // lit scenes: 560 B per lane of the largest launch so far (rt_core.h light_frame_push)
+  void* d_light_overflow = nullptr; size_t light_overflow_bytes = 0;  // lit scenes: 560 B per lane of the largest launch so far (rt_core.h lane_light_begin)
   size_t lds_cap = 0;      // dynamic LDS a workgroup may ask for on this device
   uint32_t last_pool_slots = 0, last_base_slots = 0; size_t last_lds_bytes = 0; bool last_lds_tables = false;  // of the last launch (rt_hip_scene_query)
   int chunk_spp = 0;       // 0 = automatic
@@ -332,7 +332,7 @@ int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka_in, size_t lds_bytes, uint
   if (wgs > need) wgs = need;
   s->last_waves = (uint64_t)wgs * rtk::WAVES;
   rtk::KArgs ka = ka_in;
-  if (HL) {  // the lanes' overflow slots for suspended light activations (rt_core.h light_frame_push): sized for this launch, kept
+  if (HL) {  // the lanes' overflow slots for suspended light activations (rt_core.h lane_light_begin): sized for this launch, kept
     const size_t need_bytes = (size_t)wgs * rtk::BLOCK * rtc::LIGHT_OVERFLOW_BYTES_PER_LANE;
     if (need_bytes > s->light_overflow_bytes) {
       // (an earlier launch of this scene may still be running on this stream with the old buffer: drain it first — once per scene

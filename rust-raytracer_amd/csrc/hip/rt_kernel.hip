@@ -125,7 +125,7 @@ __host__ __device__ inline uint32_t tile_slots(uint32_t tile_log2) {
 struct LdsLayout {
   uint32_t hdr_off, coop_off, light_off, park_off, geom_off, matc_off, cell_off, item_off, total;
 };
-// light records (lit scenes): [frame bitmap][base bitmap][pool of frame_slots LightParked][pool of base_slots colour-map bases] (rt_core.h)
+// light records (lit scenes): [frame bitmap][base bitmap][pool of base_slots colour-map bases][pool of frame_slots LightParked] (rt_core.h)
 __host__ __device__ constexpr uint32_t park_bytes(uint32_t frame_slots, uint32_t base_slots) {
   return 2u * LIGHT_POOL_BITMAP_BYTES + frame_slots * (uint32_t)sizeof(LightParked) + base_slots * LIGHT_BASE_BYTES;
 }
@@ -442,7 +442,10 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     if (packed) {
       const uint32_t nxt = (uint32_t)__shfl_down((int)rgb, 1);
       uint32_t i = lane & 3u;
-      asm volatile("" : "+v"(i));  // (made here: hoisted out of the path loop, i, 8 i, 24 - 8 i and a zero-extended copy held four registers for good — spilled in the lit kernels)
+      // (made here: hoisted out of the path loop, i, 8 i, 24 - 8 i and a zero-extended copy hold four registers for good — spilled
+      //  in the lit kernels and with the general colour map; the unlit short-map kernel has them to spare and is 0.6 % faster with
+      //  the hoisted form, profiles/r05_run1_ab_lit.log)
+      if constexpr (HL || !SIMPLE) asm volatile("" : "+v"(i));
       if (valid && i < 3u) *reinterpret_cast<uint32_t*>(ka.out_rgb8 + o + i) = (rgb >> (8u * i)) | (nxt << (24u - 8u * i));
     } else if (valid) {
       ka.out_rgb8[o] = (uint8_t)rgb; ka.out_rgb8[o + 1] = (uint8_t)(rgb >> 8); ka.out_rgb8[o + 2] = (uint8_t)(rgb >> 16);

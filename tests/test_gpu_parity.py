@@ -335,7 +335,7 @@ def test_lit_cover_scene_light_frame_pool(gpu_render, oracle, abi, host):
             print(f"lit cover {len(sc.lights())} light(s) pool {pool}: kernel {st['kernel_ms']:.3f} ms")
 
 
-def test_light_pools_repeats_and_the_hbm_overflow(pkg, gpu_render, oracle, abi, host, torch_cuda):
+def test_light_pools_repeats_and_the_hbm_overflow(pkg, gpu_render, oracle, abi, host, torch_cuda, load_scene):
     """The light records of a lit kernel live in two LDS pools of the workgroup (frames, colour-map bases; rt_core.h) — no
     per-lane scratch object.  Three lights and occluders: a third of the light rays' own hits start sampling the lights
     again (nested activations, linked pool records).  The frame must not depend on where a record came from: tiny frame
@@ -367,7 +367,8 @@ def test_light_pools_repeats_and_the_hbm_overflow(pkg, gpu_render, oracle, abi, 
     # what the automatic sizing gives: the reference's test scene (7 spheres, one light) has room for a base per lane and 896 frames;
     # the cover scene + one light keeps its tables in LDS beside pools of at least 1.2 x the expected demand
     import json as _json
-    gs = pkg.hip.HipScene(host.Scene.load(os.path.join(ROOT, "scenes", "cfg1_test_800x600_spp16.json")).ptr, 0)
+    sc1 = load_scene("test")
+    gs = pkg.hip.HipScene(sc1.ptr, 0)
     fb = torch_cuda.zeros((600, 800, 3), dtype=torch_cuda.uint8, device="cuda:0")
     gs.render(fb.data_ptr(), 0, None, torch_cuda.cuda.current_stream().cuda_stream); gs.wait()
     assert gs.query("lds_tables") == 1 and gs.query("light_pool_slots") >= 512 and gs.query("light_base_slots") == 1024, (gs.query("light_pool_slots"), gs.query("light_base_slots"))
@@ -381,7 +382,7 @@ def test_light_pools_repeats_and_the_hbm_overflow(pkg, gpu_render, oracle, abi, 
     fb = torch_cuda.zeros((64, 96, 3), dtype=torch_cuda.uint8, device="cuda:0")
     gs.render(fb.data_ptr(), 0, None, torch_cuda.cuda.current_stream().cuda_stream); st = gs.wait()
     print("lit cover pools:", gs.query("light_pool_slots"), gs.query("light_base_slots"), "lds", gs.query("lds_bytes"))
-    assert gs.query("lds_tables") == 1 and gs.query("light_pool_slots") >= 1.2 * 66 and gs.query("light_base_slots") >= 1.2 * 0.19 * 1024
+    assert gs.query("lds_tables") == 1 and gs.query("light_pool_slots") >= 1.2 * 66 and gs.query("light_base_slots") >= 1.2 * 0.16 * 1024
     assert st["segments_repeated"] == 0
     gs.close()
 
