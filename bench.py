@@ -240,6 +240,8 @@ def run_group(args):
     sync_all()
     # the assembled frame against ONE launch of the whole frame on the first device (same process): must be byte-identical
     frame, _ = grp.render_to_host()
+    info = grp.info()                  # (again: a gather that failed to enqueue mid-run has switched the transport)
+    ranks = grp.ranks()                # where every rank runs + its kernel of the last frame
     one = hip.HipScene(sc.ptr, devs[0])
     if args.variant:
         one.set_option("variant", args.variant)
@@ -281,11 +283,88 @@ def run_group(args):
         "speedup_vs_n1_latency": round(n1_kernel_ms / med(lat), 3),
         "speedup_vs_n1_pipelined": round(n1_kernel_ms / ms_per_step, 3),
         "frame_identical_to_n1": identical,
-        "rccl_ranks": info["rccl_comms"], "transport": info["transport"], "rank_devices": info["rank_devices"],
+        "rccl_ranks": info["rccl_comms"], "transport": info["transport"], "transport_fallback": info["transport_fallback"],
+        "transport_fallback_reason": info["fallback_reason"] or None, "rank_devices": info["rank_devices"],
         "distinct_devices": info["n_devices"], "visible_gpus": visible, "setup_ms": round(setup_s * 1e3, 1),
+        # one line explains its own efficiency: per rank, its kernel of the last blocking frame, when its host thread ran and had its
+        # launch enqueued (us since submit), where its device sits and whether it reaches the first device directly
+        "per_rank": {"kernel_ms": [round(r["kernel_ms"], 4) for r in ranks], "t_wake_us": [round(r["t_wake_us"], 1) for r in ranks],
+                     "t_enq_us": [round(r["t_enq_us"], 1) for r in ranks], "pci_bus_id": [r["pci_bus_id"] for r in ranks],
+                     "numa_node": [r["numa_node"] for r in ranks], "pinned_cpus": [r["pinned_cpus"] for r in ranks],
+                     "peer_to_root": [r["peer_to_root"] for r in ranks]},
         "git_head": _git_head(),
     }
     return json.dumps(out)
+
+
+def _init_collective(torch, dist, rank, world, dev):
+    """Bring up the process groups of an N-rank run so that the TRANSPORT can never cost the run.  The default group is gloo
+    (TCP on 127.0.0.1: the control plane — barriers, the ranks' statistics); the tiles travel on a second group, RCCL
+    ("nccl"), IF it comes up on every rank and a first gather of known bytes arrives intact on rank 0 — decided by all ranks
+    together over gloo, so nobody waits in a collective the others have given up on.  Otherwise (communicator error, a
+    gather that raises, times out — blocking wait, 120 s — or delivers wrong bytes; RT_BENCH_FORCE_TRANSPORT=gloo: tests):
+    the tiles are staged through pinned host memory and gathered over gloo ("gloo-host"): the same frame, no xGMI, and the
+    line says so.  Returns (transport, data group, note)."""
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    forced = os.environ.get("RT_BENCH_FORCE_TRANSPORT", "")
+    ok, why, pg = 1, "", None
+    if forced == "gloo":
+        ok, why = 0, "RT_BENCH_FORCE_TRANSPORT=gloo"
+    else:
+        os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")   # a collective that hangs raises after its timeout instead of taking the process down
+        try:
+            if os.environ.get("RT_BENCH_INJECT_NCCL_FAILURE") == "1":
+                raise RuntimeError("injected (RT_BENCH_INJECT_NCCL_FAILURE=1)")
+            pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))   # nccl == RCCL on ROCm; communicators come up with the first collective
+            probe = torch.full((4096,), rank + 1, dtype=torch.uint8, device=dev)
+            outs = [torch.zeros(4096, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+            dist.gather(probe, outs, dst=0, group=pg)
+            torch.cuda.synchronize()
+            if rank == 0:
+                got = [int(o[-1].item()) for o in outs]
+                if got != list(range(1, world + 1)):
+                    raise RuntimeError(f"self-test gather delivered {got}")
+        except BaseException as e:   # noqa: BLE001
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            ok, why = 0, f"{type(e).__name__}: {e}"[:300]
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # (gloo, CPU tensor: every rank learns whether ALL ranks are fine)
+    if int(flag[0]) == 1:
+        return "rccl", pg, ""
+    whys = [None] * world
+    dist.all_gather_object(whys, why)
+    if pg is not None:
+        try:
+            dist.destroy_process_group(pg)
+        except Exception:
+            pass
+    note = "; ".join(f"rank {r}: {w}" for r, w in enumerate(whys) if w) or "another rank failed"
+    return "gloo-host", None, note
+
+
+def _device_place(torch, local_rank):
+    """where this rank's GPU sits: PCI bus id, the NUMA node sysfs reports, peer access to device 0 of the node"""
+    prop = torch.cuda.get_device_properties(local_rank)
+    pci = ""
+    for attr in ("pci_bus_id", "pci_device_id", "pci_domain_id"):
+        if not hasattr(prop, attr):
+            pci = ""
+            break
+    else:
+        pci = f"{prop.pci_domain_id:04x}:{prop.pci_bus_id:02x}:{prop.pci_device_id:02x}.0"
+    numa = -1
+    try:
+        numa = int(open(f"/sys/bus/pci/devices/{pci}/numa_node").read())
+    except Exception:
+        pass
+    peer = 1
+    try:
+        peer = int(torch.cuda.can_device_access_peer(local_rank, 0)) if local_rank != 0 else 1
+    except Exception:
+        peer = -1
+    return {"pci_bus_id": pci, "numa_node": numa, "peer_to_root": peer, "uuid": str(getattr(prop, "uuid", "")), "host": os.uname().nodename, "local_rank": local_rank}
 
 
 def run_ranks(args):
@@ -306,6 +385,7 @@ def run_ranks(args):
     # code path exercised on a 1-GPU box (self-check; the line then says so in config.parallelism)
     force_coll = world == 1 and os.environ.get("RT_BENCH_FORCE_COLLECTIVE") == "1"
     collective = world > 1 or force_coll
+    transport, data_group, transport_note = "none", None, ""
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -316,8 +396,7 @@ def run_ranks(args):
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
-            dist.barrier()
+            transport, data_group, transport_note = _init_collective(torch, dist, rank, world, dev)
         finally:
             _flush_c_stdio()
             os.dup2(saved_fd, 1)
@@ -341,18 +420,18 @@ def run_ranks(args):
     if args.variant:
         gs.set_option("variant", args.variant)
     tiles = rdist.shard(rank, world)
-    pipe = rdist.FramePipeline(H, W, rank, world, dev, force_collective=force_coll)   # double-buffered tiles; frame i's gather runs under frame i+1
+    pipe = rdist.FramePipeline(H, W, rank, world, dev, force_collective=force_coll,   # double-buffered tiles; frame i's gather runs under frame i+1
+                               group=data_group if collective else None, host_staged=collective and transport == "gloo-host")
     stream = torch.cuda.current_stream()
 
     # every rank renders on its own GPU: collect (host, PCI bus id / uuid) of each rank's device and compare
     ranks_devices = None
+    place = _device_place(torch, local_rank)
     if collective:
-        prop = torch.cuda.get_device_properties(local_rank)
-        ident = (os.uname().nodename, str(getattr(prop, "uuid", "")), str(getattr(prop, "pci_bus_id", local_rank)), local_rank)
         gathered = [None] * world
-        dist.all_gather_object(gathered, ident)
+        dist.all_gather_object(gathered, place)
         ranks_devices = gathered
-        assert len({(g[0], g[1], g[2]) for g in gathered}) == world, f"ranks share a device: {gathered}"
+        assert len({(g["host"], g["uuid"], g["pci_bus_id"], g["local_rank"]) for g in gathered}) == world, f"ranks share a device: {gathered}"
 
     def fence():
         if collective:
@@ -413,7 +492,11 @@ def run_ranks(args):
         dist.barrier()
 
     t = torch.tensor([elapsed, kernel_ms, float(st["segments"]), float(st["exact_tests"]), float(st["grid_steps"]), lat_ms or 0.0],
-                     dtype=torch.float64, device=dev)
+                     dtype=torch.float64)   # (CPU: the default group is gloo)
+    per_rank = None
+    if collective:   # one line explains its own efficiency: every rank's kernel time (mean over the timed frames) and wall time
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"kernel_ms": round(kernel_ms, 4), "elapsed_ms": round(elapsed * 1e3, 3), "samples_share": round(st["samples"] / max(1, W * H * SPP), 5)})
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -481,7 +564,10 @@ def run_ranks(args):
             "dtype": "f64", "data": "scene derived from the reference's data/cover_scene.json (committed under scenes/); Philox seed 0",
             "config": {"workload": f"{os.path.basename(args.scene)}: {W}x{H} spp {SPP} depth {sc.c.max_depth}, {N_SPH} spheres"
                                    + (" (BASELINE configs[1])" if headline else " (NON-HEADLINE run)"),
-                       "parallelism": f"one process per GPU (torch.distributed.run): {world} x interleaved {rdist.TILE_ROWS}-scanline tiles, one RCCL gather per frame through torch.distributed (overlapping the next frame's render)" if world > 1 else ("single GPU (one-rank RCCL group forced: self-check)" if force_coll else "single GPU"),
+                       "parallelism": (f"one process per GPU (torch.distributed.run): {world} x interleaved {rdist.TILE_ROWS}-scanline tiles, one "
+                                       + ("RCCL gather per frame through torch.distributed (overlapping the next frame's render)" if transport == "rccl" else
+                                          "gather per frame over gloo with the tiles staged through pinned host memory — RCCL DID NOT COME UP, see transport_fallback_reason")) if world > 1
+                                      else (f"single GPU (one-rank {'RCCL' if transport == 'rccl' else 'gloo, host-staged'} group forced: self-check)" if force_coll else "single GPU"),
                        "inputs": "scene tables resident in HBM before the timed region"},
             "kernel_ms": round(kernel_ms, 4), "segments_per_sample": round(segments / samples, 4),
             "exact_tests_per_segment": round(exact / max(1.0, segments), 3),
@@ -489,9 +575,15 @@ def run_ranks(args):
             "roofline": roof,
         }
         if collective:
-            out["rccl_ranks"] = dist.get_world_size()
+            out["rccl_ranks"] = dist.get_world_size() if transport == "rccl" else 0
             out["visible_gpus"] = torch.cuda.device_count()
-            out["rank_devices"] = [f"{g[0]}:{g[2]}" for g in ranks_devices]
+            out["rank_devices"] = [f"{g['host']}:{g['pci_bus_id'] or g['local_rank']}" for g in ranks_devices]
+            out["transport"] = transport
+            out["transport_fallback"] = transport != "rccl"
+            out["transport_fallback_reason"] = transport_note or None
+            out["per_rank"] = {"kernel_ms": [p["kernel_ms"] for p in per_rank], "elapsed_ms": [p["elapsed_ms"] for p in per_rank],
+                               "samples_share": [p["samples_share"] for p in per_rank], "pci_bus_id": [g["pci_bus_id"] for g in ranks_devices],
+                               "numa_node": [g["numa_node"] for g in ranks_devices], "peer_to_root": [g["peer_to_root"] for g in ranks_devices]}
             out["frame_latency_ms"] = round(lat_ms, 4)      # ONE frame: render (slowest rank) + gather + row permutation, no overlap
             out["frame_latency_msamples_per_s"] = round(samples / lat_ms / 1e3, 1)
             if n1_kernel_ms is not None:
@@ -508,10 +600,7 @@ def run_ranks(args):
             out["frame_ms_to_host_buffer"] = round((time.perf_counter() - h0) * 1e3 / 3, 3)
             # `value` is the steady state of repeated frames of one view (the queue order learned from the previous frame,
             # DESIGN.md §4.1); a one-shot render (rt_render_rgb8, the reference's one frame per process) has no previous
-            # frame: the same kernel with the fixed bottom-row-first order, best of 3
-            # a one-shot render (rt_render_rgb8, the reference's one frame per process) has no previous frame: the same kernel
-            # with the fixed bottom-row-first order — the FIRST frame of a fresh scene, best of 3 (the seeded orders of round 4
-            # — projection guess, probe launch — are slower and off: tools/first_frame.py, profiles/r04_run3_first_frame_orders.log)
+            # frame: the same kernel with the fixed bottom-row-first order — the FIRST frame of a fresh scene, best of 3
             fb1 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
             k1 = []
             for _ in range(4):

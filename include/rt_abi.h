@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4u /* v4: RtStats.group_us, rt_hip_group_submit / _collect; v3: RtScene.n_gpus, RtStats.{segments_discarded, n_gpus_used, gather_ms, setup_ms}, rt_abi_sizeof */
+#define RT_ABI_VERSION 5u /* v5: RtGroupInfo.transport_fallback, RtGroupRank + rt_hip_group_ranks, rt_hip_group_fallback_reason; the device probes and
+                           * debug calls moved to rt_abi_test.h (librt_hip_probe.so); v4: RtStats.group_us, rt_hip_group_submit / _collect;
+                           * v3: RtScene.n_gpus, RtStats.{segments_discarded, n_gpus_used, gather_ms, setup_ms}, rt_abi_sizeof */
 
 /* Nested light-ray recursion (raytracer.rs:103-110 calls ray_color(.., 2, 1), which can
  * itself trigger light sampling again) is unbounded in the reference.  Oracle and kernel
@@ -249,58 +251,16 @@ int rt_hip_render(RtHipScene*, const RtRowTiles* tiles, void* d_rgb8, void* d_li
 /* Block until the last rt_hip_render on this scene finished; fill counters and the HIP-event
  * duration of its kernel (events are recorded on the stream the kernel was launched on). */
 int rt_hip_wait(RtHipScene*, RtStats* stats);
-/* Diagnostics (builds with -DRT_PROFILE only; other builds return stale memory): the 32 raw
- * launch counters, then {start, end, time the
- * wave found the tile queue empty, iterations after that | lanes x iterations << 32} of every
- * wave of the last launch, on the chip-wide 100 MHz clock.  Returns the number of waves copied
- * (out holds 32 + 4 x max_waves uint64) or a negative RtStatus. */
-int rt_hip_debug_timeline(RtHipScene*, uint64_t* out, uint32_t max_waves);
-/* Diagnostics: the deepest camera path per pixel tile that the last MEASURING frame recorded (tile_order 2: the first two
- * frames of a view) — what the queue order of later frames is sorted by.  out[tile], row-major over the launch's tile grid
- * (*tiles_x tiles wide); returns the number of tiles copied (<= cap) or a negative RtStatus. */
-int rt_hip_debug_tile_depth(RtHipScene*, uint32_t* out, uint32_t cap, uint32_t* tiles_x);
-/* Device self-tests (device pointers; tests/test_gpu_parity.py): correctly rounded f64 sqrt / divide,
- * f32 sqrt and atan2 of n operands; Sphere::hit (sphere.rs:46-58) of n (ray, sphere) pairs through
- * the kernel's own hit test — rays = n x {origin[3], direction[3]}, spheres = n x {center[3], radius},
- * out_t = the accepted root with t_max = f64::MAX, or -1. */
-int rt_hip_math_probe(const double* x, const double* y, double* out_sqrt, double* out_div, float* out_sqrtf, double* out_atan2,
-                      uint32_t n, void* stream);
-int rt_hip_hit_probe(const double* rays, const double* spheres, double* out_t, uint32_t n, void* stream);
-/* f64::atan2 (sphere.rs:39) of n (y, x) pairs through the device build of the routine kernel and CPU checker share
- * (csrc/common/rt_atan2.h): tests compare it with a committed fixture of correctly rounded results. */
-int rt_hip_atan2_probe(const double* d_y, const double* d_x, double* d_out, uint32_t n, void* stream);
-/* The texel of a Texture hit on the device, both ways (materials.rs:236-254 through sphere.rs:35-43): the kernel's fast
- * (u, v) — v_rsq_f64 / v_rcp_f64 + Newton steps, which only the device build takes — beside the exact path, for n hit
- * points (device, 3 doubles each) on the sphere centre_radius (host, 4 doubles).  d_out = n x {fast_ok, fast col, fast
- * row, exact col, exact row} (u64); d_uv (optional) = n x {fast u, fast v, exact u, exact v}, fast u = NaN where the fast
- * path declined.  rt_hip_quot_probe: rt_fast_quot(x, y), rt_fast_rsqrt(x) and (d_div optional) rt_div_inrange(x, y) — the
- * library division without range scaling and fix-up: must equal the IEEE quotient — of n positive normal operands. */
-int rt_hip_texel_probe(const double* d_points, const double centre_radius[4], double h_offset, uint64_t tex_w, uint64_t tex_h,
-                       uint64_t* d_out, double* d_uv, uint32_t n, void* stream);
-int rt_hip_quot_probe(const double* d_x, const double* d_y, double* d_quot, double* d_rsqrt, double* d_div, uint32_t n, void* stream);
-/* Tunables / A-B arms.  Keys: "variant" 0 = grid walk (default), 1 = the
- * reference's brute force (exact test on every sphere);
- * "chunk_spp" samples of a pixel per work item (0 = automatic); "tile_batch" tiles a workgroup takes from the frame's
- * queue at a time (0 = automatic, 1..64); "tile_log2" pixel tiles of
- * 4^k pixels (k = 0..3, -1 = automatic); "tile_shape" 0 (default) = a 2^k x 2^k square — except k = 1, which is a 4x1 strip (12 contiguous
- * framebuffer bytes: one packed store instead of two rows of byte stores; same time, 20 % less write traffic on the shards of a
- * multi-GPU frame), 1 = a run of 4^k pixels of one
- * scanline (one contiguous piece of the framebuffer: half the HBM write traffic, 0.9 % slower), 2 and 3 = the square widened
- * once and twice (16x4 and 32x2 at k = 3; 2 at k = 1 is the 2x2 square no other value selects); "tile_affinity" 1 (default) = on large frames, runs of 512 pixels of a
- * tile row are handed out by the XCD they belong to first (a framebuffer line then fills up in ONE L2 before it is written
- * back: half the HBM traffic, +0.5 % time), 0 = one queue, 2 = per-XCD queues on any frame of 8 or more runs (tests); "samples_per_pixel", "max_depth" (0 .. 2^32-1) and
- * "seed" override the scene's values; "tile_order" 0 = tiles leave the queue top row first, 1 = bottom row
- * first, 2 (default) = the tiles whose paths ran deepest in this scene's previous frame first (the frame ends on
- * its deepest paths; the image does not depend on the order) — a frame that has no previous one goes bottom row first;
- * "order_seed" (default 0) = 1 sorts such a frame's tiles by a depth guess from the spheres' projections, 2 by a probe
- * launch (one sample per pixel, 8 segments at most): round-4 experiments, both measured slower than no seed (DESIGN.md
- * §4.1); "tile_order" 3 = a seeded order alone, nothing measured or sorted for a next frame.  rt_hip_group_set_option also takes "spin_us" (0 .. 10^6,
- * default 0): how long a rank's idle host thread polls for the next frame before it sleeps.
- * Out-of-range values are RT_ERR_INVALID. */
+/* Options of a resident scene: (key, value) pairs, out-of-range values and unknown keys are RT_ERR_INVALID.  The keys, their
+ * ranges and defaults are tabulated in INTEGRATION.md §5 ("samples_per_pixel", "max_depth", "seed" override the scene's
+ * values; "variant" 1 = the reference's brute force; the rest shape the work distribution and never the image).
+ * rt_hip_group_set_option forwards to every rank's scene and takes "spin_us" itself. */
 int rt_hip_set_option(RtHipScene*, const char* key, int64_t value);
 /* What a resident scene was built into (diagnostics): "n_spheres", "n_lights", "grid_cells" (padded cell table, 8 B each),
  * "grid_items" (u16 each), "grid_large" (spheres every ray tests), "table_bytes" (geometry + material cores + cell table +
- * item lists: what a workgroup stages into LDS once per launch), "texel_bytes" (textures + sky as 4-byte texels in HBM).
+ * item lists: what a workgroup stages into LDS once per launch), "texel_bytes" (textures + sky as 4-byte texels in HBM);
+ * of the last launch: "lds_bytes" (dynamic LDS of a workgroup), "lds_tables" (1: the tables were staged in LDS),
+ * "light_pool_slots" / "light_base_slots" (lit scenes: records in the workgroup's pools of light frames / colour-map bases).
  * -1 for an unknown key. */
 int64_t rt_hip_scene_query(const RtHipScene*, const char* key);
 /* Animation (the reference's `anim/frame_%03d.png` workflow, README.md:43-57, main.rs:17): move the
@@ -327,11 +287,32 @@ typedef struct RtGroupInfo {
   uint32_t tile_rows;  /* scanlines per interleaved tile (2) */
   uint32_t pad_rows;   /* rows of one rank's slice of the gather buffer */
   uint32_t emulated;   /* 1: ranks share devices (RT_GPUS_EMULATE=1, tests) */
-  uint32_t reserved;
+  uint32_t transport_fallback; /* 1: RCCL was wanted but could not be used (library, communicators or its self-test gather failed):
+                                * the group runs on peer copies instead; rt_hip_group_fallback_reason() says why */
   int32_t device[RT_GROUP_INFO_MAX_RANKS]; /* device ordinal of rank r; -1 beyond n_ranks */
 } RtGroupInfo;
+/* One rank of a group (rt_hip_group_ranks): where it runs and what its last frame cost — enough for one bench line of an
+ * N-GPU run to explain its own efficiency. */
+typedef struct RtGroupRank {
+  int32_t device;        /* HIP device ordinal */
+  int32_t numa_node;     /* NUMA node of the device's PCI function (sysfs numa_node), -1 unknown */
+  int32_t pinned_cpus;   /* CPUs in the affinity mask the rank's host thread was pinned to (that node's), 0: not pinned */
+  int32_t peer_to_root;  /* hipDeviceCanAccessPeer(this device -> the first rank's device); 1 for rank 0 and shared devices */
+  char pci_bus_id[16];   /* "0000:c1:00.0" */
+  double kernel_ms;      /* the frame collected last: this rank's kernel (HIP events on its stream) */
+  double t_wake_us;      /* the frame submitted last, host clock since its submit was entered: the rank's host thread is running, */
+  double t_enq_us;       /* ... its launch (+ its side of the transfer) is enqueued */
+} RtGroupRank;
+/* Creation never fails because of the TRANSPORT: if RCCL is wanted (the default with one device per rank) but its library
+ * cannot be loaded (RT_RCCL_LIB overrides the path), ncclCommInitAll fails, or the self-test gather run at creation fails,
+ * times out (RT_RCCL_TIMEOUT_MS, default 20 000) or delivers wrong bytes, the communicators are torn down and the group
+ * runs on peer copies (RtGroupInfo.transport = RT_GATHER_PEER, .transport_fallback = 1); a gather that fails to enqueue in a
+ * later frame switches the same way and re-sends that frame's tiles.  Rank threads are pinned to the CPUs of their device's
+ * NUMA node unless RT_GROUP_PIN=0. */
 int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipGroup** out);
 int rt_hip_group_info(const RtHipGroup*, RtGroupInfo* info);
+uint32_t rt_hip_group_ranks(const RtHipGroup*, RtGroupRank* out, uint32_t cap); /* fills min(cap, n_ranks) entries, returns n_ranks */
+const char* rt_hip_group_fallback_reason(const RtHipGroup*);                    /* "" unless RtGroupInfo.transport_fallback */
 /* the same frame, left in HBM: scanline order, RGB8, on the group's first device (rt_hip_group_frame returns the device
  * pointer, valid until the group is destroyed, and that device's ordinal) — no device-to-host copy.  Blocking. */
 int rt_hip_group_render(RtHipGroup*, RtStats* stats);
@@ -341,8 +322,10 @@ const void* rt_hip_group_frame(const RtHipGroup*, int* device_out);
  * and returns; collect blocks until the OLDEST submitted frame is complete and fills its stats.  Two frames may be in flight
  * (a third submit is RT_ERR_INVALID): every buffer exists twice, a rank's tiles travel on a transfer stream of their own,
  * so frame i's gather + copy run while frame i+1 renders and a step costs the slowest rank's kernel.  The camera and
- * options a frame is rendered with are those in force when it is SUBMITTED.  out_rgb8 must stay valid until the frame
- * is collected; rt_hip_group_frame() points at the frame collected last.  rt_hip_group_render / _render_to_host are
+ * options a frame is rendered with are those in force when it is SUBMITTED.  out_rgb8 may be pageable memory: the frame
+ * leaves the device into a pinned staging buffer of the group (so submit never blocks on the copy) and collect moves
+ * it into out_rgb8, which must stay valid until then; a buffer that is itself pinned (hipHostMalloc / hipHostRegister)
+ * is written directly.  rt_hip_group_frame() points at the frame collected last.  rt_hip_group_render / _render_to_host are
  * submit + collect (after collecting whatever was still in flight). */
 int rt_hip_group_submit(RtHipGroup*, uint8_t* out_rgb8);
 int rt_hip_group_collect(RtHipGroup*, RtStats* stats);

@@ -1,7 +1,7 @@
 """ctypes mirror of include/rt_abi.h (plain C ABI; no torch types cross this boundary)."""
 import ctypes as C
 
-RT_ABI_VERSION = 4
+RT_ABI_VERSION = 5
 RT_MAX_LIGHT_NEST = 8
 RT_OK, RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP = 0, -1, -2, -3
 RT_ERR_IO, RT_ERR_PARSE, RT_ERR_TEXTURE, RT_ERR_PNG, RT_ERR_UNSUPPORTED = -4, -5, -6, -7, -8
@@ -53,8 +53,13 @@ RT_GATHER_NONE, RT_GATHER_RCCL, RT_GATHER_PEER = range(3)
 
 class RtGroupInfo(C.Structure):
     _fields_ = [("n_ranks", C.c_uint32), ("n_devices", C.c_uint32), ("transport", C.c_uint32), ("rccl_comms", C.c_uint32),
-                ("tile_rows", C.c_uint32), ("pad_rows", C.c_uint32), ("emulated", C.c_uint32), ("reserved", C.c_uint32),
+                ("tile_rows", C.c_uint32), ("pad_rows", C.c_uint32), ("emulated", C.c_uint32), ("transport_fallback", C.c_uint32),
                 ("device", C.c_int32 * RT_GROUP_INFO_MAX_RANKS)]
+
+
+class RtGroupRank(C.Structure):
+    _fields_ = [("device", C.c_int32), ("numa_node", C.c_int32), ("pinned_cpus", C.c_int32), ("peer_to_root", C.c_int32),
+                ("pci_bus_id", C.c_char * 16), ("kernel_ms", C.c_double), ("t_wake_us", C.c_double), ("t_enq_us", C.c_double)]
 
 
 def tiles_local_rows(height, tiles):

@@ -36,11 +36,24 @@ def build_host(force=False):
 
 
 def build_hip(force=False):
+    """librt_hip.so = the product (include/rt_abi.h, nothing else exported); librt_hip_probe.so = the same sources with
+    -DRT_TEST_PROBES: + the device probes and debug calls of include/rt_abi_test.h, for tests/ and tools/diag.py only"""
     out = os.path.join(HERE, "librt_hip.so")
+    probe = os.path.join(HERE, "librt_hip_probe.so")
     src = _srcs("csrc/hip/rt_hip_api.hip")
-    deps = _srcs(*HIP_DEPS) + [os.path.join(ROOT, "include/rt_abi.h")]
+    deps = _srcs(*HIP_DEPS) + [os.path.join(ROOT, "include/rt_abi.h"), os.path.join(ROOT, "include/rt_abi_test.h")]
+    jobs = []
     if force or _newer(out, deps):
-        _run(["hipcc", *HIPFLAGS, "-shared", *src, "-o", out])
+        jobs.append(["hipcc", *HIPFLAGS, "-shared", *src, "-o", out])
+    if force or _newer(probe, deps):
+        jobs.append(["hipcc", *HIPFLAGS, "-DRT_TEST_PROBES", "-shared", *src, "-o", probe])
+    procs = []
+    for cmd in jobs:   # (side by side: each is ~20 s of one core)
+        print("+", " ".join(cmd), file=sys.stderr, flush=True)
+        procs.append((cmd, subprocess.Popen(cmd, cwd=HERE)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     return out
 
 

@@ -63,7 +63,9 @@ static_assert(sizeof(SphereMat) == 80, "SphereMat is 80 B");
 // row * width + col < 2^49 — a column beyond 2^32 - 1 may be clamped there (the index is out of range either way) and
 // v_mad_u64_u32 forms the index exactly.  Anything else keeps the u64 arithmetic on the RGB8 bytes.
 RT_HD bool texels_fast(uint64_t tex_w, uint64_t tex_h, double h_offset, uint64_t nbytes, uint64_t texels_before) {
-  return tex_w <= (1ull << 24) && tex_h <= (1ull << 24) && h_offset >= -1024.0 && h_offset <= 1024.0 && nbytes >= 3 &&
+  // (height and width at least 1: with height 0 the reference's (height - 1) wraps to 2^64 - 1 and its row * width is taken
+  //  mod 2^64 — such records keep the general u64 path that mirrors materials.rs word for word)
+  return tex_w >= 1 && tex_h >= 1 && tex_w <= (1ull << 24) && tex_h <= (1ull << 24) && h_offset >= -1024.0 && h_offset <= 1024.0 && nbytes >= 3 &&
          texels_before + nbytes / 3 < (1ull << 31);
 }
 // f32 cull record for TWO spheres (SoA so one packed f32 instruction handles both):
@@ -1338,15 +1340,19 @@ RT_HD bool lane_light_begin(const DevScene& sc, LaneT& L, bool light_ray) {
     uint32_t base_slot = 0xFFFFFFFFu;
     if constexpr (LaneT::kSimple) {
       if (!light_ray && (L.in_light >> 16) == 0u) {
-        base_slot = light_pool_take(LIGHT_BASE_BITMAP_LDS_OFF, sc.light_base_slots, seed);
-        if (base_slot == 0xFFFFFFFFu) return false;
+        // (a base per lane fits — small scenes, the reference's test_scene: the lane's own, no bitmap; wave-uniform test)
+        if (sc.light_base_slots == (uint32_t)RT_BLOCK) base_slot = threadIdx.x;
+        else {
+          base_slot = light_pool_take(LIGHT_BASE_BITMAP_LDS_OFF, sc.light_base_slots, seed);
+          if (base_slot == 0xFFFFFFFFu) return false;
+        }
       }
     }
     const uint32_t slot = (!light_ray || sc.light_nest_pool != 0u) ? light_pool_take(LIGHT_POOL_LDS_OFF, sc.light_pool_slots, seed) : 0xFFFFFFFFu;
     const uint32_t nw = light_frames_lds_off(sc.light_base_slots) + __umul24(slot, (uint32_t)sizeof(LightParked));
     if (!light_ray) {
       if (slot == 0xFFFFFFFFu) {
-        if (base_slot != 0xFFFFFFFFu) light_pool_give(LIGHT_BASE_BITMAP_LDS_OFF, base_slot);
+        if (base_slot != 0xFFFFFFFFu && sc.light_base_slots != (uint32_t)RT_BLOCK) light_pool_give(LIGHT_BASE_BITMAP_LDS_OFF, base_slot);
         return false;
       }
       if (base_slot != 0xFFFFFFFFu) L.in_light |= (base_slot + 1u) << 16;
@@ -1378,36 +1384,66 @@ RT_HD bool lane_light_begin(const DevScene& sc, LaneT& L, bool light_ray) {
     return true;
   }
 }
-// ... and when the sample ends: its base record goes back (device form; after the last read of it)
+// ... and when the sample has ended: its base record goes back (device form; after lane_finish_sample, the last read of it).
+// Called by the KERNEL at the two places a sample can end in an iteration (a ray left the scene; lane_shade returned
+// LANE_FINISHED) rather than from each of lane_finish_sample's five call sites: a wave pays for every inlined copy.
 template <class LaneT>
 RT_HD void lane_base_release(const DevScene& sc, LaneT& L) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (LaneT::kPooled && LaneT::kSimple) {
     const uint32_t held = L.in_light >> 16;  // index + 1
     if (held != 0u) {
-      light_pool_give(LIGHT_BASE_BITMAP_LDS_OFF, held - 1u);
+      if (sc.light_base_slots != (uint32_t)RT_BLOCK) light_pool_give(LIGHT_BASE_BITMAP_LDS_OFF, held - 1u);
       L.in_light &= 0xFFFFu;
     }
   }
 #endif
   (void)sc; (void)L;
 }
+// the six floats of a base as one 16-byte and one 8-byte LDS access (records are 32-byte aligned) instead of six dwords
+struct Base6 { float p[3], h[3]; };
+template <class LaneT>
+RT_HD Base6 lane_base_load(LaneT& L) {
+  Base6 r;
+  const float* b = lane_base(L);
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (LaneT::kPooled) {
+    const float4 lo = *reinterpret_cast<const float4*>(b);
+    const float2 hi = *reinterpret_cast<const float2*>(b + 4);
+    r.p[0] = lo.x; r.p[1] = lo.y; r.p[2] = lo.z; r.h[0] = lo.w; r.h[1] = hi.x; r.h[2] = hi.y;
+    return r;
+  }
+#endif
+  r.p[0] = b[0]; r.p[1] = b[1]; r.p[2] = b[2]; r.h[0] = b[3]; r.h[1] = b[4]; r.h[2] = b[5];
+  return r;
+}
+template <class LaneT>
+RT_HD void lane_base_store(LaneT& L, const Base6& v) {
+  float* b = lane_base(L);
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (LaneT::kPooled) {
+    *reinterpret_cast<float4*>(b) = make_float4(v.p[0], v.p[1], v.p[2], v.h[0]);
+    *reinterpret_cast<float2*>(b + 4) = make_float2(v.h[1], v.h[2]);
+    return;
+  }
+#endif
+  b[0] = v.p[0]; b[1] = v.p[1]; b[2] = v.p[2]; b[3] = v.h[0]; b[4] = v.h[1]; b[5] = v.h[2];
+}
 template <class LaneT>
 RT_HD void lane_compose(LaneT& L, const float light[3], const float att[3], bool has_light) {
   if constexpr (LaneT::kLights && LaneT::kSimple) {
     if (has_light) {  // level L.k (0 or 1) contributes `light`: create / update the base
-      float* b = lane_base(L);
-      float p[3], h[3];
-      if (L.in_light & LANE_HAS_BASE) { p[0] = b[0]; p[1] = b[1]; p[2] = b[2]; h[0] = b[3]; h[1] = b[4]; h[2] = b[5]; }
-      else { p[0] = p[1] = p[2] = 0.0f; h[0] = h[1] = h[2] = 3.4028234663852886e38f; }  // (a level 0 without light before this one: its h-term 0 + 1 >= q)
+      Base6 v;
+      if (L.in_light & LANE_HAS_BASE) v = lane_base_load(L);
+      else { v.p[0] = v.p[1] = v.p[2] = 0.0f; v.h[0] = v.h[1] = v.h[2] = 3.4028234663852886e38f; }  // (a level 0 without light before this one: its h-term 0 + 1 >= q)
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const float g1 = p[i] + L.fwd.q[i] * 1.0f;
-        h[i] = g1 < h[i] ? g1 : h[i];
-        p[i] = p[i] + L.fwd.q[i] * light[i];
+        const float g1 = v.p[i] + L.fwd.q[i] * 1.0f;
+        v.h[i] = g1 < v.h[i] ? g1 : v.h[i];
+        v.p[i] = v.p[i] + L.fwd.q[i] * light[i];
         L.fwd.q[i] = L.fwd.q[i] * att[i];
       }
-      b[0] = p[0]; b[1] = p[1]; b[2] = p[2]; b[3] = h[0]; b[4] = h[1]; b[5] = h[2];
+      lane_base_store(L, v);
       L.in_light |= LANE_HAS_BASE;
     } else {
       fwd_compose(L.fwd, light, att);
@@ -1424,15 +1460,14 @@ RT_HD void lane_finish_sample(const DevScene& sc, LaneT& L, Rgb leaf) {
   const float x[3] = {leaf.r, leaf.g, leaf.b};
   if constexpr (LaneT::kLights && LaneT::kSimple) {
     if (L.in_light & LANE_HAS_BASE) {
-      const float* b = lane_base(L);
+      const Base6 v = lane_base_load(L);
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        float y = b[i] + L.fwd.q[i] * x[i];
-        y = y > b[3 + i] ? b[3 + i] : y;
+        float y = v.p[i] + L.fwd.q[i] * x[i];
+        y = y > v.h[i] ? v.h[i] : y;
         L.val[i] = y;
       }
-      lane_base_release(sc, L);
-      return;
+      return;  // (the kernel gives the base record back: lane_base_release)
     }
   }
   (void)sc;

@@ -12,10 +12,10 @@
 #include <vector>
 
 #include "rt_kernel.hip"
-#ifdef RT_WITH_SCAN_KERNEL  // A/B builds only (tools/ab_bench.py): the round-1 cull-scan kernel as "variant" 2
-#include "../../../tools/legacy/rt_kernel_scan.hip"
-#endif
 #include "rt_tables.h"
+#ifdef RT_TEST_PROBES  // librt_hip_probe.so: the device probes and debug calls of include/rt_abi_test.h (test infrastructure)
+#include "../../../include/rt_abi_test.h"
+#endif
 
 namespace {
 
@@ -62,13 +62,7 @@ struct RtHipScene {
   int order_age = 0;        // frames since the order was last invalidated (geometry / camera / option change)
   int tile_affinity = 1;    // "tile_affinity" option: runs of tiles belong to one XCD's queue (framebuffer lines complete in one L2)
   int order_mode = 2;       // "tile_order" option: 0 top row first, 1 bottom row first, 2 deepest tiles of the previous frame first
-                            // (a first frame: seeded, below), 3 the seeded order alone (a one-shot render: nothing measured or sorted for a next frame)
-  int order_seed = 0;       // "order_seed" option (round-4 experiments, both measured SLOWER than no seed and off by default —
-                            // DESIGN.md §4.1): 1 = a frame without a measured order sorts its tiles by what the spheres' projections
-                            // say about path depth (seed_tile_depths); 2 = by a probe launch; 0 = bottom row first
-  struct SeedSphere { double c[3], r; uint32_t kind; };
-  std::vector<SeedSphere> seed_spheres;  // host copy of (centre, radius, material kind): what the seed projects
-  std::vector<uint32_t> seed_depth;      // staging of the seeded depths (kept alive until the copy that reads it has run)
+                            // (a frame without a previous one: bottom row first)
   int force_lit = 0;       // "force_lit" option (diagnostics)
   int light_pool_cap = 0;  // "light_pool" option: cap on the light-frame pool of lit scenes (0 = automatic; tests shrink it to force repeats and overflows)
   int light_base_cap = 0;  // "light_base_pool" option: the same for the pool of colour-map bases
@@ -91,6 +85,7 @@ struct RtHipScene {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_copied = nullptr;
     unsigned long long* h_counters = nullptr;  // pinned, RT_SLOT_COUNTERS words
     uint32_t rows = 0;
+    uint64_t samples = 0;      // rows x width x samples per pixel AS LAUNCHED (an option set between submit and collect must not show)
     uint64_t waves = 0;
     bool launched = false;   // a kernel ran for it (false: an empty shard)
     std::chrono::steady_clock::time_point t_launch;
@@ -116,6 +111,7 @@ extern "C" size_t rt_abi_sizeof(const char* name) {
   if (!std::strcmp(name, "RtRowTiles")) return sizeof(RtRowTiles);
   if (!std::strcmp(name, "RtStats")) return sizeof(RtStats);
   if (!std::strcmp(name, "RtGroupInfo")) return sizeof(RtGroupInfo);
+  if (!std::strcmp(name, "RtGroupRank")) return sizeof(RtGroupRank);
   return 0;
 }
 
@@ -181,11 +177,6 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   s->host.spheres = nullptr; s->host.textures = nullptr; s->host.sky_rgb8 = nullptr;
   s->has_lights = !t.lights.empty();
   s->simple_colour = t.simple_colour;
-  s->seed_spheres.resize(scene->n_spheres);
-  for (uint32_t i = 0; i < scene->n_spheres; ++i) {
-    const RtSphere& sp = scene->spheres[i];
-    s->seed_spheres[i] = RtHipScene::SeedSphere{{sp.center[0], sp.center[1], sp.center[2]}, std::fabs(sp.radius), sp.kind};
-  }
   s->grid = t.grid;
   rtc::fill_dev_scene(*scene, t, s->dev);
   {
@@ -260,17 +251,12 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
 
 extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) {
   if (!s || !key) return fail(RT_ERR_INVALID, "null argument");
-#ifdef RT_WITH_SCAN_KERNEL
-  constexpr int64_t max_variant = 2;
-#else
   constexpr int64_t max_variant = 1;
-#endif
   if (!std::strcmp(key, "variant")) { if (value < 0 || value > max_variant) return fail(RT_ERR_INVALID, "variant must be 0 (grid walk) or 1 (brute force)"); s->variant = (int)value; return RT_OK; }
   if (!std::strcmp(key, "tile_log2")) { if (value < -1 || value > 3) return fail(RT_ERR_INVALID, "tile_log2 must be -1..3"); s->tile_log2 = (int)value; return RT_OK; }
   if (!std::strcmp(key, "tile_shape")) { if (value < 0 || value > 3) return fail(RT_ERR_INVALID, "tile_shape must be 0 (square), 1 (scanline runs), 2 (4:1) or 3 (16:1)"); s->tile_shape = (int)value; return RT_OK; }
   if (!std::strcmp(key, "tile_affinity")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_affinity must be 0 (off), 1 (large frames) or 2 (any frame of 8+ runs: tests)"); s->tile_affinity = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
-  if (!std::strcmp(key, "tile_order")) { if (value < 0 || value > 3) return fail(RT_ERR_INVALID, "tile_order must be 0, 1, 2 or 3"); s->order_mode = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
-  if (!std::strcmp(key, "order_seed")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "order_seed must be 0 (off), 1 (projection) or 2 (probe launch)"); s->order_seed = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
+  if (!std::strcmp(key, "tile_order")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_order must be 0, 1 or 2"); s->order_mode = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
   if (!std::strcmp(key, "light_pool")) { if (value < 0 || value > 1024 || (value != 0 && value < 32)) return fail(RT_ERR_INVALID, "light_pool must be 0 (automatic) or 32..1024"); s->light_pool_cap = (int)value; return RT_OK; }
   if (!std::strcmp(key, "light_base_pool")) { if (value < 0 || value > 1024 || (value != 0 && value < 32)) return fail(RT_ERR_INVALID, "light_base_pool must be 0 (automatic) or 32..1024"); s->light_base_cap = (int)value; return RT_OK; }
   if (!std::strcmp(key, "light_nest_pool")) { if (value < 0 || value > 1) return fail(RT_ERR_INVALID, "light_nest_pool must be 0 or 1"); s->light_nest_pool = (int)value; return RT_OK; }
@@ -288,30 +274,6 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
 }
 
 namespace {
-#ifdef RT_WITH_SCAN_KERNEL
-// legacy arm (variant 2): the round-1 cull-scan kernel, one workgroup per 16x16 tile
-int launch_scan(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb8, void* d_linear, hipStream_t stream, uint32_t local_rows) {
-  rtk_scan::KArgs ka;
-  ka.sc = s->dev;
-  ka.out_rgb8 = (uint8_t*)d_rgb8; ka.out_linear = (float*)d_linear; ka.counters = s->d_counters;
-  ka.local_rows = local_rows;
-  const bool tiled = tiles && tiles->tile_rows && tiles->tile_stride;
-  ka.tile_rows = tiled ? tiles->tile_rows : 0; ka.first_tile = tiled ? tiles->first_tile : 0;
-  ka.tile_stride = tiled ? tiles->tile_stride : 0;
-  const uint32_t tiles_x = (s->host.width + rtk_scan::TILE_W - 1) / rtk_scan::TILE_W;
-  const uint32_t tiles_y = (local_rows + rtk_scan::TILE_H - 1) / rtk_scan::TILE_H;
-  const dim3 grid(tiles_x * tiles_y), block(rtk_scan::BLOCK);
-  const bool geom_lds = s->host.n_spheres <= rtk_scan::LDS_GEOM_MAX_SPHERES;
-  const size_t lds_bytes = rtk_scan::LDS_GEOM_OFF + (geom_lds ? (size_t)s->host.n_spheres * sizeof(rtc::SphereGeom) : 0);
-#define RT_LAUNCH(HL, G, P) hipLaunchKernelGGL((rtk_scan::rt_megakernel<HL, 0, G, P>), grid, block, lds_bytes, stream, ka)
-#define RT_LAUNCH_P(HL, G) RT_LAUNCH(HL, G, true)
-  if (s->has_lights) { if (geom_lds) RT_LAUNCH_P(true, true); else RT_LAUNCH_P(true, false); }
-  else { if (geom_lds) RT_LAUNCH_P(false, true); else RT_LAUNCH_P(false, false); }
-#undef RT_LAUNCH_P
-#undef RT_LAUNCH
-  return RT_OK;
-}
-#endif  // RT_WITH_SCAN_KERNEL
 
 template <bool HL, bool SIMPLE, bool LDS>
 int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka_in, size_t lds_bytes, uint32_t n_items, hipStream_t stream) {
@@ -348,63 +310,6 @@ int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka_in, size_t lds_bytes, uint
 }
 }  // namespace
 
-namespace {
-// A depth guess per pixel tile without tracing anything: where the spheres project.  The frame ends on its deepest paths
-// (DESIGN.md §4.1), and those start where a camera ray meets glass (internal reflections), metal, or any sphere resting on
-// the ground (bounces between the two) — so a tile under the projected bounding box of a Glass sphere gets depth 40, Metal
-// 20, anything else 10, bare ground and sky 0; rt_order_tiles sorts by it like by a measured depth.  Spheres that cover more
-// than half the frame (the ground) or cross the camera plane say nothing and are skipped.  Fills s->seed_depth[n_tiles].
-void rt_seed_tile_depths(RtHipScene* s, const rtk::KArgs& ka, const RtRowTiles* tiles, uint32_t local_rows) {
-  std::vector<uint32_t>& out = s->seed_depth;
-  out.assign(ka.n_tiles, 0u);
-  const double* O = s->host.cam_origin;
-  double M[3][3], inv[3][3];  // columns: lower_left - origin, horizontal, vertical (camera.rs:79-84: dir = ll + u h + v v - o)
-  for (int i = 0; i < 3; ++i) { M[i][0] = s->host.cam_lower_left[i] - O[i]; M[i][1] = s->host.cam_horizontal[i]; M[i][2] = s->host.cam_vertical[i]; }
-  const double det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
-                     M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
-  if (!(std::fabs(det) > 1e-300) || !std::isfinite(det)) return;  // degenerate camera: no seed (bottom row first within one bucket)
-  inv[0][0] = (M[1][1] * M[2][2] - M[1][2] * M[2][1]) / det; inv[0][1] = (M[0][2] * M[2][1] - M[0][1] * M[2][2]) / det; inv[0][2] = (M[0][1] * M[1][2] - M[0][2] * M[1][1]) / det;
-  inv[1][0] = (M[1][2] * M[2][0] - M[1][0] * M[2][2]) / det; inv[1][1] = (M[0][0] * M[2][2] - M[0][2] * M[2][0]) / det; inv[1][2] = (M[0][2] * M[1][0] - M[0][0] * M[1][2]) / det;
-  inv[2][0] = (M[1][0] * M[2][1] - M[1][1] * M[2][0]) / det; inv[2][1] = (M[0][1] * M[2][0] - M[0][0] * M[2][1]) / det; inv[2][2] = (M[0][0] * M[1][1] - M[0][1] * M[1][0]) / det;
-  const double W = (double)s->host.width, H = (double)s->host.height;
-  const bool tiled = tiles && tiles->tile_rows && tiles->tile_stride;
-  const uint32_t tiles_y = (local_rows + (1u << ka.tile_hl) - 1u) >> ka.tile_hl;
-  for (const RtHipScene::SeedSphere& sp : s->seed_spheres) {
-    if (!(sp.r > 0.0) || !std::isfinite(sp.r) || sp.kind == RT_MAT_LIGHT) continue;
-    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
-    bool behind = false;
-    for (int corner = 0; corner < 8 && !behind; ++corner) {
-      double w[3];
-      for (int i = 0; i < 3; ++i) w[i] = sp.c[i] + (((corner >> i) & 1) ? sp.r : -sp.r) - O[i];
-      const double a = inv[0][0] * w[0] + inv[0][1] * w[1] + inv[0][2] * w[2];
-      const double b = inv[1][0] * w[0] + inv[1][1] * w[1] + inv[1][2] * w[2];
-      const double c = inv[2][0] * w[0] + inv[2][1] * w[1] + inv[2][2] * w[2];
-      if (!(a > 1e-9)) { behind = true; break; }
-      const double px = b / a * (W - 1.0), py = H - c / a * (H - 1.0);  // raytracer.rs:199-200 inverted
-      if (!std::isfinite(px) || !std::isfinite(py)) { behind = true; break; }
-      x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
-    }
-    if (behind || x1 < 0.0 || y1 < 0.0 || x0 > W - 1.0 || y0 > H - 1.0) continue;
-    x0 = std::max(x0, 0.0); y0 = std::max(y0, 0.0); x1 = std::min(x1, W - 1.0); y1 = std::min(y1, H - 1.0);
-    if ((x1 - x0 + 1.0) * (y1 - y0 + 1.0) > 0.5 * W * H) continue;
-    const uint32_t depth = sp.kind == RT_MAT_GLASS ? 40u : (sp.kind == RT_MAT_METAL ? 20u : 10u);
-    const uint32_t bx0 = (uint32_t)x0 >> ka.tile_wl, bx1 = (uint32_t)x1 >> ka.tile_wl;
-    for (uint32_t y = (uint32_t)y0; y <= (uint32_t)y1; ++y) {
-      uint32_t lr = y;  // the packed row of scanline y in this launch, if it renders it (inverse of rt_tiles_global_row)
-      if (tiled) {
-        const uint32_t k = y / tiles->tile_rows;
-        if (k < tiles->first_tile || (k - tiles->first_tile) % tiles->tile_stride != 0u) continue;
-        lr = (k - tiles->first_tile) / tiles->tile_stride * tiles->tile_rows + y % tiles->tile_rows;
-      }
-      const uint32_t by = lr >> ka.tile_hl;
-      if (by >= tiles_y) continue;
-      uint32_t* row = out.data() + (size_t)by * ka.tiles_x;
-      for (uint32_t bx = bx0; bx <= bx1 && bx < ka.tiles_x; ++bx) if (row[bx] < depth) row[bx] = depth;
-    }
-  }
-}
-}  // namespace
-
 extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb8, void* d_linear, void* stream_) {
   if (!s) return fail(RT_ERR_INVALID, "null argument");
   const uint32_t local_rows = rt_tiles_local_rows(s->host.height, tiles);
@@ -428,6 +333,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   RtHipScene::Slot& sl = s->slot[s->n_launches & 1];
   s->n_launches++;
   sl.rows = local_rows; sl.waves = 0; sl.launched = false;
+  sl.samples = (uint64_t)local_rows * s->host.width * s->host.samples_per_pixel;
   s->last_stream = stream;
   sl.t_launch = std::chrono::steady_clock::now();
   RT_HIP_TRY(hipMemsetAsync(s->d_counters, 0, 32 * sizeof(unsigned long long), stream));
@@ -441,16 +347,6 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
     return RT_OK;
   };
   if (local_rows == 0) return finish_launch(false);
-#ifdef RT_WITH_SCAN_KERNEL
-  if (s->variant == 2) {
-    RT_HIP_TRY(hipEventRecord(sl.ev_start, stream));
-    int rc = launch_scan(s, tiles, d_rgb8, d_linear, stream, local_rows);
-    if (rc != RT_OK) return rc;
-    RT_HIP_TRY(hipGetLastError());
-    RT_HIP_TRY(hipEventRecord(sl.ev_stop, stream));
-    return finish_launch(true);
-  }
-#endif
 
   rtk::KArgs ka;
   ka.sc = s->dev;
@@ -476,7 +372,8 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   // (default shape: squares — but the 2x2 tiles of a small frame / a multi-GPU shard as 4x1 strips: 12 contiguous bytes
   //  leave in one packed store instead of two rows of byte stores; same time, WRITE_SIZE 2.71 -> 2.17 MB on an 1/8 shard
   //  of the headline frame, profiles/r03_run10_shape_traffic_sweep.log)
-  auto widen = [&](uint32_t t) { const uint32_t k = s->tile_shape == 0 ? (t == 1u ? 1u : 0u) : (s->tile_shape == 1 ? t : (uint32_t)s->tile_shape - 1u); return k < t ? k : t; };
+  // (shape 2 at t = 1 is the 2x2 square — the A/B arm of the 4x1 default, which no other value selects)
+  auto widen = [&](uint32_t t) { const uint32_t k = s->tile_shape == 0 ? (t == 1u ? 1u : 0u) : (s->tile_shape == 1 ? t : (s->tile_shape == 2 && t == 1u ? 0u : (uint32_t)s->tile_shape - 1u)); return k < t ? k : t; };
   auto tiles_xy = [&](uint32_t t, uint32_t& tx, uint32_t& ty) {
     const uint32_t wl = t + widen(t), hl = t - widen(t);
     tx = (s->host.width + (1u << wl) - 1) >> wl; ty = (local_rows + (1u << hl) - 1) >> hl;
@@ -614,7 +511,6 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
       for (int x = 1; x < 8; ++x) ka.xcd_off[x] = ka.xcd_off[x - 1] + ka.xcd_cnt[x - 1];
     }
   }
-  bool seed_now = false;  // this frame has no measured order: sort its tiles by a seed first
   if (s->order_mode >= 2) {
     RtHipScene::OrderKey key;
     key.n_tiles = ka.n_tiles; key.tile_log2 = tl; key.tile_shape = (uint32_t)s->tile_shape; key.aff_group_log2 = ka.aff_group_log2;
@@ -629,8 +525,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
     }
     if (!(key == s->order_key)) { s->order_key = key; s->order_ready = false; s->order_age = 0; }
     if (s->order_mode == 2 && s->order_age < 2) ka.tile_depth = s->d_tile_depth;  // (measured only while the order is still being built)
-    seed_now = !s->order_ready && s->order_seed != 0;
-    if (s->order_ready || seed_now) ka.tile_order = s->d_tile_order;
+    if (s->order_ready) ka.tile_order = s->d_tile_order;
   }
 
   int rc;
@@ -654,32 +549,12 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
     RT_HIP_TRY(hipGetLastError());
     return RT_OK;
   };
-  RT_HIP_TRY(hipEventRecord(sl.ev_start, stream));  // (a seeded frame's upload / probe and sort are inside its kernel_ms)
+  RT_HIP_TRY(hipEventRecord(sl.ev_start, stream));
   // A frame without a measured order (the first of a scene, a one-shot render) leaves the queue bottom row first and ends on
-  // whatever deep path started last: 13.3 instead of 12.85 ms on the headline frame, 2.09 instead of 1.75 ms on its 1/8 shards.
-  // Two ways to SEED an order were built and measured in round 4 (tools/first_frame.py, profiles/r04_run3_first_frame_orders.log):
-  //   order_seed 1: a depth GUESS per tile from the spheres' projections (seed_tile_depths: a 4-byte-per-tile upload + the sort):
-  //                 13.61 ms — worse than no seed;
-  //   order_seed 2: a PROBE — this kernel at one sample per pixel and 8 segments at most measures the tiles' depths, then
-  //                 the sort: 13.39 ms including itself — no better.
-  // Why neither can work: what the measured order knows is WHICH tiles hold one of the rare 50-segment paths (8.6 % of the
-  // tiles hold at least one among their 2048 samples, spread over the whole ground: tools/depth_map.py) — rare events that a
-  // replay of the same seeds predicts exactly and nothing cheaper predicts at all.  Both stay as options (off by default).
-  if (seed_now) {
-    if (s->order_seed == 2) {
-      rtk::KArgs kp = ka;
-      kp.sc.spp = 1; kp.sc.max_depth = ka.sc.max_depth < 8u ? ka.sc.max_depth : 8u;
-      kp.chunk_spp = 1; kp.n_chunks = 1; kp.out_linear = nullptr;
-      kp.tile_order = nullptr; kp.tile_depth = s->d_tile_depth;
-      if ((rc = launch(kp, ka.n_tiles)) != RT_OK) return rc;
-      RT_HIP_TRY(hipMemsetAsync(s->d_counters, 0, 32 * sizeof(unsigned long long), stream));  // counters and queue cursors of the probe
-    } else {
-      rt_seed_tile_depths(s, ka, tiles, local_rows);
-      RT_HIP_TRY(hipMemcpyAsync(s->d_tile_depth, s->seed_depth.data(), (size_t)ka.n_tiles * 4, hipMemcpyHostToDevice, stream));
-    }
-    if ((rc = sort_tiles()) != RT_OK) return rc;
-    if (s->order_mode == 3) s->order_ready = true;  // (mode 2: this frame's measured depths replace the seed below)
-  }
+  // whatever deep path started last: 13.3 instead of 12.8 ms on the headline frame.  Two ways to SEED an order — a depth guess
+  // from the spheres' projections, a one-sample probe launch — were built and measured in round 4, both slower than no seed
+  // (profiles/r04_run3_first_frame_orders.log; the code: profiles/r05_order_seed_removed.patch): what the measured order
+  // knows is WHICH tiles hold one of the rare 50-segment paths, which a replay of the same seeds predicts and nothing cheaper does.
   if ((rc = launch(ka, n_items)) != RT_OK) return rc;
   RT_HIP_TRY(hipEventRecord(sl.ev_stop, stream));
   // The next frame's order from this frame's depths (stream-ordered: ready before the next launch reads it).  Which tiles
@@ -693,6 +568,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   return finish_launch(true);
 }
 
+#ifdef RT_TEST_PROBES
 // Diagnostics: the per-tile path depths the last measuring frame left behind (tile_order 2, first two frames of a view):
 // out[tile] = deepest camera path seen in the tile, tiles in row-major order of the launch's tile grid (*tiles_x wide).
 // Returns the number of tiles copied (at most cap), or a negative RtStatus.
@@ -715,6 +591,8 @@ extern "C" int rt_hip_debug_timeline(RtHipScene* s, uint64_t* out, uint32_t max_
   return (int)n;
 }
 
+#endif  // RT_TEST_PROBES
+
 namespace {
 // the report of the launch that used `sl` (its counter copy must have completed: the caller synchronised)
 void fill_stats(const RtHipScene* s, const RtHipScene::Slot& sl, RtStats* stats) {
@@ -723,7 +601,7 @@ void fill_stats(const RtHipScene* s, const RtHipScene::Slot& sl, RtStats* stats)
   const unsigned long long* c = sl.h_counters;  // segments, exact tests, tex_oob, grid steps, 4 x wave trip counts, 8 x section cycles, profile clocks
   float ms = 0.f;
   if (sl.launched && hipEventElapsedTime(&ms, sl.ev_start, sl.ev_stop) != hipSuccess) { ms = 0.f; (void)hipGetLastError(); }
-  stats->samples = (uint64_t)sl.rows * s->host.width * s->host.samples_per_pixel;
+  stats->samples = sl.samples;
   stats->segments = c[0];
   stats->sphere_tests = c[0] * (uint64_t)s->host.n_spheres;
   stats->exact_tests = c[1];
@@ -816,6 +694,7 @@ extern "C" int rt_hip_render_to_host(RtHipScene* s, uint8_t* out_rgb8, RtStats* 
 
 #include "rt_hip_group.hip"  // rt_hip_group_* and rt_render_rgb8: the frame over 1..G devices
 
+#ifdef RT_TEST_PROBES
 // math self-test hook (see rtk::rt_math_probe); all pointers are DEVICE pointers
 extern "C" int rt_hip_hit_probe(const double* rays, const double* spheres, double* out_t, uint32_t n, void* stream) {
   hipLaunchKernelGGL(rtk::rt_hit_probe, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rays, spheres, out_t, n);
@@ -855,3 +734,4 @@ extern "C" int rt_hip_quot_probe(const double* d_x, const double* d_y, double* d
   RT_HIP_TRY(hipGetLastError());
   return RT_OK;
 }
+#endif  // RT_TEST_PROBES

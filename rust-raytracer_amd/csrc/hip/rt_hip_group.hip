@@ -16,11 +16,21 @@
 // kernel's event — so frame i's gather, de-interleave and device-to-host copy run while frame i+1 renders, and an
 // animation's step is the slowest rank's kernel, not kernel + gather + copy.
 //
+// The transport can never cost the frame: RCCL is the default with one device per rank, but if its library does not load
+// (RT_RCCL_LIB names another path), ncclCommInitAll fails, or the self-test gather run at creation fails, times out or
+// delivers wrong bytes, the communicators are torn down and the group runs on peer copies — and says so (RtGroupInfo.
+// transport_fallback, rt_hip_group_fallback_reason).  A gather that fails to enqueue in a later frame switches the same way
+// and re-sends that frame's tiles.  Rank threads are pinned to the CPUs of their device's NUMA node (RT_GROUP_PIN=0: not).
+// A frame handed to a pageable host buffer leaves the device into a pinned staging buffer of the group (an asynchronous
+// copy into pageable memory is synchronous in HIP: submit used to block until the frame was done) and collect moves it on.
+//
 // Test hooks: RT_GPUS_EMULATE=1 lets ranks share devices (rank r -> device r mod visible devices; peer
 // transport only), so the whole path — threads, sharding, gather buffer layout, de-interleave — runs on a
 // one-GPU box; RT_GATHER_SELFTEST=1 makes a ONE-rank group go through the gather (RCCL communicator of one
 // rank, in-place ncclGather) and the de-interleave kernel too.
 #include <dlfcn.h>
+#include <pthread.h>
+#include <sched.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library is dlopen'ed below, never linked
 
 #include <atomic>
@@ -40,13 +50,19 @@ struct RcclApi {
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGather) Gather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;  // (optional: only used to abandon communicators whose self-test hangs)
   bool load(std::string& err) {
     if (h) return true;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (h) break;
+    if (const char* forced = std::getenv("RT_RCCL_LIB")) {  // (a site's own build of the library; tests: a path that does not exist)
+      h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+      if (!h) { const char* e = dlerror(); err = std::string("cannot load RCCL (RT_RCCL_LIB=") + forced + "): " + (e ? e : "?"); return false; }
+    } else {
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+      }
+      if (!h) { const char* e = dlerror(); err = std::string("cannot load RCCL: ") + (e ? e : "?"); return false; }
     }
-    if (!h) { err = std::string("cannot load RCCL: ") + dlerror(); return false; }
 #define RT_SYM(field, sym)                                                      \
   field = reinterpret_cast<decltype(field)>(dlsym(h, sym));                     \
   if (!field) { err = std::string("RCCL lacks ") + sym; return false; }
@@ -57,6 +73,7 @@ struct RcclApi {
     RT_SYM(Gather, "ncclGather")
     RT_SYM(GetErrorString, "ncclGetErrorString")
 #undef RT_SYM
+    CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(h, "ncclCommAbort"));
     return true;
   }
 };
@@ -87,6 +104,12 @@ struct RtHipGroup {
   uint32_t G = 1, width = 0, height = 0, pad_rows = 0;
   size_t row_bytes = 0, pad_bytes = 0;
   bool rccl = false;
+  bool wanted_rccl = false;          // the transport asked for (environment / default) was RCCL
+  std::string fallback_reason;       // why it is not the one in use ("" when it is)
+  bool pin_threads = true;           // RT_GROUP_PIN != 0
+  struct RankPlace { int numa_node = -1; int pinned_cpus = 0; int peer_to_root = 1; char pci[16] = {0}; std::vector<int> cpus; };
+  std::vector<RankPlace> place;      // rank r: where its device sits (filled at creation)
+  std::vector<double> kernel_ms_last;  // rank r: its kernel of the frame collected last
   bool shared_device = false;        // RT_GPUS_EMULATE: some ranks share a device
   bool gather = false;               // G > 1 (or the one-rank self-test): gather + de-interleave after the kernels
   std::vector<int> device;
@@ -107,6 +130,8 @@ struct RtHipGroup {
     hipEvent_t ev_final = nullptr;     // ... and in the caller's buffer, if one was given
     bool busy = false;                 // submitted, not collected
     uint8_t* out = nullptr;
+    uint8_t* h_stage = nullptr;        // pinned staging buffer of the frame (height rows), allocated when a pageable `out` is first seen
+    bool staged = false;               // this frame's device-to-host copy went into h_stage: collect moves it into `out`
     std::chrono::steady_clock::time_point t0;
     double us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // RtStats.group_us
   } frame[2];
@@ -148,6 +173,121 @@ inline double us_since(std::chrono::steady_clock::time_point t0) {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// where device `dev` sits: PCI bus id, the NUMA node sysfs reports for it, the CPUs of that node
+void locate_device(int dev, RtHipGroup::RankPlace& p) {
+  char id[32] = {0};
+  if (hipDeviceGetPCIBusId(id, (int)sizeof id, dev) != hipSuccess) { (void)hipGetLastError(); return; }
+  for (char* c = id; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');  // sysfs names are lower case
+  std::snprintf(p.pci, sizeof p.pci, "%s", id);
+  auto slurp = [](const std::string& path, std::string& out) {
+    FILE* f = std::fopen(path.c_str(), "r");
+    if (!f) return false;
+    char buf[4096];
+    const size_t n = std::fread(buf, 1, sizeof buf - 1, f);
+    std::fclose(f);
+    buf[n] = 0; out = buf;
+    return true;
+  };
+  std::string t;
+  if (!slurp(std::string("/sys/bus/pci/devices/") + id + "/numa_node", t)) return;
+  const long node = std::strtol(t.c_str(), nullptr, 10);
+  if (node < 0) return;  // (-1: the platform does not say — VMs, single-socket boxes)
+  p.numa_node = (int)node;
+  if (!slurp("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist", t)) return;
+  for (const char* c = t.c_str(); *c;) {  // "0-31,64-95"
+    char* e = nullptr;
+    const long a = std::strtol(c, &e, 10);
+    if (e == c) break;
+    long b = a;
+    if (*e == '-') { const char* c2 = e + 1; b = std::strtol(c2, &e, 10); if (e == c2) break; }
+    for (long k = a; k <= b && k < CPU_SETSIZE; ++k) p.cpus.push_back((int)k);
+    c = *e == ',' ? e + 1 : e;
+    if (*e != ',' ) break;
+  }
+}
+// the calling thread runs on the CPUs of rank r's device from now on (memory it touches first lands on that node)
+void pin_to_rank(RtHipGroup* g, uint32_t r) {
+  RtHipGroup::RankPlace& p = g->place[r];
+  if (!g->pin_threads || p.cpus.empty()) return;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  for (int c : p.cpus) CPU_SET(c, &set);
+  if (pthread_setaffinity_np(pthread_self(), sizeof set, &set) == 0) p.pinned_cpus = (int)p.cpus.size();
+}
+
+// RCCL as the gather's transport: library, communicators, and ONE gather of known bytes through the frame's own buffers
+// before any frame depends on it (it also takes RCCL's lazy first-collective setup out of the first frame).  Returns ""
+// when the transport is usable; otherwise everything it created is gone again and the text says what failed.
+std::string try_rccl(RtHipGroup* g) {
+  std::string why;
+  if (!g->api.load(why)) return why;
+  const uint32_t G = g->G;
+  g->comm.assign(G, nullptr);
+  ncclResult_t nr = g->api.CommInitAll(g->comm.data(), (int)G, g->device.data());
+  if (nr != ncclSuccess) { g->comm.clear(); return std::string("ncclCommInitAll: ") + g->api.GetErrorString(nr); }
+  auto drop_comms = [&](bool abort) {
+    for (uint32_t r = 0; r < g->comm.size(); ++r)
+      if (g->comm[r]) { (void)hipSetDevice(g->device[r]); if (abort && g->api.CommAbort) (void)g->api.CommAbort(g->comm[r]); else (void)g->api.CommDestroy(g->comm[r]); }
+    g->comm.clear();
+    (void)hipGetLastError();
+  };
+  if (g->pad_bytes == 0) return "";
+  RtHipGroup::Frame& f = g->frame[0];
+  const size_t probe = g->pad_bytes < 4096 ? g->pad_bytes : 4096;  // bytes per rank the self-test sends (the buffers are pad_bytes each)
+  for (uint32_t r = 0; r < G; ++r) {
+    if (hipSetDevice(g->device[r]) != hipSuccess || hipMemsetAsync(f.d_tiles[r], (int)(r + 1u), probe, g->xstream[r]) != hipSuccess) {
+      drop_comms(false);
+      return "self-test: hipMemsetAsync failed";
+    }
+  }
+  nr = g->api.GroupStart();
+  for (uint32_t r = 0; r < G && nr == ncclSuccess; ++r) nr = g->api.Gather(f.d_tiles[r], f.d_stacked, probe, ncclUint8, 0, g->comm[r], g->xstream[r]);
+  const ncclResult_t ne = g->api.GroupEnd();
+  if (nr == ncclSuccess) nr = ne;
+  if (nr != ncclSuccess) { drop_comms(false); return std::string("self-test ncclGather: ") + g->api.GetErrorString(nr); }
+  long timeout_ms = 20000;
+  if (const char* e = std::getenv("RT_RCCL_TIMEOUT_MS")) { const long v = std::strtol(e, nullptr, 10); if (v > 0) timeout_ms = v; }
+  const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+  for (uint32_t r = 0; r < G; ++r) {
+    (void)hipSetDevice(g->device[r]);
+    for (;;) {
+      const hipError_t q = hipStreamQuery(g->xstream[r]);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) { (void)hipGetLastError(); drop_comms(true); return std::string("self-test gather: ") + hipGetErrorString(q); }
+      if (std::chrono::steady_clock::now() > until) {
+        (void)hipGetLastError();
+        drop_comms(true);  // abandon the communicators; the transfer streams may be wedged behind them: fresh ones for the peer copies
+        for (uint32_t q2 = 0; q2 < G; ++q2) {
+          (void)hipSetDevice(g->device[q2]);
+          hipStream_t fresh = nullptr;
+          if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) g->xstream[q2] = fresh;  // (the old stream is leaked on purpose)
+        }
+        return "self-test gather timed out after " + std::to_string(timeout_ms) + " ms";
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+  }
+  (void)hipSetDevice(g->device[0]);
+  std::vector<uint8_t> got(G, 0);
+  for (uint32_t r = 0; r < G; ++r)
+    if (hipMemcpy(&got[r], static_cast<const uint8_t*>(f.d_stacked) + (size_t)r * probe + (probe - 1), 1, hipMemcpyDeviceToHost) != hipSuccess) {
+      (void)hipGetLastError(); drop_comms(false); return "self-test: reading the gathered bytes back failed";
+    }
+  if (const char* inj = std::getenv("RT_RCCL_INJECT")) if (!std::strcmp(inj, "selftest")) got[G - 1] = 0;  // (test hook: the self-test sees wrong bytes)
+  for (uint32_t r = 0; r < G; ++r)
+    if (got[r] != (uint8_t)(r + 1u)) { drop_comms(false); return "self-test gather delivered rank " + std::to_string(r) + "'s bytes as " + std::to_string((int)got[r]); }
+  return "";
+}
+// peer copies instead (and from now on): peer access towards the root where the devices allow it, else the runtime stages
+void use_peer_transport(RtHipGroup* g, const std::string& reason) {
+  g->rccl = false;
+  g->fallback_reason = reason;
+  for (uint32_t r = 1; r < g->G; ++r)
+    if (g->device[r] != g->device[0]) { (void)hipSetDevice(g->device[r]); (void)hipDeviceEnablePeerAccess(g->device[0], 0); }
+  (void)hipGetLastError();  // (already enabled / not supported: the copy is staged instead)
+  (void)hipSetDevice(g->device[0]);
+}
+
 // rank r's part of frame `f`: kernel on its render stream, then — on its transfer stream, behind the kernel's event —
 // its slice of the gather (peer transport; RCCL's gather is enqueued for all ranks together by the submitting thread)
 void enqueue_rank(RtHipGroup* g, RtHipGroup::Frame& f, uint32_t r) {
@@ -171,6 +311,7 @@ void enqueue_rank(RtHipGroup* g, RtHipGroup::Frame& f, uint32_t r) {
 }
 
 void worker_main(RtHipGroup* g, uint32_t r) {
+  pin_to_rank(g, r);
   uint64_t seen = 0;
   for (;;) {
     if (const int spin = g->spin_us.load(std::memory_order_relaxed)) {  // (frames of an animation follow each other closely: poll before sleeping)
@@ -228,6 +369,7 @@ extern "C" void rt_hip_group_destroy(RtHipGroup* g) {
   }
   if (!g->device.empty()) (void)hipSetDevice(g->device[0]);
   for (auto& f : g->frame) {
+    if (f.h_stage) (void)hipHostFree(f.h_stage);
     if (f.d_frame && f.d_frame != f.d_stacked) (void)hipFree(f.d_frame);
     if (f.d_stacked) (void)hipFree(f.d_stacked);
     if (f.ev_assembled) (void)hipEventDestroy(f.ev_assembled);
@@ -253,6 +395,8 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
   g->row_bytes = (size_t)scene->width * 3;
   g->device.resize(G); g->scene.assign(G, nullptr); g->stream.assign(G, nullptr); g->xstream.assign(G, nullptr);
   g->tiles.resize(G); g->rc.assign(G, RT_OK); g->err.resize(G); g->t_wake_us.assign(G, 0.0); g->t_enq_us.assign(G, 0.0);
+  g->place.resize(G); g->kernel_ms_last.assign(G, 0.0);
+  { const char* pin = std::getenv("RT_GROUP_PIN"); g->pin_threads = !(pin && pin[0] == '0'); }
   for (auto& f : g->frame) { f.d_tiles.assign(G, nullptr); f.ev_done.assign(G, nullptr); f.ev_sent.assign(G, nullptr); f.slot.assign(G, 0); }
   bool& shared_device = g->shared_device;
   for (uint32_t r = 0; r < G; ++r) {
@@ -269,12 +413,20 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
   g->gather = G > 1 || (st && st[0] == '1');
   g->rccl = g->gather && (tr ? !std::strcmp(tr, "rccl") : !shared_device);
   if (g->rccl && shared_device) { delete g; return fail(RT_ERR_INVALID, "RT_GATHER=rccl needs one device per rank (RT_GPUS_EMULATE shares devices)"); }
+  g->wanted_rccl = g->rccl;
+  for (uint32_t r = 0; r < G; ++r) {
+    rtg::locate_device(g->device[r], g->place[r]);
+    int can = 1;
+    if (g->device[r] != g->device[0] && hipDeviceCanAccessPeer(&can, g->device[r], g->device[0]) != hipSuccess) { can = 0; (void)hipGetLastError(); }
+    g->place[r].peer_to_root = can;
+  }
   auto bail = [&](int code, const std::string& m) { rt_hip_group_destroy(g); return fail(code, m); };
   // scene replicas: one thread per rank (table upload + texture copy run in parallel)
   {
     std::vector<std::thread> th;
     for (uint32_t r = 0; r < G; ++r)
       th.emplace_back([g, scene, r]() {
+        rtg::pin_to_rank(g, r);  // (the replica's pinned counter words and staging copies are first touched on the device's node)
         g->rc[r] = rt_hip_scene_create(scene, g->device[r], &g->scene[r]);
         if (g->rc[r] != RT_OK) { g->err[r] = rt_hip_last_error(); return; }
         bool ok = hipStreamCreateWithFlags(&g->stream[r], hipStreamNonBlocking) == hipSuccess &&
@@ -301,17 +453,10 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
       return bail(RT_ERR_HIP, "hipEventCreate failed");
   }
   g->last = &g->frame[0];
-  if (g->rccl) {
-    std::string why;
-    if (!g->api.load(why)) return bail(RT_ERR_HIP, why);
-    g->comm.assign(G, nullptr);
-    const ncclResult_t nr = g->api.CommInitAll(g->comm.data(), (int)G, g->device.data());
-    if (nr != ncclSuccess) { g->comm.clear(); return bail(RT_ERR_HIP, std::string("ncclCommInitAll: ") + g->api.GetErrorString(nr)); }
-  } else if (g->gather) {
-    for (uint32_t r = 1; r < G; ++r)
-      if (g->device[r] != g->device[0]) { (void)hipSetDevice(g->device[r]); (void)hipDeviceEnablePeerAccess(g->device[0], 0); }
-    (void)hipGetLastError();  // (already enabled / not supported: the copy is staged instead)
-  }
+  if (g->rccl) {  // never fatal: whatever RCCL cannot do here, peer copies can (the frame is the same bytes either way)
+    const std::string why = rtg::try_rccl(g);
+    if (!why.empty()) rtg::use_peer_transport(g, why);
+  } else if (g->gather) rtg::use_peer_transport(g, "");
   for (uint32_t r = 1; r < G; ++r) g->worker.emplace_back(rtg::worker_main, g, r);
   *out = g;
   return RT_OK;
@@ -349,6 +494,7 @@ extern "C" int rt_hip_group_info(const RtHipGroup* g, RtGroupInfo* info) {
   info->rccl_comms = (uint32_t)g->comm.size();
   info->tile_rows = RT_GROUP_TILE_ROWS; info->pad_rows = g->pad_rows;
   info->emulated = g->shared_device ? 1u : 0u;
+  info->transport_fallback = (g->wanted_rccl && !g->rccl) ? 1u : 0u;
   uint64_t seen[16] = {0};  // device ordinals < 1024
   for (uint32_t r = 0; r < RT_GROUP_INFO_MAX_RANKS; ++r) info->device[r] = -1;
   for (uint32_t r = 0; r < g->G; ++r) {
@@ -358,6 +504,21 @@ extern "C" int rt_hip_group_info(const RtHipGroup* g, RtGroupInfo* info) {
   }
   return RT_OK;
 }
+
+extern "C" uint32_t rt_hip_group_ranks(const RtHipGroup* g, RtGroupRank* out, uint32_t cap) {
+  if (!g) return 0u;
+  for (uint32_t r = 0; out && r < g->G && r < cap; ++r) {
+    RtGroupRank& o = out[r];
+    std::memset(&o, 0, sizeof o);
+    const RtHipGroup::RankPlace& p = g->place[r];
+    o.device = g->device[r]; o.numa_node = p.numa_node; o.pinned_cpus = p.pinned_cpus; o.peer_to_root = p.peer_to_root;
+    std::memcpy(o.pci_bus_id, p.pci, sizeof o.pci_bus_id);
+    o.pci_bus_id[sizeof o.pci_bus_id - 1] = 0;
+    o.kernel_ms = g->kernel_ms_last[r]; o.t_wake_us = g->t_wake_us[r]; o.t_enq_us = g->t_enq_us[r];
+  }
+  return g->G;
+}
+extern "C" const char* rt_hip_group_fallback_reason(const RtHipGroup* g) { return g ? g->fallback_reason.c_str() : ""; }
 
 extern "C" const void* rt_hip_group_frame(const RtHipGroup* g, int* device_out) {
   if (!g) return nullptr;
@@ -379,6 +540,21 @@ void drain(RtHipGroup* g) {
   for (auto& f : g->frame) f.busy = false;
   g->n_collected = g->n_submitted;
   g_err = keep;
+}
+
+// is `p` pinned host memory (hipHostMalloc / hipHostRegister)?  Pageable memory is unknown to the runtime: an error, cleared.
+bool out_is_pinned(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+// the staging buffers of both frames in flight, ahead of time (rt_render_rgb8: outside its frame_ms window)
+void prepare_staging(RtHipGroup* g) {
+  const size_t bytes = (size_t)g->height * g->row_bytes;
+  if (!bytes) return;
+  (void)hipSetDevice(g->device[0]);
+  for (auto& f : g->frame)
+    if (!f.h_stage && hipHostMalloc((void**)&f.h_stage, bytes, hipHostMallocDefault) != hipSuccess) { f.h_stage = nullptr; (void)hipGetLastError(); }
 }
 
 // Enqueue one frame: G parallel launches, ONE gather, de-interleave, (optionally) ONE device-to-host copy.  Returns as
@@ -424,14 +600,31 @@ int group_submit(RtHipGroup* g, uint8_t* out_rgb8) {
     hipStream_t x0 = g->xstream[0];
     if (g->gather) {
       if (g->rccl) {  // ONE gather over xGMI: every rank's packed tiles -> rank 0's `stacked`, each rank's side behind its kernel's event
-        ncclResult_t nr = g->api.GroupStart();
-        for (uint32_t r = 0; r < G && nr == ncclSuccess; ++r)
-          nr = g->api.Gather(f.d_tiles[r], f.d_stacked, g->pad_bytes, ncclUint8, 0, g->comm[r], g->xstream[r]);
-        const ncclResult_t ne = g->api.GroupEnd();
-        if (nr == ncclSuccess) nr = ne;
-        if (nr != ncclSuccess) return fail(RT_ERR_HIP, std::string("ncclGather: ") + g->api.GetErrorString(nr));
+        ncclResult_t nr = ncclSuccess;
+        const char* inj = std::getenv("RT_RCCL_INJECT");
+        if (inj && !std::strcmp(inj, "gather") && g->n_submitted == 1) nr = ncclInternalError;  // (test hook: the SECOND frame's gather fails to enqueue)
+        else {
+          nr = g->api.GroupStart();
+          for (uint32_t r = 0; r < G && nr == ncclSuccess; ++r)
+            nr = g->api.Gather(f.d_tiles[r], f.d_stacked, g->pad_bytes, ncclUint8, 0, g->comm[r], g->xstream[r]);
+          const ncclResult_t ne = g->api.GroupEnd();
+          if (nr == ncclSuccess) nr = ne;
+        }
+        if (nr != ncclSuccess) {
+          // the gather did not go out: the frame's kernels are enqueued and their events recorded — send the tiles by peer
+          // copies instead (this frame and every later one), each behind its kernel's event like the worker would have
+          for (uint32_t r = 0; r < g->comm.size(); ++r) if (g->comm[r]) { (void)hipSetDevice(g->device[r]); if (g->api.CommAbort) (void)g->api.CommAbort(g->comm[r]); }
+          g->comm.clear();
+          use_peer_transport(g, std::string("ncclGather: ") + g->api.GetErrorString(nr));
+          for (uint32_t r = 1; r < G; ++r) {
+            RT_HIP_TRY(hipSetDevice(g->device[r]));
+            RT_HIP_TRY(hipMemcpyPeerAsync(static_cast<uint8_t*>(f.d_stacked) + (size_t)r * g->pad_bytes, g->device[0], f.d_tiles[r], g->device[r], g->pad_bytes, g->xstream[r]));
+            RT_HIP_TRY(hipEventRecord(f.ev_sent[r], g->xstream[r]));
+          }
+        }
         RT_HIP_TRY(hipSetDevice(g->device[0]));
-      } else {
+      }
+      if (!g->rccl) {
         for (uint32_t r = 1; r < G; ++r) RT_HIP_TRY(hipStreamWaitEvent(x0, f.ev_sent[r], 0));
       }
       f.us[3] = us_since(f.t0);
@@ -443,7 +636,19 @@ int group_submit(RtHipGroup* g, uint8_t* out_rgb8) {
       f.us[3] = us_since(f.t0);
     }
     RT_HIP_TRY(hipEventRecord(f.ev_assembled, x0));
-    if (f.out) RT_HIP_TRY(hipMemcpyAsync(f.out, f.d_frame, (size_t)g->height * g->row_bytes, hipMemcpyDeviceToHost, x0));
+    f.staged = false;
+    if (f.out) {
+      // An asynchronous copy into PAGEABLE memory is synchronous in HIP (submit blocked until the frame was rendered: 1.8 ms,
+      // profiles/r04_run1_group_overhead.json — the two-deep pipeline gone for exactly the call a drop-in host makes): the frame
+      // goes into a pinned staging buffer of the group and collect moves it on.  A destination that is pinned itself is written directly.
+      const size_t bytes = (size_t)g->height * g->row_bytes;
+      uint8_t* dst = f.out;
+      if (bytes != 0 && !out_is_pinned(f.out)) {
+        if (!f.h_stage && hipHostMalloc((void**)&f.h_stage, bytes, hipHostMallocDefault) != hipSuccess) { f.h_stage = nullptr; (void)hipGetLastError(); }
+        if (f.h_stage) { dst = f.h_stage; f.staged = true; }  // (no pinned memory to be had: the old, blocking copy)
+      }
+      if (bytes != 0) RT_HIP_TRY(hipMemcpyAsync(dst, f.d_frame, bytes, hipMemcpyDeviceToHost, x0));
+    }
     RT_HIP_TRY(hipEventRecord(f.ev_final, x0));
     return RT_OK;
   };
@@ -465,6 +670,7 @@ int group_collect(RtHipGroup* g, RtStats* stats) {
     RT_HIP_TRY(hipEventSynchronize(f.ev_assembled));
     f.us[5] = us_since(f.t0);
     RT_HIP_TRY(hipEventSynchronize(f.ev_final));
+    if (f.staged && f.out) std::memcpy(f.out, f.h_stage, (size_t)g->height * g->row_bytes);
     f.us[6] = us_since(f.t0);
     const double frame_ms = f.us[6] * 1e-3;
     RtStats total;
@@ -478,6 +684,7 @@ int group_collect(RtHipGroup* g, RtStats* stats) {
       total.segments_repeated = (uint32_t)std::min<uint64_t>((uint64_t)total.segments_repeated + st.segments_repeated, 0xFFFFFFFFull);
       for (int k = 0; k < 4; ++k) total.wave_iters[k] += st.wave_iters[k];
       for (int k = 0; k < 12; ++k) total.prof_cycles[k] += st.prof_cycles[k];
+      g->kernel_ms_last[r] = st.kernel_ms;
       if (st.kernel_ms > total.kernel_ms) total.kernel_ms = st.kernel_ms;  // the slowest rank
     }
     f.us[7] = us_since(f.t0);
@@ -537,6 +744,7 @@ extern "C" int rt_render_rgb8(const RtScene* scene, uint8_t* out_rgb8, RtStats* 
   // one frame per scene: no later frame could use a queue order learned from this one (tile_order 2 would measure
   // the tile depths and run rt_order_tiles inside frame_ms for nothing) — bottom row first
   (void)rt_hip_group_set_option(g, "tile_order", 1);
+  rtg::prepare_staging(g);  // (the caller's buffer is pageable as a rule: its pinned staging buffer is made before the window opens)
   const double setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   RtStats st;
   rc = rt_hip_group_render_to_host(g, out_rgb8, &st);

@@ -835,7 +835,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     const uint32_t k_miss = my_k;
     if (wave_any(miss)) {
       if (miss) {
-        { const DevScene& scf = fresh_args().sc; lane_finish_sample(scf, L, sky_color(scf, L.d, L.n_tex_oob)); }
+        { const DevScene& scf = fresh_args().sc; lane_finish_sample(scf, L, sky_color(scf, L.d, L.n_tex_oob)); lane_base_release(scf, L); }
         flush_oob();
         has_ray = false;
       }
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     }
     RT_PROF(2);
     if (wave_any(finished)) {
-      if (finished) has_ray = false;
+      if (finished) { has_ray = false; lane_base_release(fresh_args().sc, L); }
       add_sample(finished);
     }
     count_tiles(miss || finished, miss ? k_miss : my_k);
@@ -992,6 +992,7 @@ __global__ __launch_bounds__(1024) void rt_order_tiles(const uint32_t* __restric
   }
 }
 
+#ifdef RT_TEST_PROBES
 // --------------------------------------------------------------------------- device self-test
 // f64 sqrt / divide / f32 sqrt must be correctly rounded on the GPU for bit-parity with the CPU
 // oracle; tests/test_gpu_parity.py checks these against numpy.
@@ -1056,5 +1057,6 @@ __global__ void rt_quot_probe(const double* x, const double* y, double* out_quot
   out_rsqrt[i] = rt_fast_rsqrt(x[i]);
   if (out_div) out_div[i] = rt_div_inrange(x[i], y[i]);
 }
+#endif  // RT_TEST_PROBES
 
 }  // namespace rtk

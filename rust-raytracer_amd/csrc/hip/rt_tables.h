@@ -324,7 +324,9 @@ inline void build_texels(const RtScene& sc, HostTables& t) {
     expand(sc.textures[k].rgb8, n_px, t.tex4);
     before += n_px;
   }
-  t.sky_fast = sc.sky_mode == RT_SKY_TEXTURE && sc.sky_w <= (1ull << 24) && sc.sky_h <= (1ull << 24) && sc.sky_w * sc.sky_h < (1ull << 31);
+  // (sky_w strictly below 2^24: sky_color() forms y * sky_w with a 24-bit multiply, which keeps only the low 24 bits of each
+  //  operand — at sky_w == 2^24 the device product would be 0; y <= sky_h - 1 < 2^24 either way)
+  t.sky_fast = sc.sky_mode == RT_SKY_TEXTURE && sc.sky_w < (1ull << 24) && sc.sky_h <= (1ull << 24) && sc.sky_w * sc.sky_h < (1ull << 31);
   if (t.sky_fast) expand(sc.sky_rgb8, sc.sky_w * sc.sky_h, t.sky4);
 }
 

@@ -45,7 +45,7 @@ def _assembly_perm(height, world, tile_rows, pad_rows, device):
     return perm
 
 
-def gather_frame(local_rgb8, height, width, rank, world, tile_rows=TILE_ROWS, dst=0):
+def gather_frame(local_rgb8, height, width, rank, world, tile_rows=TILE_ROWS, dst=0, group=None):
     """local_rgb8: uint8 tensor [max_local_rows, width, 3] on this rank's device (rows beyond
     this rank's share are padding).  Returns the assembled [height, width, 3] frame on `dst`,
     None elsewhere.  ONE collective (gather of the packed tiles) + one row permutation on dst."""
@@ -55,10 +55,10 @@ def gather_frame(local_rgb8, height, width, rank, world, tile_rows=TILE_ROWS, ds
     assert local_rgb8.shape[0] == pad_rows, (local_rgb8.shape, pad_rows)
     if rank == dst:
         stacked = torch.empty((world, pad_rows, width, 3), dtype=torch.uint8, device=local_rgb8.device)
-        dist.gather(local_rgb8, [stacked[r] for r in range(world)], dst=dst)
+        dist.gather(local_rgb8, [stacked[r] for r in range(world)], dst=dst, group=group)
         perm = _assembly_perm(height, world, tile_rows, pad_rows, local_rgb8.device)
         return stacked.view(world * pad_rows, width, 3).index_select(0, perm)  # de-interleave: packed rows -> scanlines
-    dist.gather(local_rgb8, None, dst=dst)
+    dist.gather(local_rgb8, None, dst=dst, group=group)
     return None
 
 
@@ -71,14 +71,22 @@ class FramePipeline:
         ... render into buf on the current stream ...
         pipe.submit(i)                # gather of frame i starts once the render has finished
         frames = pipe.drain()         # after the last frame: the frames still in flight, in order
+
+    `group`: the process group the gather runs on (None = the default one).  `host_staged`: the fall-back for a node whose
+    RCCL does not come up (bench.py decides, all ranks together): the tiles leave each GPU into pinned host memory, the
+    gather runs over a CPU group (gloo) and the frame is assembled in host memory of `dst` — same bytes, no xGMI.
     """
 
-    def __init__(self, height, width, rank, world, device, tile_rows=TILE_ROWS, dst=0, depth=2, force_collective=False):
+    def __init__(self, height, width, rank, world, device, tile_rows=TILE_ROWS, dst=0, depth=2, force_collective=False, group=None, host_staged=False):
         self.h, self.w, self.rank, self.world, self.dst, self.depth, self.tile_rows = height, width, rank, world, dst, depth, tile_rows
         self.collective = world > 1 or force_collective   # (force_collective: a 1-rank group still goes through the gather; tests)
+        self.group, self.host_staged = group, bool(host_staged and self.collective)
         self.pad_rows = max_local_rows(height, world, tile_rows) if world > 1 else height
         self.local = [torch.zeros((self.pad_rows, width, 3), dtype=torch.uint8, device=device) for _ in range(depth)]
-        self.stacked = [torch.empty((world, self.pad_rows, width, 3), dtype=torch.uint8, device=device)
+        gdev = "cpu" if self.host_staged else device
+        self.host_local = [torch.zeros((self.pad_rows, width, 3), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+                           for _ in range(depth)] if self.host_staged else None
+        self.stacked = [torch.empty((world, self.pad_rows, width, 3), dtype=torch.uint8, device=gdev)
                         if (self.collective and rank == dst) else None for _ in range(depth)]
         self.work = [None] * depth
         self.order = []  # buffer slots with a gather in flight, oldest first
@@ -91,7 +99,7 @@ class FramePipeline:
             work.wait()  # the current stream (or the host, with gloo) waits for the collective
         if self.rank != self.dst:
             return None
-        perm = _assembly_perm(self.h, self.world, self.tile_rows, self.pad_rows, self.local[slot].device)
+        perm = _assembly_perm(self.h, self.world, self.tile_rows, self.pad_rows, self.stacked[slot].device)
         return self.stacked[slot].view(self.world * self.pad_rows, self.w, 3).index_select(0, perm)
 
     def begin(self, i):
@@ -106,7 +114,15 @@ class FramePipeline:
         slot = i % self.depth
         if self.collective:
             outs = [self.stacked[slot][r] for r in range(self.world)] if self.rank == self.dst else None
-            self.work[slot] = dist.gather(self.local[slot], outs, dst=self.dst, async_op=True)
+            src = self.local[slot]
+            if self.host_staged:   # device -> pinned host, then the CPU gather (it runs on gloo's own thread, under the next frame's render)
+                src = self.host_local[slot]
+                if self.local[slot].is_cuda:
+                    src.copy_(self.local[slot], non_blocking=True)
+                    torch.cuda.current_stream().synchronize()
+                else:
+                    src.copy_(self.local[slot])
+            self.work[slot] = dist.gather(src, outs, dst=self.dst, async_op=True, group=self.group)
         self.order.append(slot)
 
     def drain(self):

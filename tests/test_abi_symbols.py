@@ -13,21 +13,37 @@ HOST_SYMS = {"rt_scene_camera", "rt_scene_load_file", "rt_scene_load_string", "r
              "rt_png_write_rgb8", "rt_free"}
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "rt_abi.h")).read()
+def declared_functions(header="rt_abi.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text))
     return names - {"rt_tiles_local_rows", "rt_tiles_global_row", "rt_tiles_stacked_row"}  # static inline helpers
 
 
 def test_every_declared_symbol_is_exported(pkg):
+    """include/rt_abi.h = the seam: every function it declares is exported by the two PRODUCT libraries; include/rt_abi_test.h =
+    the lab (device probes, debug calls): exported by librt_hip_probe.so — which carries the whole product API too, a scene the
+    debug calls look into is created through it — and by nothing a drop-in host links."""
     host = C.CDLL(os.path.join(ROOT, "rust-raytracer_amd", "librt_host.so"))
     hip = C.CDLL(pkg.hip.LIB_PATH)
+    probe = C.CDLL(pkg.hip.PROBE_LIB_PATH)
     names = declared_functions()
     assert len(names) >= 20
     for n in sorted(names):
         lib = host if n in HOST_SYMS else hip
         assert hasattr(lib, n), f"{n} not exported"
+        if n not in HOST_SYMS:
+            assert hasattr(probe, n), f"{n} not exported by the probe library"
+    lab = declared_functions("rt_abi_test.h")
+    assert len(lab) == 7 and not (lab & names), sorted(lab)
+    for n in sorted(lab):
+        assert hasattr(probe, n), f"{n} not exported by librt_hip_probe.so"
+        assert not hasattr(hip, n) and not hasattr(host, n), f"{n} is exported by a product library"
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "_probe" not in out and "rt_hip_debug" not in out, [l for l in out.splitlines() if "_probe" in l or "debug" in l]
+    # and nothing the product exports is undeclared: every defined rt_* symbol of librt_hip.so is in the header
+    exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("rt_")}
+    assert exported <= names, sorted(exported - names)
 
 
 def _rust_structs(text):
@@ -75,7 +91,7 @@ def test_rust_shim_in_integration_md_matches_the_header(abi):
 def test_abi_sizeof_export(pkg, abi):
     """rt_abi_sizeof / rt_abi_version: what a foreign binding compares its own struct sizes with"""
     L = pkg.hip.lib()
-    for name in ("RtSphere", "RtTexture", "RtScene", "RtRowTiles", "RtStats"):
+    for name in ("RtSphere", "RtTexture", "RtScene", "RtRowTiles", "RtStats", "RtGroupInfo", "RtGroupRank"):
         assert L.rt_abi_sizeof(name.encode()) == C.sizeof(getattr(abi, name))
     assert L.rt_abi_sizeof(b"NoSuchStruct") == 0 and L.rt_abi_version() == abi.RT_ABI_VERSION
 
@@ -83,14 +99,16 @@ def test_abi_sizeof_export(pkg, abi):
 def test_struct_layout_matches_header(abi, tmp_path):
     """ctypes mirrors == C sizeof/offsetof (compiled from the header with gcc)."""
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "rt_abi.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(RtSphere), sizeof(RtTexture),'
+    src.write_text('#include <stdio.h>\n#include "rt_abi_test.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(RtSphere), sizeof(RtTexture),'
                    ' sizeof(RtScene), sizeof(RtRowTiles), sizeof(RtStats), offsetof(RtScene, spheres), offsetof(RtScene, seed), offsetof(RtSphere, albedo));'
+                   'printf("%zu %zu %zu %zu %zu\\n", sizeof(RtGroupInfo), sizeof(RtGroupRank), offsetof(RtGroupInfo, device), offsetof(RtGroupRank, pci_bus_id), offsetof(RtGroupRank, kernel_ms));'
                    'printf("%zu %zu %zu %zu\\n", offsetof(RtScene, n_gpus), offsetof(RtStats, segments_discarded), offsetof(RtStats, gather_ms), offsetof(RtStats, prof_cycles));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     want = [C.sizeof(abi.RtSphere), C.sizeof(abi.RtTexture), C.sizeof(abi.RtScene), C.sizeof(abi.RtRowTiles), C.sizeof(abi.RtStats),
             abi.RtScene.spheres.offset, abi.RtScene.seed.offset, abi.RtSphere.albedo.offset,
+            C.sizeof(abi.RtGroupInfo), C.sizeof(abi.RtGroupRank), abi.RtGroupInfo.device.offset, abi.RtGroupRank.pci_bus_id.offset, abi.RtGroupRank.kernel_ms.offset,
             abi.RtScene.n_gpus.offset, abi.RtStats.segments_discarded.offset, abi.RtStats.gather_ms.offset, abi.RtStats.prof_cycles.offset]
     assert got == want
 
@@ -128,7 +146,7 @@ def test_product_does_not_reference_oracle():
                         assert libs and all("rccl" in x for x in libs), libs
     assert bad == [], bad
     # and the built product libraries carry no dependency on / symbol of the oracle
-    for so in ("librt_hip.so", "librt_host.so"):
+    for so in ("librt_hip.so", "librt_hip_probe.so", "librt_host.so"):
         out = subprocess.run(["nm", "-D", os.path.join(ROOT, "rust-raytracer_amd", so)], capture_output=True, text=True).stdout
         assert "rt_oracle" not in out and "hostsim" not in out
 

@@ -56,7 +56,7 @@ def test_two_rank_gather_matches_single(tmp_path, oracle, abi, load_scene, w, h)
     assert np.array_equal(np.load(out), full)
 
 
-def _pipeline_worker(rank, world, port, w, h, n_frames, out_path):
+def _pipeline_worker(rank, world, port, w, h, n_frames, out_path, host_staged=False):
     sys.path.insert(0, ROOT)
     import __graft_entry__ as graft
     os.chdir(ROOT)
@@ -69,7 +69,10 @@ def _pipeline_worker(rank, world, port, w, h, n_frames, out_path):
         sc = pkg.host.Scene.load("scenes/cfg2_cover_1200x800_spp128.json")
         sc.c.width, sc.c.height, sc.c.samples_per_pixel = w, h, 1
         tiles = rdist.shard(rank, world)
-        pipe = rdist.FramePipeline(h, w, rank, world, torch.device("cpu"))
+        # host_staged: bench.py's fall-back when RCCL does not come up — a data group of its own (here gloo again), the
+        # tiles staged through a host buffer, the frame assembled in host memory
+        grp = dist.new_group(backend="gloo") if host_staged else None
+        pipe = rdist.FramePipeline(h, w, rank, world, torch.device("cpu"), group=grp, host_staged=host_staged)
         frames = []
         for i in range(n_frames):  # frame i = seed i: every frame differs, so a mixed-up buffer shows
             buf, done = pipe.begin(i)
@@ -92,11 +95,13 @@ def _pipeline_worker(rank, world, port, w, h, n_frames, out_path):
         dist.destroy_process_group()
 
 
-def test_two_rank_frame_pipeline_keeps_frames_apart(tmp_path, oracle, abi, load_scene):
-    """bench.py's N>1 loop: double-buffered tiles, asynchronous gather of frame i under frame i+1."""
+@pytest.mark.parametrize("host_staged", [False, True])
+def test_two_rank_frame_pipeline_keeps_frames_apart(tmp_path, oracle, abi, load_scene, host_staged):
+    """bench.py's N>1 loop: double-buffered tiles, asynchronous gather of frame i under frame i+1 — on the default group,
+    and in the host-staged form on a data group of its own (what bench.py falls back to when RCCL does not come up)."""
     w, h, n = 24, 10, 5
     out = str(tmp_path / "frames.npy")
-    mp.spawn(_pipeline_worker, args=(2, _free_port(), w, h, n, out), nprocs=2, join=True)
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), w, h, n, out, host_staged), nprocs=2, join=True)
     got = np.load(out)
     for i in range(n):
         sc = load_scene("cover", w, h, 1, seed=i)

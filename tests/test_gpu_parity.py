@@ -91,7 +91,7 @@ def test_gpu_math_is_ieee_exact(pkg, oracle, abi, torch_cuda):
     dx, dy = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
     o_sqrt, o_div, o_at = torch.empty_like(dx), torch.empty_like(dx), torch.empty_like(dx)
     o_sqrtf = torch.empty(n, dtype=torch.float32, device="cuda")
-    rc = pkg.hip.lib().rt_hip_math_probe(dx.data_ptr(), dy.data_ptr(), o_sqrt.data_ptr(), o_div.data_ptr(), o_sqrtf.data_ptr(),
+    rc = pkg.hip.probe_lib().rt_hip_math_probe(dx.data_ptr(), dy.data_ptr(), o_sqrt.data_ptr(), o_div.data_ptr(), o_sqrtf.data_ptr(),
                                          o_at.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     torch.cuda.synchronize()
@@ -718,6 +718,69 @@ def test_group_gather_through_rccl_one_rank(pkg, gpu_render, load_scene):
         grp.close()
 
 
+def test_group_transport_fallback_never_costs_the_frame(pkg, gpu_render, load_scene):
+    """The first 8-GPU run happens without a builder watching: whatever RCCL cannot do there, the group must still deliver the
+    frame — on peer copies — and say so.  On the one-GPU box (a one-rank communicator, RT_GATHER_SELFTEST=1): the library that
+    does not load (RT_RCCL_LIB), a self-test gather that delivers wrong bytes, and a gather that fails to enqueue in the
+    SECOND frame (the switch happens mid-stream, that frame's tiles are re-sent) all end on transport "peer" with
+    transport_fallback set and a reason, and every frame — blocking and pipelined — is the single launch's bytes."""
+    sc = load_scene("cover", 96, 40, 2, 50)
+    rgb, _, _ = gpu_render(sc, want_linear=False)
+    base = {"RT_GATHER_SELFTEST": "1", "RT_GATHER": "rccl"}
+    cases = (("healthy", {}, "rccl", ""), ("library", {"RT_RCCL_LIB": "/nonexistent/librccl.so"}, "peer", "cannot load RCCL"),
+             ("selftest", {"RT_RCCL_INJECT": "selftest"}, "peer", "self-test gather delivered"), ("gather", {"RT_RCCL_INJECT": "gather"}, "peer", "ncclGather"))
+    for name, extra, transport, reason in cases:
+        def run():
+            grp = pkg.hip.HipGroup(sc.ptr, 1)
+            infos = [grp.info()]
+            frames = []
+            for _ in range(3):                  # (the injected gather failure hits the second submit of the group)
+                out, st = grp.render_to_host()
+                frames.append(out)
+            bufs = [np.zeros_like(rgb) for _ in range(3)]
+            grp.submit(bufs[0]); grp.submit(bufs[1]); grp.collect(); grp.submit(bufs[2]); grp.collect(); grp.collect()
+            infos.append(grp.info())
+            ranks = grp.ranks()
+            grp.close()
+            return infos, frames + bufs, ranks
+        infos, frames, ranks = _with_env(dict(base, **extra), run)
+        for k, f in enumerate(frames):
+            assert np.array_equal(f, rgb), (name, k)
+        first, last = infos
+        assert last["transport"] == transport and last["transport_fallback"] == (transport == "peer") and reason in last["fallback_reason"], (name, last)
+        if name == "gather":
+            assert first["transport"] == "rccl" and not first["transport_fallback"]      # it switched in the second frame, not before
+        if name in ("library", "selftest"):
+            assert first["transport"] == "peer" and first["rccl_comms"] == 0
+        assert len(ranks) == 1 and ranks[0]["device"] == 0 and ranks[0]["kernel_ms"] > 0 and ranks[0]["peer_to_root"] == 1 and len(ranks[0]["pci_bus_id"]) >= 7, ranks
+        print(f"group transport case {name}: {last['transport']} fallback={last['transport_fallback']} reason={last['fallback_reason']!r} rank0={ranks[0]}")
+
+
+@pytest.mark.parametrize("world,env,bar_us", [(1, {}, 150.0), (8, {"RT_GPUS_EMULATE": "1"}, 400.0)])
+def test_group_submit_into_a_pageable_buffer_does_not_block(pkg, load_scene, world, env, bar_us):
+    """rt_hip_group_submit(out) with an ordinary (pageable) host buffer used to block until the frame was rendered — an
+    asynchronous copy into pageable memory is synchronous in HIP — so the two-deep pipeline degenerated for exactly the call a
+    drop-in host makes (submit returned after 1 840 us, profiles/r04_run1_group_overhead.json).  The frame now leaves into
+    a pinned staging buffer of the group and collect moves it on: submit returns within the host's enqueue time (bar: 150 us
+    for one rank) while the kernel is still running, and the bytes are the blocking frame's."""
+    sc = load_scene("cover", 600, 400, 16, 50)     # ~1 ms of kernel: a blocking submit would show
+    grp = _with_env(env, lambda: pkg.hip.HipGroup(sc.ptr, world))
+    want, st0 = grp.render_to_host()
+    assert st0["kernel_ms"] > 0.3
+    bufs = [np.zeros_like(want) for _ in range(3)]
+    returns = []
+    for rep in range(12):
+        grp.submit(bufs[rep % 3])
+        st = grp.collect()
+        assert np.array_equal(bufs[rep % 3], want)
+        returns.append(st["group_us"][4])
+        assert st["group_us"][6] >= st["group_us"][4]
+    grp.close()
+    best = sorted(returns[2:])[len(returns[2:]) // 2]
+    print(f"group of {world}: submit(out = pageable numpy) returns after {best:.0f} us (median; kernel {st0['kernel_ms']:.2f} ms); all: {[round(r) for r in returns]}")
+    assert best <= bar_us and best < 0.5 * st0["kernel_ms"] * 1e3, (best, returns)
+
+
 def test_group_rejects_more_gpus_than_visible(pkg, load_scene):
     sc = load_scene("cover", 16, 16, 1, 5)
     os.environ.pop("RT_GPUS_EMULATE", None)
@@ -784,17 +847,22 @@ def test_scene_is_not_reentrant_across_streams(pkg, load_scene, torch_cuda):
     gs.close()
 
 
-@pytest.mark.parametrize("force_rccl", [False, True])
+@pytest.mark.parametrize("force_rccl", [False, True, "gloo", "inject"])
 def test_bench_line_contract(force_rccl):
     """bench.py prints ONE JSON line with the driver's keys (+ roofline / cpu_baseline / other_configs objects) and
     nothing else on stdout — also when an RCCL group is up (RT_BENCH_FORCE_COLLECTIVE: the N > 1 code path with one
-    rank; RCCL's version banner must not reach stdout), where it also carries the one-frame latency and the rank /
-    device census."""
-    env = dict(os.environ, MASTER_PORT="29561")
+    rank; RCCL's version banner must not reach stdout), where it also carries the one-frame latency, the rank /
+    device census and the per-rank arrays — and when RCCL does NOT come up ("inject": its set-up raises; "gloo": forced):
+    the run falls back to a host-staged gather over gloo, says so, and still delivers its line."""
+    env = dict(os.environ, MASTER_PORT={False: "29561", True: "29562", "gloo": "29563", "inject": "29564"}[force_rccl])
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-row-stride", "200"]
     if force_rccl:
         env["RT_BENCH_FORCE_COLLECTIVE"] = "1"
         cmd.append("--no-other-configs")
+    if force_rccl == "gloo":
+        env["RT_BENCH_FORCE_TRANSPORT"] = "gloo"
+    if force_rccl == "inject":
+        env["RT_BENCH_INJECT_NCCL_FAILURE"] = "1"
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = r.stdout.strip().splitlines()
@@ -818,7 +886,14 @@ def test_bench_line_contract(force_rccl):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     if force_rccl:
-        assert d["rccl_ranks"] == 1 and d["visible_gpus"] >= 1 and len(d["rank_devices"]) == 1
+        healthy = force_rccl is True
+        assert d["rccl_ranks"] == (1 if healthy else 0) and d["visible_gpus"] >= 1 and len(d["rank_devices"]) == 1
+        assert d["transport"] == ("rccl" if healthy else "gloo-host") and d["transport_fallback"] == (not healthy)
+        assert (d["transport_fallback_reason"] is None) == healthy
+        if force_rccl == "inject":
+            assert "injected" in d["transport_fallback_reason"]
+        pr = d["per_rank"]
+        assert len(pr["kernel_ms"]) == 1 and pr["kernel_ms"][0] > 0 and pr["samples_share"] == [1.0] and len(pr["pci_bus_id"]) == 1 and pr["peer_to_root"] == [1]
         assert d["frame_latency_ms"] >= d["kernel_ms"] * 0.9 and "other_configs" not in d
     else:
         oc = d["other_configs"]
@@ -931,7 +1006,7 @@ def test_device_sphere_hit_matches_oracle_and_host_build(pkg, hostsim, oracle, a
     sph = np.ascontiguousarray(np.concatenate([c, r[:, None]], axis=1))
     d_rays, d_sph = torch.from_numpy(rays).cuda(), torch.from_numpy(sph).cuda()
     out = torch.empty(n, dtype=torch.float64, device="cuda")
-    assert pkg.hip.lib().rt_hip_hit_probe(d_rays.data_ptr(), d_sph.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream) == 0
+    assert pkg.hip.probe_lib().rt_hip_hit_probe(d_rays.data_ptr(), d_sph.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
     got = out.cpu().numpy()
     want, want_o = np.empty(n), np.empty(n)
@@ -958,7 +1033,7 @@ def test_device_fast_texel_arithmetic(pkg, torch_cuda):
     must stay inside); it declines < 1e-4 of ordinary points.  rt_fast_quot / rt_fast_rsqrt: relative error vs numpy."""
     import texel_points
     torch = torch_cuda
-    L = pkg.hip.lib()
+    L = pkg.hip.probe_lib()
     rng = np.random.default_rng(23)
     n = 2_000_000
     total = wrong = refused = 0
@@ -1106,6 +1181,10 @@ def test_bench_multi_gpu_without_torchrun_runs_the_in_library_group():
     assert "BASELINE configs[1]" in d["config"]["workload"] and "in-library group" in d["config"]["parallelism"]
     assert "RANKS SHARE DEVICES" in d["config"]["parallelism"]          # an emulation says so
     assert d["transport"] == "peer" and d["rccl_ranks"] == 0 and len(d["rank_devices"]) == 4 and d["distinct_devices"] == 1
+    assert d["transport_fallback"] is False and d["transport_fallback_reason"] is None    # (peer was what an emulation asks for)
+    pr = d["per_rank"]
+    assert all(len(pr[k]) == 4 for k in ("kernel_ms", "t_wake_us", "t_enq_us", "pci_bus_id", "numa_node", "pinned_cpus", "peer_to_root")), pr
+    assert min(pr["kernel_ms"]) > 0 and max(pr["t_enq_us"]) > 0
     assert d["frame_identical_to_n1"] is True
     samples = 1200 * 800 * 128
     assert abs(d["value"] - samples / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * d["value"]
@@ -1185,17 +1264,17 @@ def test_group_submit_collect_pipelines_frames_bit_identically(pkg, gpu_render, 
     grp.close()
 
 
-def test_seeded_first_frame_order_is_only_an_order(gpu_render, abi, load_scene):
-    """A frame without a measured queue order sorts its tiles by a seed (rt_hip_api.hip: projection of the spheres, or a
-    probe launch) — the bytes, the linear image and the path count never depend on it: whole frames and shards, lit and
-    unlit, against the fixed bottom-row-first order."""
+def test_queue_order_is_only_an_order(gpu_render, abi, load_scene):
+    """The order in which tiles leave the frame's queue — top row first, bottom row first, the deepest tiles of the previous
+    frame first (measured by frame 1, used by frame 2), one queue or one per XCD — never shows in the bytes, the linear
+    image or the path count: whole frames and shards, lit and unlit.  (The two first-frame order SEEDS of round 4 left the
+    product in round 5: profiles/r05_order_seed_removed.patch.)"""
     for scene, w, h, spp, depth in (("cover", 200, 120, 4, 50), ("test", 96, 72, 3, 8)):
         sc = load_scene(scene, w, h, spp, depth)
         for tiles in (None, abi.RtRowTiles(2, 1, 3)):
             ref = gpu_render(sc, tiles=tiles, tile_order=1)
-            for opts in ({"tile_order": 3, "order_seed": 1}, {"tile_order": 3, "order_seed": 2}, {"tile_order": 2, "order_seed": 1},
-                         {"tile_order": 2, "order_seed": 2}, {"tile_order": 2, "order_seed": 0}, {"tile_order": 3, "order_seed": 1, "tile_affinity": 2}):
-                got = gpu_render(sc, tiles=tiles, opts=opts, frames=2)
+            for opts in ({"tile_order": 0}, {"tile_order": 2}, {"tile_order": 2, "tile_affinity": 2}, {"tile_order": 0, "tile_affinity": 2}, {"tile_order": 2, "tile_affinity": 0}):
+                got = gpu_render(sc, tiles=tiles, opts=opts, frames=3)
                 assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), (scene, opts)
                 assert got[2]["segments"] == ref[2]["segments"] and got[2]["samples"] == ref[2]["samples"]
 
@@ -1222,7 +1301,7 @@ def test_device_atan2_against_a_million_correctly_rounded_results(pkg, torch_cud
     y, x, _ = points()
     dy, dx = torch.from_numpy(y).cuda(), torch.from_numpy(x).cuda()
     out = torch.empty_like(dy)
-    assert pkg.hip.lib().rt_hip_atan2_probe(dy.data_ptr(), dx.data_ptr(), out.data_ptr(), y.size, torch.cuda.current_stream().cuda_stream) == 0
+    assert pkg.hip.probe_lib().rt_hip_atan2_probe(dy.data_ptr(), dx.data_ptr(), out.data_ptr(), y.size, torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
     check_atan2_against_the_fixture(out.cpu().numpy(), y, x)
 
@@ -1248,7 +1327,7 @@ def test_scene_query_and_tile_depth_diagnostics(pkg, load_scene, torch_cuda):
     leaves a depth per tile — 0 where no path bounces (sky), up to max_depth where glass is."""
     torch = torch_cuda
     sc = load_scene("cover", 240, 160, 8, 50)
-    gs = pkg.hip.HipScene(sc.ptr, 0)
+    gs = pkg.hip.HipScene(sc.ptr, 0, library=pkg.hip.probe_lib())   # (the debug call lives in librt_hip_probe.so: include/rt_abi_test.h)
     assert gs.query("n_spheres") == 484 and gs.query("n_lights") == 0 and gs.query("no_such_key") == -1
     cells, items, large = gs.query("grid_cells"), gs.query("grid_items"), gs.query("grid_large")
     assert cells > 1000 and items >= 480 and 1 <= large <= 8

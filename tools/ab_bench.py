@@ -22,7 +22,7 @@ SRC = os.path.join(ROOT, "rust-raytracer_amd", "csrc", "hip", "rt_hip_api.hip")
 BASE = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DRT_DEV_KNOBS"]  # A/B builds read the RT_GRID_* / RT_AFF_RUN_LOG2 knobs; the product does not
 # name -> (extra compile flags, runtime options, environment at scene creation)
 W4 = ["-DRT_WAVES_PER_EU=4"]
-SCAN = ["-DRT_WITH_SCAN_KERNEL"]   # the round-1 cull-scan kernel is compiled into A/B builds only ("variant" 2)
+
 VARIANTS = {
     # (slow reference arms first: whatever is measured right after a 100+ ms kernel reads ~4 % high)
     "brute_force_on_gpu": (W4, {"variant": 1}, {}),

@@ -16,7 +16,7 @@ def main():
     os.chdir(ROOT)
     pkg = graft.load_package()
     sc = pkg.host.Scene.load("scenes/cfg2_cover_1200x800_spp128.json")
-    gs = pkg.hip.HipScene(sc.ptr, 0)
+    gs = pkg.hip.HipScene(sc.ptr, 0, library=pkg.hip.probe_lib())   # (rt_hip_debug_tile_depth: include/rt_abi_test.h)
     fb = torch.zeros((sc.c.height, sc.c.width, 3), dtype=torch.uint8, device="cuda:0")
     gs.render(fb.data_ptr(), 0, None, torch.cuda.current_stream().cuda_stream)
     gs.wait()

@@ -42,8 +42,8 @@ def main():
     import torch
     os.chdir(ROOT)
     pkg = graft.load_package()
-    if a.lib:
-        pkg.hip.LIB_PATH = os.path.abspath(a.lib)
+    if a.lib:   # (a -DRT_PROFILE -DRT_TEST_PROBES build: the timeline comes through rt_hip_debug_timeline, include/rt_abi_test.h)
+        pkg.hip.LIB_PATH = pkg.hip.PROBE_LIB_PATH = os.path.abspath(a.lib)
     if a.procedural:
         sys.path.insert(0, os.path.join(ROOT, "scenes"))
         import procedural
@@ -57,7 +57,7 @@ def main():
         sc.c.height = a.height
     if a.spp:
         sc.c.samples_per_pixel = a.spp
-    gs = pkg.hip.HipScene(sc.ptr, 0)
+    gs = pkg.hip.HipScene(sc.ptr, 0, library=pkg.hip.probe_lib() if a.lib else None)   # (--lib: a profile build with the debug calls)
     for kv in a.opt:
         k, v = kv.split("=")
         gs.set_option(k, int(v))
