@@ -191,6 +191,9 @@ typedef struct RtSceneFile RtSceneFile; /* owns the RtScene and every buffer it 
 /* main.rs:14-15: read + parse a scene file; texture paths resolve relative to cwd. */
 int rt_scene_load_file(const char* json_path, RtSceneFile** out);
 int rt_scene_load_string(const char* json_text, size_t len, RtSceneFile** out);
+/* where a load went, milliseconds: out = {reading the file, parsing the JSON text, the longest JPEG decode (the textures are
+ * decoded concurrently, beside the parse), the whole call}; the CLI prints them under RT_STATS=1 */
+void rt_scene_load_timings(const RtSceneFile*, double out[4]);
 const RtScene* rt_scene_get(const RtSceneFile*);
 RtScene* rt_scene_get_mut(RtSceneFile*); /* tests override width/height like raytracer.rs:272-273 */
 void rt_scene_free(RtSceneFile*);

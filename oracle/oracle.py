@@ -10,6 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_INDEP = None
 
 
 def build():
@@ -65,7 +66,22 @@ def lib(abi):
     return _LIB
 
 
-def render(abi, scene_ptr, tiles=None, n_threads=0, want_linear=True, x_range=None):
+def indep_lib(abi):
+    """librt_oracle_indep.so: the restatement with the light-sampling draw on a Philox block of its own (round 3's addressing);
+    an independent reference for STATISTICS of the shipped addressing (tests/test_light_draw_statistics.py), never for parity"""
+    global _INDEP
+    if _INDEP is None:
+        path = os.path.join(_HERE, "librt_oracle_indep.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.rt_oracle_render_window.argtypes = [C.POINTER(abi.RtScene), C.POINTER(abi.RtRowTiles), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                              C.POINTER(abi.RtStats), C.c_int]
+        _INDEP = L
+    return _INDEP
+
+
+def render(abi, scene_ptr, tiles=None, n_threads=0, want_linear=True, x_range=None, independent_light_draw=False):
     """-> (rgb8 [rows,w,3] u8, linear [rows,w,3] f32 | None, stats dict); x_range = (x0, x1): only those pixels
     of the rows are rendered (the rest of the arrays stays 0)"""
     sc = scene_ptr.contents
@@ -74,7 +90,7 @@ def render(abi, scene_ptr, tiles=None, n_threads=0, want_linear=True, x_range=No
     lin = np.zeros((rows, sc.width, 3), np.float32) if want_linear else None
     st = abi.RtStats()
     x0, x1 = x_range if x_range is not None else (0, sc.width)
-    rc = lib(abi).rt_oracle_render_window(scene_ptr, C.byref(tiles) if tiles is not None else None, x0, x1, rgb.ctypes.data,
+    rc = (indep_lib(abi) if independent_light_draw else lib(abi)).rt_oracle_render_window(scene_ptr, C.byref(tiles) if tiles is not None else None, x0, x1, rgb.ctypes.data,
                                           lin.ctypes.data if lin is not None else None, C.byref(st), n_threads)
     if rc != 0:
         raise RuntimeError(f"rt_oracle_render failed: {rc}")

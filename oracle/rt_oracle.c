@@ -370,7 +370,12 @@ static Rgb ray_color(Ctx* c, Ray ray, uint32_t max_depth, uint32_t depth, uint32
        * is the fourth word of attempt 0's call) */
       uint32_t w[4]; rng_words(c, node, 0, w);
       uint32_t high = w[3];
+#ifndef RT_ORACLE_INDEPENDENT_LIGHT_DRAW
+      /* (librt_oracle_indep.so is built WITH the macro: every hit's draw is slot 0's words 2 and 3, a Philox block no other
+       *  draw of the node touches — round 3's addressing.  Only tests/test_light_draw_statistics.py uses it: an independent
+       *  reference for the statistics of the shared-word addressing below; its images differ, by design.) */
       if (sc->spheres[rec.idx].kind != RT_MAT_GLASS) { uint32_t a0[4]; rng_words(c, node, 1, a0); high = a0[3]; }
+#endif
       if (u01_53(w[2], high) > (1.0 - (double)c->n_lights * prob)) {
         if (st == SCATTER_EMIT) c->discarding++;  /* (counter only: :124 returns `albedo`, not the light sum) */
         for (uint32_t j = 0; j < c->n_lights; ++j) {                                    /* :103-110 */

@@ -145,7 +145,8 @@ RT_HD double grid_walk_eps(uint32_t n_max) {
 
 struct DevScene {
   uint32_t width, height, spp, max_depth;
-  uint32_t sky_mode, n_spheres, n_lights, n_pairs;
+  uint32_t sky_mode, n_spheres, n_lights;
+  uint32_t light_nest_pool;    // lit scenes: 1 (default) = nested light activations take pool records; 0 = always the HBM overflow ("light_nest_pool" option, tests)
   uint32_t seed_lo, seed_hi;
   uint32_t light_pool_slots;  // lit scenes: records in the workgroup's pool of light frames (LightState<true, true>)
   uint32_t cam_fast;          // inv_wm1 and inv_hm1 are both usable (width, height > 1): divide through them
@@ -157,7 +158,11 @@ struct DevScene {
   double wm1, hm1, inv_wm1, inv_hm1, height_d;  // (width-1), (height-1), their RN reciprocals (0: slow divide), height
   const SphereGeom* geom;
   const SphereMat* mat;
-  const CullPair* cull;
+  // lit scenes: where a SUSPENDED light activation goes when the workgroup's pool has no record for the nested one that
+  // suspends it (80 B x (RT_MAX_LIGHT_NEST - 1) per lane of the launch, in HBM; practically never touched): the guarantee
+  // that a lane holding records never waits for one (lane_light_begin).  (This pointer and the flag above sit where the
+  // round-1 scan kernel's cull table and pair count sat: the kernel arguments keep the layout the unlit kernels were tuned with.)
+  unsigned char* light_overflow;
   const uint32_t* lights;  // sphere indices of Light spheres, object order (raytracer.rs:220-229)
   const uint8_t* tex;      // all textures back to back, RGB8 (null on the device when every texture takes the 4-byte path)
   const uint8_t* sky;      // sky texture RGB8 (null on the device when sky_fast)
@@ -173,12 +178,6 @@ struct DevScene {
   const uint32_t* large;       // [n_large] sphere indices, object order
   const SphereGeom* large_geom;  // [n_large] their geometry, packed in the same order (streamed by scalar loads)
   const MatCore* matc;         // [n_spheres]
-  // lit scenes: where a SUSPENDED light activation goes when the workgroup's pool has no record for the nested one that
-  // suspends it (80 B x (RT_MAX_LIGHT_NEST - 1) per lane of the launch, in HBM; practically never touched): the guarantee
-  // that a lane holding records never waits for one (lane_light_begin)
-  unsigned char* light_overflow;
-  uint32_t light_nest_pool;    // 1 (default): nested activations take pool records; 0: always the overflow ("light_nest_pool" option, tests)
-  uint32_t pad3;
 };
 
 // ------------------------------------------------------------------ f64 square root

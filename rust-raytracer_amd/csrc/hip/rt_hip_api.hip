@@ -38,7 +38,7 @@ struct RtHipScene {
   RtScene host{};          // scalar fields only (pointers are not kept)
   rtc::DevScene dev{};     // device pointers filled in
   bool has_lights = false, simple_colour = false;
-  void* d_geom = nullptr; void* d_mat = nullptr; void* d_cull = nullptr; void* d_lights = nullptr;
+  void* d_geom = nullptr; void* d_mat = nullptr; void* d_lights = nullptr;
   void* d_tex = nullptr; void* d_sky = nullptr; void* d_tex4 = nullptr; void* d_sky4 = nullptr;
   size_t texel_bytes = 0;
   void* d_matc = nullptr; void* d_cell_word = nullptr; void* d_cell_items = nullptr; void* d_large = nullptr;
@@ -139,7 +139,7 @@ extern "C" int rt_hip_device_count(void) {
 extern "C" void rt_hip_scene_destroy(RtHipScene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  for (void* p : {s->d_geom, s->d_mat, s->d_cull, s->d_lights, s->d_tex, s->d_sky, s->d_tex4, s->d_sky4, (void*)s->d_counters, s->d_matc,
+  for (void* p : {s->d_geom, s->d_mat, s->d_lights, s->d_tex, s->d_sky, s->d_tex4, s->d_sky4, (void*)s->d_counters, s->d_matc,
                   s->d_cell_word, s->d_cell_items, s->d_large, s->d_all, s->d_large_geom, s->d_frame, (void*)s->d_tile_depth,
                   (void*)s->d_tile_order, s->d_light_overflow})
     if (p) (void)hipFree(p);
@@ -192,7 +192,6 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   auto bail = [&](int code) { rt_hip_scene_destroy(s); return code; };
   if ((rc = upload(&s->d_geom, t.geom)) != RT_OK) return bail(rc);
   if ((rc = upload(&s->d_mat, t.mat)) != RT_OK) return bail(rc);
-  if ((rc = upload(&s->d_cull, t.cull)) != RT_OK) return bail(rc);
   if ((rc = upload(&s->d_lights, t.lights)) != RT_OK) return bail(rc);
   if ((rc = upload(&s->d_matc, t.matc)) != RT_OK) return bail(rc);
   if ((rc = upload(&s->d_cell_word, t.cell_word)) != RT_OK) return bail(rc);
@@ -233,7 +232,7 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   if (hipMemset(s->d_counters, 0, (32 + 4 * RT_TIMELINE_WAVES) * sizeof(unsigned long long)) != hipSuccess)
     return bail(fail(RT_ERR_HIP, "hipMemset failed"));
   s->dev.geom = (const rtc::SphereGeom*)s->d_geom; s->dev.mat = (const rtc::SphereMat*)s->d_mat;
-  s->dev.cull = (const rtc::CullPair*)s->d_cull; s->dev.lights = (const uint32_t*)s->d_lights;
+  s->dev.lights = (const uint32_t*)s->d_lights;
   s->dev.tex = (const uint8_t*)s->d_tex; s->dev.sky = (const uint8_t*)s->d_sky;
   s->dev.tex4 = (const uint32_t*)s->d_tex4; s->dev.sky4 = (const uint32_t*)s->d_sky4;
   s->dev.matc = (const rtc::MatCore*)s->d_matc; s->dev.cell_word = (const uint32_t*)s->d_cell_word;

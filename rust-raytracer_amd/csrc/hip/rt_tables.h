@@ -334,7 +334,7 @@ inline void fill_dev_scene(const RtScene& sc, const HostTables& t, DevScene& d) 
   std::memset(&d, 0, sizeof d);
   d.width = sc.width; d.height = sc.height; d.spp = sc.samples_per_pixel; d.max_depth = sc.max_depth;
   d.sky_mode = sc.sky_mode; d.n_spheres = sc.n_spheres; d.n_lights = (uint32_t)t.lights.size();
-  d.n_pairs = t.n_pairs;
+  d.light_nest_pool = 1u;
   d.seed_lo = (uint32_t)sc.seed; d.seed_hi = (uint32_t)(sc.seed >> 32);
   d.light_thr[0] = 1.0 - (double)d.n_lights * 0.1;   // raytracer.rs:100, the reference's operations (no contraction: -ffp-contract=off)
   d.light_thr[1] = 1.0 - (double)d.n_lights * 0.05;  // Glass (raytracer.rs:94-96)

@@ -171,6 +171,8 @@ int animate(RtSceneFile* sf, const char* prefix, int frames, double orbit_deg) {
 }  // namespace
 
 int main(int argc, char** argv) {
+  const auto t_main = std::chrono::steady_clock::now();
+  auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
   int frames = 0;
   double orbit = 0.0;
   bool orbit_given = false, bad_args = argc < 3;
@@ -197,9 +199,13 @@ int main(int argc, char** argv) {
     return status;
   }
   const char* filename = argv[2];
+  const double load_done_ms = ms_since(t_main);
   std::printf("\nRendering %s\n", filename);  // main.rs:18
   std::vector<uint8_t> pixels((size_t)sc->width * sc->height * 3);  // raytracer.rs:254
   RtStats st{};
+  const auto t_hip = std::chrono::steady_clock::now();
+  (void)rt_hip_device_count();  // (the HIP runtime comes up with the first call into it: timed apart from the scene's own set-up)
+  const double hip_init_ms = ms_since(t_hip);
   rc = rt_render_rgb8(sc, pixels.data(), &st);
   if (rc != RT_OK) {
     std::fprintf(stderr, "render failed: %s: %s\n", rt_strerror(rc), rt_hip_last_error());
@@ -207,13 +213,19 @@ int main(int argc, char** argv) {
     return 101;
   }
   std::printf("Frame time: %lldms\n", (long long)st.frame_ms);  // raytracer.rs:263
-  if (std::getenv("RT_STATS"))
+  const auto t_png = std::chrono::steady_clock::now();
+  rc = rt_png_write_rgb8(filename, pixels.data(), sc->width, sc->height);  // raytracer.rs:265
+  const double png_ms = ms_since(t_png);
+  if (std::getenv("RT_STATS")) {  // where a drop-in user's wall time goes: main() entered -> PNG on disk
+    double lt[4] = {0, 0, 0, 0};
+    rt_scene_load_timings(sf, lt);
     std::fprintf(stderr, "{\"samples\":%llu,\"segments\":%llu,\"sphere_tests\":%llu,\"exact_tests\":%llu,\"n_gpus\":%u,\"kernel_ms\":%.3f,"
-                         "\"gather_ms\":%.3f,\"frame_ms\":%.3f,\"setup_ms\":%.3f,\"msamples_per_s\":%.3f}\n",
+                         "\"gather_ms\":%.3f,\"frame_ms\":%.3f,\"setup_ms\":%.3f,\"msamples_per_s\":%.3f,"
+                         "\"load_ms\":%.3f,\"read_ms\":%.3f,\"json_ms\":%.3f,\"jpeg_ms\":%.3f,\"hip_init_ms\":%.3f,\"png_ms\":%.3f,\"main_ms\":%.3f}\n",
                  (unsigned long long)st.samples, (unsigned long long)st.segments, (unsigned long long)st.sphere_tests,
                  (unsigned long long)st.exact_tests, st.n_gpus_used, st.kernel_ms, st.gather_ms, st.frame_ms, st.setup_ms,
-                 st.samples / (st.kernel_ms * 1e3));
-  rc = rt_png_write_rgb8(filename, pixels.data(), sc->width, sc->height);  // raytracer.rs:265
+                 st.samples / (st.kernel_ms * 1e3), load_done_ms, lt[0], lt[1], lt[2], hip_init_ms, png_ms, ms_since(t_main));
+  }
   rt_scene_free(sf);
   if (rc != RT_OK) {
     std::fprintf(stderr, "error writing image: %s\n", rt_host_last_error());

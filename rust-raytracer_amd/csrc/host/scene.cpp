@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -117,6 +118,10 @@ struct RtSceneFile {
   std::unique_ptr<uint8_t, void (*)(void*)> sky_pixels{nullptr, std::free};
   std::string sky_path;
   double look_from[3]{}, look_at[3]{}, vup[3]{}, vfov = 0, aspect = 0, focal_length = 0;
+  // where the load went (rt_scene_load_timings): reading the file, parsing the JSON text, the longest JPEG decode (they run
+  // concurrently, beside the parse), everything (read + parse + schema + waiting for the decodes)
+  double read_ms = 0, json_ms = 0, jpeg_ms = 0, total_ms = 0;
+  std::shared_ptr<std::atomic<long long>> jpeg_us_max{new std::atomic<long long>(0)};
 };
 
 namespace {
@@ -130,12 +135,20 @@ struct Decoded {
   std::string err;
 };
 typedef std::map<std::string, std::shared_future<Decoded>> DecodeJobs;
+thread_local std::shared_ptr<std::atomic<long long>> g_jpeg_us_max;  // the load in progress on this thread records its longest decode here
 void start_decode(DecodeJobs& jobs, const std::string& path) {
   if (path.empty() || jobs.count(path)) return;
-  jobs[path] = std::async(std::launch::async, [path]() {
+  std::shared_ptr<std::atomic<long long>> longest = g_jpeg_us_max;
+  jobs[path] = std::async(std::launch::async, [path, longest]() {
     Decoded d;
+    const auto t0 = std::chrono::steady_clock::now();
     d.rc = rt_jpeg_decode_file(path.c_str(), &d.px, &d.w, &d.h);
     if (d.rc != RT_OK) d.err = rt_jpeg_last_error();  // (thread-local in the decoder: read it on this thread)
+    if (longest) {
+      const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+      long long cur = longest->load();
+      while (us > cur && !longest->compare_exchange_weak(cur, us)) {}
+    }
     return d;
   }).share();
 }
@@ -369,8 +382,13 @@ extern "C" int rt_scene_load_string(const char* json_text, size_t len, RtSceneFi
   if (!json_text || !out) return set_err(RT_ERR_INVALID, "null argument");
   *out = nullptr;
   std::unique_ptr<RtSceneFile> sf(new RtSceneFile);
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+  g_jpeg_us_max = sf->jpeg_us_max;
+  struct Reset { ~Reset() { g_jpeg_us_max.reset(); } } reset;
   try {
     rtjson::ValuePtr root = rtjson::parse(json_text, len);
+    sf->json_ms = ms_since(t0);
     build_scene(*root, *sf);
   } catch (const rtjson::ParseError& e) {
     return set_err(RT_ERR_PARSE, std::string("Unable to parse config json: ") + e.what());
@@ -378,18 +396,29 @@ extern "C" int rt_scene_load_string(const char* json_text, size_t len, RtSceneFi
     bool tex = e.msg.rfind("texture ", 0) == 0 || e.msg.rfind("sky texture ", 0) == 0;
     return set_err(tex ? RT_ERR_TEXTURE : RT_ERR_PARSE, (tex ? std::string() : std::string("Unable to parse config json: ")) + e.msg);
   }
+  sf->jpeg_ms = (double)sf->jpeg_us_max->load() * 1e-3;
+  sf->total_ms = ms_since(t0);
   *out = sf.release();
   return RT_OK;
+}
+
+extern "C" void rt_scene_load_timings(const RtSceneFile* sf, double out[4]) {
+  if (!sf || !out) return;
+  out[0] = sf->read_ms; out[1] = sf->json_ms; out[2] = sf->jpeg_ms; out[3] = sf->total_ms;
 }
 
 extern "C" int rt_scene_load_file(const char* json_path, RtSceneFile** out) {
   if (!json_path || !out) return set_err(RT_ERR_INVALID, "null argument");
   FILE* f = std::fopen(json_path, "rb");
   if (!f) return set_err(RT_ERR_IO, std::string("Unable to read config file. (") + json_path + ": " + std::strerror(errno) + ")");
+  const auto t0 = std::chrono::steady_clock::now();
   std::string text; char buf[65536]; size_t n;
   while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
   std::fclose(f);
-  return rt_scene_load_string(text.data(), text.size(), out);
+  const double read_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  const int rc = rt_scene_load_string(text.data(), text.size(), out);
+  if (rc == RT_OK) { (*out)->read_ms = read_ms; (*out)->total_ms += read_ms; }
+  return rc;
 }
 
 extern "C" const RtScene* rt_scene_get(const RtSceneFile* sf) { return sf ? &sf->scene : nullptr; }

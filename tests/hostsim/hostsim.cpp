@@ -145,7 +145,7 @@ extern "C" int hostsim_render(const RtScene* scene, const RtRowTiles* tiles, uin
   std::vector<uint8_t> blob(t.tex_bytes ? t.tex_bytes : 1);
   for (uint32_t i = 0; i < scene->n_textures; ++i)
     if (scene->textures[i].nbytes) std::memcpy(&blob[t.tex_off[i]], scene->textures[i].rgb8, scene->textures[i].nbytes);
-  ds.geom = t.geom.data(); ds.mat = t.mat.data(); ds.cull = t.cull.data(); ds.lights = t.lights.data();
+  ds.geom = t.geom.data(); ds.mat = t.mat.data(); ds.lights = t.lights.data();
   ds.tex = blob.data(); ds.sky = scene->sky_rgb8;
   ds.matc = t.matc.data(); ds.cell_word = t.cell_word.data(); ds.cell_items = t.cell_items.data(); ds.large = t.large.data(); ds.large_geom = t.large_geom.data();
   // +32: the SHORT colour maps the product kernel takes when every albedo lies in [0, 1] (rt_core.h FwdT<true>; lit scenes:

@@ -8,7 +8,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HOST_SYMS = {"rt_scene_camera", "rt_scene_load_file", "rt_scene_load_string", "rt_scene_get", "rt_scene_get_mut", "rt_scene_free", "rt_scene_to_json",
+HOST_SYMS = {"rt_scene_camera", "rt_scene_load_timings", "rt_scene_load_file", "rt_scene_load_string", "rt_scene_get", "rt_scene_get_mut", "rt_scene_free", "rt_scene_to_json",
              "rt_host_last_error", "rt_camera_derive", "rt_find_lights", "rt_jpeg_decode_file", "rt_jpeg_decode_mem", "rt_jpeg_last_error",
              "rt_png_write_rgb8", "rt_free"}
 

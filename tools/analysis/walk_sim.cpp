@@ -31,6 +31,7 @@ struct SimGrid {
   bool dedupe_free = false;   // landing in a cell whose candidate is the sphere tested last drops it in the step block (no test round)
   int cull = 0;               // 0: the product; 1: candidates whose exact test cannot accept are dropped for free when their cell is entered (ideal cull); 2: the conservative f32 cull of rt_core.h; 3 / 4: the same two, realisable form (the two candidates of the cell word only; a culled-out cell ends the step round)
   const DevScene* ds;
+  const CullPair* cull_table = nullptr;  // (host table: the device scene no longer carries the round-1 cull table)
   std::vector<uint8_t> skip;  // per padded cell: Chebyshev distance to the nearest non-empty cell or EXIT border, capped (0 for non-empty)
   int max_cells = 2;          // cells a lane may advance per step round
   bool use_skip = false;
@@ -124,7 +125,7 @@ static void lane_walk_cull(const SimGrid& sg, V3 o, V3 d, double& closest, int& 
     if (sg.cull == 8) return true;
     const SphereGeom& g = sc.geom[idx];
     if (sg.cull == 2 || sg.cull == 4) {
-      const CullPair& cp = sc.cull[idx / 2];
+      const CullPair& cp = sg.cull_table[idx / 2];
       return cull_pass(cull_disc(rf, cp.cx[idx & 1], cp.cy[idx & 1], cp.cz[idx & 1], cp.R[idx & 1]));
     }
     const V3 oc = sub(o, v3(g.cx, g.cy, g.cz));
@@ -224,7 +225,7 @@ int main(int argc, char** argv) {
   build_texels(sc, t);
   DevScene ds; fill_dev_scene(sc, t, ds);
   ds.tex4 = t.tex4.data(); ds.sky4 = t.sky4.data();
-  ds.geom = t.geom.data(); ds.mat = t.mat.data(); ds.cull = t.cull.data(); ds.lights = t.lights.data(); ds.sky = sc.sky_rgb8;
+  ds.geom = t.geom.data(); ds.mat = t.mat.data(); ds.lights = t.lights.data(); ds.sky = sc.sky_rgb8;
   ds.matc = t.matc.data(); ds.cell_word = t.cell_word.data(); ds.cell_items = t.cell_items.data(); ds.large = t.large.data(); ds.large_geom = t.large_geom.data();
   std::vector<uint8_t> blob(t.tex_bytes ? t.tex_bytes : 1);
   for (uint32_t i = 0; i < sc.n_textures; ++i) std::memcpy(&blob[t.tex_off[i]], sc.textures[i].rgb8, sc.textures[i].nbytes);
@@ -236,7 +237,7 @@ int main(int argc, char** argv) {
     std::printf("grid %ux%ux%u, %u cells (%u padded), %u items, %u large, non-empty %.1f %%, cell bytes %u\n", G.n[0], G.n[1], G.n[2], inner, G.n_cells,
                 G.n_items, G.n_large, 100.0 * nonempty / inner, G.n_cells * 8u);
   }
-  SimGrid sg; sg.ds = &ds; sg.max_cells = max_cells; sg.use_skip = use_skip; sg.cull = cull; sg.dedupe_free = argc > 9 && atoi(argv[9]) != 0;
+  SimGrid sg; sg.ds = &ds; sg.cull_table = t.cull.data(); sg.max_cells = max_cells; sg.use_skip = use_skip; sg.cull = cull; sg.dedupe_free = argc > 9 && atoi(argv[9]) != 0;
   const GlobalTables tb{ds.geom, ds.matc};
   const uint32_t TW = 4, TH = 4, NPX = TW * TH;
   const uint32_t tx = (sc.width + TW - 1) / TW, ty = (sc.height + TH - 1) / TH, n_tiles = tx * ty;
