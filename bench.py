@@ -617,6 +617,8 @@ def run_ranks(args):
             out["git_head"] = _git_head()
         if world == 1 and headline and not args.no_other_configs:
             out["other_configs"] = other_configs(pkg, torch, dev, stream)
+            out["mixed_radius_worlds"] = mixed_radius_worlds(pkg, torch, dev, stream)
+            out["cli"] = cli_wall_times()
         if world == 1 and not args.no_cpu_baseline:
             oracle = graft.load_oracle()
             cores = oracle.lib(abi).rt_oracle_threads()
@@ -706,6 +708,71 @@ def other_configs(pkg, torch, dev, stream):
         res.append(rec)
         g.close()
         del fb
+    return res
+
+
+def mixed_radius_worlds(pkg, torch, dev, stream):
+    """SURVEY §8 f2 outside BASELINE's sphere distribution: 10^4 spheres with radii over two decades (scenes/procedural.py
+    radii="loguniform" / "bimodal"; parity: tests/test_gpu_parity.py::test_mixed_radius_10k_sphere_worlds) at 1920x1080 spp 128:
+    what the single-level grid + `large` list make of them"""
+    sys.path.insert(0, os.path.join(ROOT, "scenes"))
+    import procedural
+    res = []
+    for radii in ("loguniform", "bimodal"):
+        s = pkg.host.Scene.loads(procedural.make_json(width=1920, height=1080, spp=128, half=50, seed=0, radii=radii))
+        g = pkg.hip.HipScene(s.ptr, dev.index or 0)
+        fb = torch.zeros((s.c.height, s.c.width, 3), dtype=torch.uint8, device=dev)
+        ks = []
+        for _ in range(3):
+            g.render(fb.data_ptr(), 0, None, stream.cuda_stream)
+            st = g.wait()
+            ks.append(st["kernel_ms"])
+        k = min(ks[1:])
+        n = s.c.width * s.c.height * s.c.samples_per_pixel
+        res.append({"world": f"procedural, radii {radii}: {s.c.n_spheres} spheres, 1920x1080 spp 128 depth 50", "kernel_ms": round(k, 2),
+                    "msamples_per_s": round(n / k / 1e3, 1), "segments_per_sample": round(st["segments"] / n, 3),
+                    "exact_tests_per_segment": round(st["exact_tests"] / max(1, st["segments"]), 2), "grid_steps_per_segment": round(st["grid_steps"] / max(1, st["segments"]), 2),
+                    "grid_cells": g.query("grid_cells"), "grid_items": g.query("grid_items"), "grid_large": g.query("grid_large"), "lds_tables": g.query("lds_tables")})
+        g.close()
+        del fb
+    return res
+
+
+def cli_wall_times():
+    """What a drop-in user sees: wall time of `raytracer <scene> out.png` from process start to PNG on disk — the
+    reference's one frame per process (main.rs:7-20) — for the headline config and the reference's test_scene (three JPEG
+    decodes), split by the CLI's own clocks (RT_STATS=1): JSON, JPEG, HIP start-up, scene set-up (tables + upload + module
+    load), frame (the window the reference times, raytracer.rs:259-263), PNG.  Median of 3 runs each."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "rust-raytracer_amd", "raytracer")
+    res = []
+    if not os.path.exists(exe):
+        return res
+    for name, scene in (("cfg2 cover 1200x800 spp128", HEADLINE), ("cfg1 test_scene 800x600 spp16 (3 JPEG textures)", "scenes/cfg1_test_800x600_spp16.json")):
+        runs = []
+        with tempfile.TemporaryDirectory() as td:
+            for _ in range(3):
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, scene, os.path.join(td, "out.png")], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, RT_STATS="1"), timeout=120)
+                wall = (time.perf_counter() - t0) * 1e3
+                if r.returncode != 0:
+                    continue
+                try:
+                    st = json.loads([l for l in r.stderr.splitlines() if l.startswith("{")][-1])
+                except Exception:
+                    continue
+                st["wall_ms"] = wall
+                runs.append(st)
+        if not runs:
+            continue
+        runs.sort(key=lambda d: d["wall_ms"])
+        m = runs[len(runs) // 2]
+        res.append({"scene": name, "wall_ms": round(m["wall_ms"], 1), "main_ms": round(m["main_ms"], 1),
+                    "process_start_and_exit_ms": round(m["wall_ms"] - m["main_ms"], 1),
+                    "load_ms": round(m["load_ms"], 2), "json_ms": round(m["json_ms"], 2), "jpeg_ms": round(m["jpeg_ms"], 2),
+                    "hip_init_ms": round(m["hip_init_ms"], 1), "setup_ms": round(m["setup_ms"], 1), "frame_ms": round(m["frame_ms"], 2),
+                    "kernel_ms": round(m["kernel_ms"], 2), "png_ms": round(m["png_ms"], 2), "runs": len(runs)})
     return res
 
 

@@ -1167,14 +1167,11 @@ RT_HD void light_frame_release(const DevScene&, LightState<true, false>&) {}
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ LightParked& light_frame(LightState<true, true>& ls) { return *reinterpret_cast<LightParked*>(rt_lds_dyn + ls_where(ls)); }
 __device__ __forceinline__ uint32_t& light_link(uint32_t where) { return *reinterpret_cast<uint32_t*>(rt_lds_dyn + where + (uint32_t)sizeof(LightFrame)); }
-// Take a record of the pool whose bitmap sits at `bitmap_off` (n_slots of them, a multiple of 32): its index, or ~0: none
-// free.  Everything here is full-rate arithmetic: the start word is a 16-bit multiplicative hash of the seed scaled to the
-// word count by a 24-bit multiply (the round-4 form took `hash % words` — ~20 instructions of emulated division, five of
-// them quarter-rate multiplies — in a branch some lane of nearly every wave iteration takes), and one flat loop.
-__device__ __forceinline__ uint32_t light_pool_take(uint32_t bitmap_off, uint32_t n_slots, uint32_t seed) {
-  uint32_t* const bitmap = reinterpret_cast<uint32_t*>(rt_lds_dyn + bitmap_off);
-  const uint32_t words = n_slots >> 5;
-  uint32_t w = __umul24(__umul24(seed & 0xFFFFu, 0x9E3Bu) & 0xFFFFu, words) >> 16, full = 0;
+// Take a record of a pool (a bitmap of `words` 32-bit words): its index, or ~0: none free — every word once, starting at w.
+// One flat loop of full-rate arithmetic.  (Inlined twice, frames and bases: as a real call it cost the lit kernels 1 - 5 spilled
+// registers around the call site.)
+__device__ __forceinline__ uint32_t light_pool_take(uint32_t* bitmap, uint32_t words, uint32_t w) {
+  uint32_t full = 0;
   uint32_t cur = __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   for (;;) {
     if (cur == 0xFFFFFFFFu) {  // this word is full (as far as this lane has seen): the next one, all of them once
@@ -1189,6 +1186,9 @@ __device__ __forceinline__ uint32_t light_pool_take(uint32_t bitmap_off, uint32_
     cur = old | (1u << b);
   }
 }
+// 16-bit multiplicative hash of a seed; scaled to a word count by a 24-bit multiply (full-rate arithmetic: the round-4 form
+// took `hash % words` — ~20 instructions of emulated division, five of them quarter-rate multiplies)
+__device__ __forceinline__ uint32_t light_pool_hash(uint32_t seed) { return __umul24(seed & 0xFFFFu, 0x9E3Bu) & 0xFFFFu; }
 __device__ __forceinline__ void light_pool_give(uint32_t bitmap_off, uint32_t slot) {  // (after the last read of the record)
   uint32_t* const bitmap = reinterpret_cast<uint32_t*>(rt_lds_dyn + bitmap_off);
   __hip_atomic_fetch_and(&bitmap[slot >> 5], ~(1u << (slot & 31u)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1335,26 +1335,33 @@ template <class LaneT>
 RT_HD bool lane_light_begin(const DevScene& sc, LaneT& L, bool light_ray) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (LaneT::kPooled) {
-    const uint32_t seed = L.ra.pixel + L.ra.sample + L.node;
-    uint32_t base_slot = 0xFFFFFFFFu;
-    if constexpr (LaneT::kSimple) {
-      if (!light_ray && (L.in_light >> 16) == 0u) {
-        // (a base per lane fits — small scenes, the reference's test_scene: the lane's own, no bitmap; wave-uniform test)
-        if (sc.light_base_slots == (uint32_t)RT_BLOCK) base_slot = threadIdx.x;
-        else {
-          base_slot = light_pool_take(LIGHT_BASE_BITMAP_LDS_OFF, sc.light_base_slots, seed);
-          if (base_slot == 0xFFFFFFFFu) return false;
-        }
-      }
+    const uint32_t h = light_pool_hash(L.ra.pixel + L.ra.sample + L.node);
+    uint32_t* const fbits = reinterpret_cast<uint32_t*>(rt_lds_dyn + LIGHT_POOL_LDS_OFF);
+    uint32_t* const bbits = reinterpret_cast<uint32_t*>(rt_lds_dyn + LIGHT_BASE_BITMAP_LDS_OFF);
+    const uint32_t fwords = sc.light_pool_slots >> 5, bwords = sc.light_base_slots >> 5;
+    const bool direct_base = sc.light_base_slots == (uint32_t)RT_BLOCK;  // (a base per lane fits — small scenes, the reference's test_scene: the lane's own, no bitmap)
+    bool want_base = false;
+    if constexpr (LaneT::kSimple) want_base = !light_ray && (L.in_light >> 16) == 0u;
+    const bool pool_base = want_base && !direct_base;
+    const bool want_frame = !light_ray || sc.light_nest_pool != 0u;
+    const uint32_t wf = __umul24(h, fwords) >> 16, wb = __umul24(h, bwords) >> 16;
+    // (The two takes one after the other.  Overlapped — both bitmap words loaded together, both bits claimed back to back: two
+    //  dependent LDS round trips instead of four — was built and measured: lit cover 4.465 against 4.483 ms, the reference's
+    //  test scene 0.936 against 0.930, and one spilled register in the path loop: not adopted, profiles/r05_run6_ab_takes_and_flush.log.)
+    uint32_t base_slot = 0xFFFFFFFFu, slot = 0xFFFFFFFFu;
+    if (pool_base) {
+      base_slot = light_pool_take(bbits, bwords, wb);
+      if (base_slot == 0xFFFFFFFFu) return false;
     }
-    const uint32_t slot = (!light_ray || sc.light_nest_pool != 0u) ? light_pool_take(LIGHT_POOL_LDS_OFF, sc.light_pool_slots, seed) : 0xFFFFFFFFu;
+    if (want_frame) slot = light_pool_take(fbits, fwords, wf);
+    if (want_base && direct_base) base_slot = threadIdx.x;
     const uint32_t nw = light_frames_lds_off(sc.light_base_slots) + __umul24(slot, (uint32_t)sizeof(LightParked));
     if (!light_ray) {
       if (slot == 0xFFFFFFFFu) {
-        if (base_slot != 0xFFFFFFFFu && sc.light_base_slots != (uint32_t)RT_BLOCK) light_pool_give(LIGHT_BASE_BITMAP_LDS_OFF, base_slot);
+        if (pool_base) light_pool_give(LIGHT_BASE_BITMAP_LDS_OFF, base_slot);
         return false;
       }
-      if (base_slot != 0xFFFFFFFFu) L.in_light |= (base_slot + 1u) << 16;
+      if (want_base) L.in_light |= (base_slot + 1u) << 16;
       L.ls.wt = nw;  // (nesting level 0)
       return true;
     }

@@ -31,6 +31,9 @@ int fail(int code, const std::string& m) { g_err = m; return code; }
 
 }  // namespace
 
+struct RtHipScene;
+namespace { int warm_up(RtHipScene* s); }
+
 constexpr uint32_t RT_TIMELINE_WAVES = 8192;  // profile builds: {start, end} wall clock per wave behind the counters
 
 struct RtHipScene {
@@ -243,6 +246,10 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   // The frames run on the CALLER's streams, and a non-blocking stream does not order itself behind the NULL stream: a first
   // frame launched right away could start before the tables had landed, or have its tile-queue cursor zeroed under it
   // (round 4: the group launches rank 0 from the creating thread at once — 65 % of fresh 3-rank groups traced tiles twice).
+  // ... and nothing a first frame should pay for is left for it: the code object on the device, the default configuration's
+  // kernel attribute / occupancy / (lit scenes) overflow slots (a one-shot rt_render_rgb8 — the reference renders one frame per
+  // process — reports this under setup_ms, outside its frame_ms window)
+  if ((rc = warm_up(s)) != RT_OK) return bail(rc);
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(RT_ERR_HIP, "hipDeviceSynchronize failed"));
   *out = s;
   return RT_OK;
@@ -274,10 +281,14 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
 
 namespace {
 
+// Everything a launch needs that is NOT the launch: the kernel's dynamic-LDS attribute and its occupancy (worked out once per
+// configuration: two runtime calls a frame otherwise) and, lit kernels, the lanes' HBM overflow slots.  Runs BEFORE the
+// launch's start event is recorded — a first frame used to carry the 147 MB hipMalloc of a lit scene and the runtime's
+// first look at the kernel inside its kernel_ms (one-shot CLI frames: 8.4 ms for a 0.9 ms kernel, profiles/r05_run5_cli_stats_before_warmup.log)
+// — and once at scene creation for the scene's default configuration (warm_up).
 template <bool HL, bool SIMPLE, bool LDS>
-int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka_in, size_t lds_bytes, uint32_t n_items, hipStream_t stream) {
+int prepare_grid_t(RtHipScene* s, size_t lds_bytes, hipStream_t stream) {
   auto kern = rtk::rt_megakernel<HL, SIMPLE, LDS>;
-  // the launch configuration of this scene's kernel is worked out once (it costs two runtime calls a frame otherwise)
   const int key = (HL ? 4 : 0) | (SIMPLE ? 2 : 0) | (LDS ? 1 : 0);
   if (s->cfg_key != key || s->cfg_lds != lds_bytes) {
     if (lds_bytes > 48 * 1024) RT_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -286,27 +297,108 @@ int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka_in, size_t lds_bytes, uint
     if (per_cu_q < 1) return fail(RT_ERR_HIP, "megakernel does not fit on a CU");
     s->cfg_key = key; s->cfg_lds = lds_bytes; s->cfg_per_cu = per_cu_q;
   }
-  const int per_cu = s->cfg_per_cu;
-  // persistent: exactly the resident set, never more workgroups than there are wave-sized items
-  uint32_t wgs = (uint32_t)per_cu * (uint32_t)s->num_cus;
-  const uint32_t need = (n_items + rtk::WAVES - 1) / rtk::WAVES;
-  if (wgs > need) wgs = need;
-  s->last_waves = (uint64_t)wgs * rtk::WAVES;
-  rtk::KArgs ka = ka_in;
-  if (HL) {  // the lanes' overflow slots for suspended light activations (rt_core.h lane_light_begin): sized for this launch, kept
-    const size_t need_bytes = (size_t)wgs * rtk::BLOCK * rtc::LIGHT_OVERFLOW_BYTES_PER_LANE;
+  if (HL) {  // the lanes' overflow slots for suspended light activations (rt_core.h lane_light_begin): for the resident set, kept
+    const size_t need_bytes = (size_t)s->cfg_per_cu * (size_t)s->num_cus * rtk::BLOCK * rtc::LIGHT_OVERFLOW_BYTES_PER_LANE;
     if (need_bytes > s->light_overflow_bytes) {
-      // (an earlier launch of this scene may still be running on this stream with the old buffer: drain it first — once per scene
-      //  and launch size, never in a frame loop)
+      // (an earlier launch of this scene may still be running on this stream with the old buffer: drain it first — once per
+      //  scene and configuration, never in a frame loop)
       if (s->d_light_overflow) { RT_HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(s->d_light_overflow); s->d_light_overflow = nullptr; s->light_overflow_bytes = 0; }
       RT_HIP_TRY(hipMalloc(&s->d_light_overflow, need_bytes));
       s->light_overflow_bytes = need_bytes;
     }
-    ka.sc.light_overflow = (unsigned char*)s->d_light_overflow;
   }
+  return RT_OK;
+}
+template <bool HL, bool SIMPLE, bool LDS>
+int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka_in, size_t lds_bytes, uint32_t n_items, hipStream_t stream) {
+  auto kern = rtk::rt_megakernel<HL, SIMPLE, LDS>;
+  // persistent: exactly the resident set, never more workgroups than there are wave-sized items
+  uint32_t wgs = (uint32_t)s->cfg_per_cu * (uint32_t)s->num_cus;
+  const uint32_t need = (n_items + rtk::WAVES - 1) / rtk::WAVES;
+  if (wgs > need) wgs = need;
+  s->last_waves = (uint64_t)wgs * rtk::WAVES;
+  rtk::KArgs ka = ka_in;
+  if (HL) ka.sc.light_overflow = (unsigned char*)s->d_light_overflow;
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(rtk::BLOCK), lds_bytes, stream, ka);
   return RT_OK;
 }
+// (lights, every albedo in [0, 1], tables in LDS) -> the instantiation's prepare / launch
+int dispatch_grid(RtHipScene* s, bool has_lights, bool lds_tables, bool prepare_only, const rtk::KArgs* ka, size_t lds_bytes, uint32_t n_items, hipStream_t stream) {
+  int rc;
+#define RT_GO(HL, SIMPLE, LDS) rc = prepare_only ? prepare_grid_t<HL, SIMPLE, LDS>(s, lds_bytes, stream) : launch_grid_t<HL, SIMPLE, LDS>(s, *ka, lds_bytes, n_items, stream)
+  const bool simple = s->simple_colour;
+  if (has_lights) {
+    if (lds_tables) { if (simple) RT_GO(true, true, true); else RT_GO(true, false, true); }
+    else { if (simple) RT_GO(true, true, false); else RT_GO(true, false, false); }
+  } else if (lds_tables) { if (simple) RT_GO(false, true, true); else RT_GO(false, false, true); }
+  else { if (simple) RT_GO(false, true, false); else RT_GO(false, false, false); }
+#undef RT_GO
+  return rc;
+}
+
+// LDS budget of a launch: do the tables fit, how big are the light pools, how much dynamic LDS does a workgroup ask for.
+struct LdsPlan { bool lds_tables = false; uint32_t pool_slots = 0, base_slots = 0; size_t lds_bytes = 0; };
+int plan_lds(const RtHipScene* s, const rtc::GridDesc& G, bool has_lights, LdsPlan* out) {
+  // LDS budget.  Tables + tile slots + (lit scenes) the two pools of light records (rt_core.h): frames — held by a lane while
+  // it sums over the lights — and, with the short colour map, bases — held from a sample's first light sampling to its end.
+  // Expected demand: a camera path starts summing over the n lights with probability ~0.1 n at each of its first two hits
+  // (raytracer.rs:92-102) and then shoots n light rays, so about f = 0.2 n^2 / (2.9 + 0.2 n^2) of the lanes hold a frame at
+  // any moment (n = 1: 6.5 % = 66 of 1024 lanes; n = 2: 22 %; n = 3: 38 %) and about b = 0.2 n (n + 2) / (2.9 + 0.2 n^2) a
+  // base (n = 1: 19 %).  A lane that finds a pool exhausted repeats its segment, so undersized pools are slow, never wrong
+  // (forced pools of 64 / 32 frames on the lit cover scene: +1 % / +64 %, profiles/r03_run*_lit.log).  The pools get what is
+  // left beside the tables, in the proportion of their demands, up to one record per lane; if that is less than 1.2 x the
+  // demand the TABLES stay in L2 instead and the pools take their room.
+  const bool short_map = has_lights && s->simple_colour;
+  uint32_t pool_slots = 0, base_slots = 0;
+  auto size_pools = [&](size_t avail, double* margin) {  // largest x with frames = x f 1024, bases = x b 1024 (multiples of 32, 32 .. 1024) inside `avail`
+    const double n = (double)s->dev.n_lights, den = 2.9 + 0.2 * n * n;
+    const double f = std::max(0.2 * n * n / den, 1.0 / 64.0), b = short_map ? std::min(1.0, std::max(0.2 * n * (n + 2.0) / den, 1.0 / 64.0)) : 0.0;
+    auto slots = [&](double x, double share) -> uint32_t {
+      if (share == 0.0) return 0u;
+      const double v = x * share * (double)rtk::BLOCK;
+      const uint32_t q = v >= (double)rtc::LIGHT_POOL_MAX_SLOTS ? rtc::LIGHT_POOL_MAX_SLOTS : ((uint32_t)v & ~31u);
+      return q < 32u ? 32u : q;
+    };
+    auto bytes = [&](double x) { return (size_t)((rtk::park_bytes(slots(x, f), slots(x, b)) + 15u) & ~15u); };
+    double lo = 0.0, hi = 1.0 / std::min(f, b > 0.0 ? b : f) + 1.0;  // at `hi` both pools hold one record per lane
+    if (bytes(hi) <= avail) lo = hi;
+    else for (int it = 0; it < 40; ++it) { const double mid = 0.5 * (lo + hi); if (bytes(mid) <= avail) lo = mid; else hi = mid; }
+    pool_slots = slots(lo, f); base_slots = slots(lo, b);
+    const bool forced_f = s->light_pool_cap > 0, forced_b = s->light_base_cap > 0;  // (tests: small pools on purpose)
+    if (forced_f && pool_slots > (uint32_t)s->light_pool_cap) pool_slots = (uint32_t)s->light_pool_cap & ~31u;
+    if (forced_b && base_slots > (uint32_t)s->light_base_cap) base_slots = (uint32_t)s->light_base_cap & ~31u;
+    if (margin) *margin = (forced_f || forced_b) ? 1e9 : std::min((double)pool_slots / (f * rtk::BLOCK), b > 0.0 ? (double)base_slots / (b * rtk::BLOCK) : 1e9);
+    return bytes(0.0) <= avail;  // (the smallest pools fit)
+  };
+  const rtk::LdsLayout no_pools = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, false);
+  bool lds_tables = no_pools.total <= rtk::LDS_TABLES_MAX_BYTES;
+  if (has_lights) {
+    const size_t fixed = rtc::LIGHT_CENTRES_LDS_MAX * 24u;
+    double margin = 0.0;
+    bool ok = lds_tables && no_pools.total + fixed < s->lds_cap && size_pools(s->lds_cap - no_pools.total - fixed, &margin) && margin >= 1.2;
+    if (!ok) {
+      lds_tables = false;
+      const size_t bare = rtk::lds_layout(0, 0, 0, false, false).total + fixed;
+      if (!size_pools(s->lds_cap - bare, nullptr)) return fail(RT_ERR_UNSUPPORTED, "no room for the light pools in LDS");
+    }
+  }
+  out->lds_tables = lds_tables; out->pool_slots = pool_slots; out->base_slots = base_slots;
+  out->lds_bytes = lds_tables ? rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, has_lights, pool_slots, base_slots).total
+                              : rtk::lds_layout(0, 0, 0, false, has_lights, pool_slots, base_slots).total;
+  return RT_OK;
+}
+
+int warm_up(RtHipScene* s) {
+  // (keeping every CU busy for 0.5 - 20 ms here does NOT make a first frame faster — it is not the clocks:
+  //  profiles/r05_run7_cli_warm_spin.log)
+  hipLaunchKernelGGL(rtk::rt_warm_up, dim3(1), dim3(64), 0, nullptr);
+  RT_HIP_TRY(hipGetLastError());
+  LdsPlan plan;
+  const int rc = plan_lds(s, s->dev.grid, s->has_lights, &plan);
+  if (rc != RT_OK) return rc;
+  return dispatch_grid(s, s->has_lights, plan.lds_tables, true, nullptr, plan.lds_bytes, 0, nullptr);
+}
+
 }  // namespace
 
 extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb8, void* d_linear, void* stream_) {
@@ -426,58 +518,15 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
 #ifdef RT_DEV_KNOBS
   if (const char* e = std::getenv("RT_BATCH_SHARE")) { const int v = std::atoi(e); if (v >= 1 && v <= 1024) ka.batch_share = (uint32_t)v; }
 #endif
-  // LDS budget.  Tables + tile slots + (lit scenes) the two pools of light records (rt_core.h): frames — held by a lane while
-  // it sums over the lights — and, with the short colour map, bases — held from a sample's first light sampling to its end.
-  // Expected demand: a camera path starts summing over the n lights with probability ~0.1 n at each of its first two hits
-  // (raytracer.rs:92-102) and then shoots n light rays, so about f = 0.2 n^2 / (2.9 + 0.2 n^2) of the lanes hold a frame at
-  // any moment (n = 1: 6.5 % = 66 of 1024 lanes; n = 2: 22 %; n = 3: 38 %) and about b = 0.2 n (n + 2) / (2.9 + 0.2 n^2) a
-  // base (n = 1: 19 %).  A lane that finds a pool exhausted repeats its segment, so undersized pools are slow, never wrong
-  // (forced pools of 64 / 32 frames on the lit cover scene: +1 % / +64 %, profiles/r03_run*_lit.log).  The pools get what is
-  // left beside the tables, in the proportion of their demands, up to one record per lane; if that is less than 1.2 x the
-  // demand the TABLES stay in L2 instead and the pools take their room.
-  const rtc::GridDesc& G = ka.sc.grid;
-  const bool short_map = has_lights && s->simple_colour;
-  uint32_t pool_slots = 0, base_slots = 0;
-  auto size_pools = [&](size_t avail, double* margin) {  // largest x with frames = x f 1024, bases = x b 1024 (multiples of 32, 32 .. 1024) inside `avail`
-    const double n = (double)s->dev.n_lights, den = 2.9 + 0.2 * n * n;
-    const double f = std::max(0.2 * n * n / den, 1.0 / 64.0), b = short_map ? std::min(1.0, std::max(0.2 * n * (n + 2.0) / den, 1.0 / 64.0)) : 0.0;
-    auto slots = [&](double x, double share) -> uint32_t {
-      if (share == 0.0) return 0u;
-      const double v = x * share * (double)rtk::BLOCK;
-      const uint32_t q = v >= (double)rtc::LIGHT_POOL_MAX_SLOTS ? rtc::LIGHT_POOL_MAX_SLOTS : ((uint32_t)v & ~31u);
-      return q < 32u ? 32u : q;
-    };
-    auto bytes = [&](double x) { return (size_t)((rtk::park_bytes(slots(x, f), slots(x, b)) + 15u) & ~15u); };
-    double lo = 0.0, hi = 1.0 / std::min(f, b > 0.0 ? b : f) + 1.0;  // at `hi` both pools hold one record per lane
-    if (bytes(hi) <= avail) lo = hi;
-    else for (int it = 0; it < 40; ++it) { const double mid = 0.5 * (lo + hi); if (bytes(mid) <= avail) lo = mid; else hi = mid; }
-    pool_slots = slots(lo, f); base_slots = slots(lo, b);
-    const bool forced_f = s->light_pool_cap > 0, forced_b = s->light_base_cap > 0;  // (tests: small pools on purpose)
-    if (forced_f && pool_slots > (uint32_t)s->light_pool_cap) pool_slots = (uint32_t)s->light_pool_cap & ~31u;
-    if (forced_b && base_slots > (uint32_t)s->light_base_cap) base_slots = (uint32_t)s->light_base_cap & ~31u;
-    if (margin) *margin = (forced_f || forced_b) ? 1e9 : std::min((double)pool_slots / (f * rtk::BLOCK), b > 0.0 ? (double)base_slots / (b * rtk::BLOCK) : 1e9);
-    return bytes(0.0) <= avail;  // (the smallest pools fit)
-  };
-  const rtk::LdsLayout no_pools = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, false);
-  bool lds_tables = no_pools.total <= rtk::LDS_TABLES_MAX_BYTES;
-  if (has_lights) {
-    const size_t fixed = rtc::LIGHT_CENTRES_LDS_MAX * 24u;
-    double margin = 0.0;
-    bool ok = lds_tables && no_pools.total + fixed < s->lds_cap && size_pools(s->lds_cap - no_pools.total - fixed, &margin) && margin >= 1.2;
-    if (!ok) {
-      lds_tables = false;
-      const size_t bare = rtk::lds_layout(0, 0, 0, false, false).total + fixed;
-      if (!size_pools(s->lds_cap - bare, nullptr)) return fail(RT_ERR_UNSUPPORTED, "no room for the light pools in LDS");
-    }
-  }
-  ka.sc.light_pool_slots = pool_slots;
-  ka.sc.light_base_slots = base_slots;
+  LdsPlan plan;
+  { const int rc_plan = plan_lds(s, ka.sc.grid, has_lights, &plan); if (rc_plan != RT_OK) return rc_plan; }
+  const bool lds_tables = plan.lds_tables;
+  const size_t lds_bytes = plan.lds_bytes;
+  ka.sc.light_pool_slots = plan.pool_slots;
+  ka.sc.light_base_slots = plan.base_slots;
   ka.sc.light_nest_pool = (uint32_t)s->light_nest_pool;
   ka.sc.light_overflow = nullptr;  // (launch_grid_t fills it in for the lit kernels)
-  s->last_pool_slots = pool_slots; s->last_base_slots = base_slots; s->last_lds_tables = lds_tables;
-  const size_t lds_bytes = lds_tables ? rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, has_lights, pool_slots, base_slots).total
-                                      : rtk::lds_layout(0, 0, 0, false, has_lights, pool_slots, base_slots).total;
-  s->last_lds_bytes = lds_bytes;
+  s->last_pool_slots = plan.pool_slots; s->last_base_slots = plan.base_slots; s->last_lds_tables = lds_tables; s->last_lds_bytes = lds_bytes;
 
   // queue order: bottom of the image first; from the second frame of a tile geometry on, the tiles whose samples ran
   // deepest in the previous frame first (their paths are what a frame ends on)
@@ -528,21 +577,13 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   }
 
   int rc;
-  // instantiation = (lights, every albedo in [0, 1], tables in LDS)
   auto launch = [&](const rtk::KArgs& ka, uint32_t n_items) -> int {
-    int rc;
-#define RT_GO(HL, SIMPLE, LDS) rc = launch_grid_t<HL, SIMPLE, LDS>(s, ka, lds_bytes, n_items, stream)
-    const bool simple = s->simple_colour;
-    if (has_lights) {
-      if (lds_tables) { if (simple) RT_GO(true, true, true); else RT_GO(true, false, true); }
-      else { if (simple) RT_GO(true, true, false); else RT_GO(true, false, false); }
-    } else if (lds_tables) { if (simple) RT_GO(false, true, true); else RT_GO(false, false, true); }
-    else { if (simple) RT_GO(false, true, false); else RT_GO(false, false, false); }
-#undef RT_GO
+    const int rc = dispatch_grid(s, has_lights, lds_tables, false, &ka, lds_bytes, n_items, stream);
     if (rc != RT_OK) return rc;
     RT_HIP_TRY(hipGetLastError());
     return RT_OK;
   };
+  if ((rc = dispatch_grid(s, has_lights, lds_tables, true, nullptr, lds_bytes, 0, stream)) != RT_OK) return rc;  // (host-side set-up: before the start event)
   auto sort_tiles = [&]() -> int {
     hipLaunchKernelGGL(rtk::rt_order_tiles, dim3(1), dim3(1024), 0, stream, (const uint32_t*)s->d_tile_depth, s->d_tile_order, ka.n_tiles, ka.aff_group_log2);
     RT_HIP_TRY(hipGetLastError());
@@ -689,6 +730,28 @@ extern "C" int rt_hip_render_to_host(RtHipScene* s, uint8_t* out_rgb8, RtStats* 
     stats->frame_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
   return RT_OK;
+}
+
+// The scene's own kernel through the stream its frames will use, once, on ONE scanline — whatever the runtime does with the first
+// launch of a kernel on a queue (its scratch, its kernarg pool, the instruction cache) happens here, at set-up, instead of inside
+// the first frame: the group calls it per rank.  The launch leaves no trace in the scene (slots, queue order, counters of the
+// "last launch" are as after creation).
+int rt_hip_scene_warm(RtHipScene* s, hipStream_t stream) {
+  if (!s || s->host.width == 0 || s->host.height == 0) return RT_OK;
+  RT_HIP_TRY(hipSetDevice(s->device));
+  void* row = nullptr;
+  RT_HIP_TRY(hipMalloc(&row, (size_t)s->host.width * 3 + 16));
+  const int saved_order = s->order_mode;
+  s->order_mode = 1;  // (nothing measured, nothing sorted)
+  const RtRowTiles first_row{1u, 0u, s->host.height};
+  int rc = rt_hip_render(s, &first_row, row, nullptr, stream);
+  if (rc == RT_OK) rc = rt_hip_wait(s, nullptr);
+  s->order_mode = saved_order;
+  s->n_launches = 0; s->in_flight = false; s->last_stream = nullptr; s->last_waves = 0;
+  s->order_key = RtHipScene::OrderKey(); s->order_ready = false; s->order_age = 0;
+  for (auto& sl : s->slot) { sl.rows = 0; sl.samples = 0; sl.waves = 0; sl.launched = false; }
+  (void)hipFree(row);
+  return rc;
 }
 
 #include "rt_hip_group.hip"  // rt_hip_group_* and rt_render_rgb8: the frame over 1..G devices

@@ -436,7 +436,12 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
                hipEventCreateWithFlags(&f.ev_sent[r], hipEventDisableTiming) == hipSuccess;
           if (ok && r != 0 && hipMalloc(&f.d_tiles[r], g->pad_bytes ? g->pad_bytes : 16) != hipSuccess) ok = false;
         }
-        if (!ok) { g->rc[r] = RT_ERR_HIP; g->err[r] = "hipStreamCreate / hipEventCreate / hipMalloc(tiles) failed"; }
+        if (!ok) { g->rc[r] = RT_ERR_HIP; g->err[r] = "hipStreamCreate / hipEventCreate / hipMalloc(tiles) failed"; return; }
+        // the rank's kernel once through the rank's own render stream (one scanline): the first frame finds a warm queue
+        if (!std::getenv("RT_NO_KERNEL_WARMUP")) {
+          g->rc[r] = rt_hip_scene_warm(g->scene[r], g->stream[r]);
+          if (g->rc[r] != RT_OK) g->err[r] = rt_hip_last_error();
+        }
       });
     for (auto& t : th) t.join();
     for (uint32_t r = 0; r < G; ++r)
@@ -555,6 +560,14 @@ void prepare_staging(RtHipGroup* g) {
   (void)hipSetDevice(g->device[0]);
   for (auto& f : g->frame)
     if (!f.h_stage && hipHostMalloc((void**)&f.h_stage, bytes, hipHostMallocDefault) != hipSuccess) { f.h_stage = nullptr; (void)hipGetLastError(); }
+  // ... and the copy path itself: the runtime sets its device-to-host machinery up with the first copy of a process (measured:
+  // the first hipMemcpyAsync of a one-shot frame kept submit for ~8 ms — seven times the reference's test-scene kernel,
+  // profiles/r05_run7_cli_warm_spin.log): one copy of the frame's size through the frame's own stream and buffers, here
+  if (g->frame[0].h_stage && g->frame[0].d_frame && !std::getenv("RT_NO_COPY_WARMUP")) {
+    (void)hipMemcpyAsync(g->frame[0].h_stage, g->frame[0].d_frame, bytes, hipMemcpyDeviceToHost, g->xstream[0]);
+    (void)hipStreamSynchronize(g->xstream[0]);
+    (void)hipGetLastError();
+  }
 }
 
 // Enqueue one frame: G parallel launches, ONE gather, de-interleave, (optionally) ONE device-to-host copy.  Returns as
@@ -643,11 +656,16 @@ int group_submit(RtHipGroup* g, uint8_t* out_rgb8) {
       // goes into a pinned staging buffer of the group and collect moves it on.  A destination that is pinned itself is written directly.
       const size_t bytes = (size_t)g->height * g->row_bytes;
       uint8_t* dst = f.out;
-      if (bytes != 0 && !out_is_pinned(f.out)) {
+      static const bool trace = std::getenv("RT_GROUP_TRACE") != nullptr;  // (development: where a submit's host time goes)
+      const double t_a = trace ? us_since(f.t0) : 0.0;
+      const bool pinned_out = bytes != 0 && out_is_pinned(f.out);
+      const double t_b = trace ? us_since(f.t0) : 0.0;
+      if (bytes != 0 && !pinned_out) {
         if (!f.h_stage && hipHostMalloc((void**)&f.h_stage, bytes, hipHostMallocDefault) != hipSuccess) { f.h_stage = nullptr; (void)hipGetLastError(); }
         if (f.h_stage) { dst = f.h_stage; f.staged = true; }  // (no pinned memory to be had: the old, blocking copy)
       }
       if (bytes != 0) RT_HIP_TRY(hipMemcpyAsync(dst, f.d_frame, bytes, hipMemcpyDeviceToHost, x0));
+      if (trace) std::fprintf(stderr, "[rt group] submit: before pointer query %.1f us, after %.1f, after hipMemcpyAsync %.1f (staged %d)\n", t_a, t_b, us_since(f.t0), (int)f.staged);
     }
     RT_HIP_TRY(hipEventRecord(f.ev_final, x0));
     return RT_OK;

@@ -442,10 +442,10 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     if (packed) {
       const uint32_t nxt = (uint32_t)__shfl_down((int)rgb, 1);
       uint32_t i = lane & 3u;
-      // (made here: hoisted out of the path loop, i, 8 i, 24 - 8 i and a zero-extended copy hold four registers for good — spilled
-      //  in the lit kernels and with the general colour map; the unlit short-map kernel has them to spare and is 0.6 % faster with
-      //  the hoisted form, profiles/r05_run1_ab_lit.log)
-      if constexpr (HL || !SIMPLE) asm volatile("" : "+v"(i));
+      // (made HERE: hoisted out of the path loop, i, 8 i, 24 - 8 i and a zero-extended copy hold four registers for good — spilled in
+      //  the lit kernels and with the general colour map: <lights=0, simple=0> 12 -> 0 spilled registers.  The unlit short-map
+      //  kernel has them to spare; measured both ways three times, it is 0.0 - 0.9 % faster with this form, profiles/r05_run6_ab_takes_and_flush.log)
+      asm volatile("" : "+v"(i));
       if (valid && i < 3u) *reinterpret_cast<uint32_t*>(ka.out_rgb8 + o + i) = (rgb >> (8u * i)) | (nxt << (24u - 8u * i));
     } else if (valid) {
       ka.out_rgb8[o] = (uint8_t)rgb; ka.out_rgb8[o + 1] = (uint8_t)(rgb >> 8); ka.out_rgb8[o + 2] = (uint8_t)(rgb >> 16);
@@ -949,6 +949,10 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     }
   }
 }
+
+// Launched once when a scene is created: the runtime loads a module's code object onto the device with the first launch of ANY
+// of its kernels — milliseconds that would otherwise sit inside the first frame.
+__global__ void rt_warm_up() {}
 
 // --------------------------------------------------------------------------- queue order for the next frame
 // tile_order <- the tiles sorted by descending tile_depth (counting sort over 64 depth buckets, one workgroup; the

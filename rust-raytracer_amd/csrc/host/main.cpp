@@ -221,10 +221,12 @@ int main(int argc, char** argv) {
     rt_scene_load_timings(sf, lt);
     std::fprintf(stderr, "{\"samples\":%llu,\"segments\":%llu,\"sphere_tests\":%llu,\"exact_tests\":%llu,\"n_gpus\":%u,\"kernel_ms\":%.3f,"
                          "\"gather_ms\":%.3f,\"frame_ms\":%.3f,\"setup_ms\":%.3f,\"msamples_per_s\":%.3f,"
-                         "\"load_ms\":%.3f,\"read_ms\":%.3f,\"json_ms\":%.3f,\"jpeg_ms\":%.3f,\"hip_init_ms\":%.3f,\"png_ms\":%.3f,\"main_ms\":%.3f}\n",
+                         "\"load_ms\":%.3f,\"read_ms\":%.3f,\"json_ms\":%.3f,\"jpeg_ms\":%.3f,\"hip_init_ms\":%.3f,\"png_ms\":%.3f,\"main_ms\":%.3f,"
+                         "\"group_us\":[%.1f,%.1f,%.1f,%.1f,%.1f,%.1f,%.1f,%.1f]}\n",
                  (unsigned long long)st.samples, (unsigned long long)st.segments, (unsigned long long)st.sphere_tests,
                  (unsigned long long)st.exact_tests, st.n_gpus_used, st.kernel_ms, st.gather_ms, st.frame_ms, st.setup_ms,
-                 st.samples / (st.kernel_ms * 1e3), load_done_ms, lt[0], lt[1], lt[2], hip_init_ms, png_ms, ms_since(t_main));
+                 st.samples / (st.kernel_ms * 1e3), load_done_ms, lt[0], lt[1], lt[2], hip_init_ms, png_ms, ms_since(t_main),
+                 st.group_us[0], st.group_us[1], st.group_us[2], st.group_us[3], st.group_us[4], st.group_us[5], st.group_us[6], st.group_us[7]);
   }
   rt_scene_free(sf);
   if (rc != RT_OK) {

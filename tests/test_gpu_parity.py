@@ -646,6 +646,34 @@ def test_full_size_cfg5_10k_spheres_4k(gpu_render, oracle, abi, host):
     print(f"cfg5 full size: {len(windows)} windows x 192 px x 2048 spp vs oracle (10 001 spheres brute force), max |dlin| {worst:.2e}")
 
 
+@pytest.mark.parametrize("radii", ["loguniform", "bimodal"])
+def test_mixed_radius_10k_sphere_worlds(gpu_render, oracle, abi, host, radii):
+    """SURVEY §8 f2 outside BASELINE's sphere distribution (round-4 verdict next #7): 10^4 spheres whose radii span two
+    decades — log-uniform in [0.05, 5], and 95 % r = 0.05 + 5 % r = 3.0 — on the configs[4] lattice stretched by 4
+    (scenes/procedural.py).  A single-level uniform grid is not made for these (a cell sized for the small spheres is crossed by
+    every big one): the table builder coarsens the grid and keeps the 8 biggest spheres in the `large` list.  The frame must be
+    the oracle's (brute force over all 10^4 spheres: pixel windows of scanlines at full spp) and the brute-force variant's
+    bit for bit; the speed number and the exact tests per segment are printed (the bench line carries them too)."""
+    import procedural
+    sc = host.Scene.loads(procedural.make_json(width=640, height=360, spp=32, half=50, seed=0, radii=radii))
+    assert 9900 < sc.c.n_spheres <= 10001
+    rgb, lin, st = gpu_render(sc)
+    assert st["grid_steps"] > 0 and st["exact_tests"] < 40 * st["segments"]
+    worst = 0.0
+    for y, x0 in ((20, 100), (120, 400), (200, 0), (250, 250), (300, 480), (359, 320)):
+        worst = max(worst, _check_rows_against_oracle(rgb, lin, oracle, abi, sc, (y,), 32, f"mixed radii {radii}", x_range=(x0, x0 + 160)))
+    small = host.Scene.loads(procedural.make_json(width=160, height=90, spp=4, half=50, seed=0, radii=radii))
+    g_rgb, g_lin, g_st = gpu_render(small, variant=0)
+    b_rgb, b_lin, b_st = gpu_render(small, variant=1)
+    assert np.array_equal(g_rgb, b_rgb) and np.array_equal(g_lin, b_lin) and g_st["segments"] == b_st["segments"]
+    big = host.Scene.loads(procedural.make_json(width=1920, height=1080, spp=128, half=50, seed=0, radii=radii))
+    ks = [gpu_render(big, want_linear=False)[2] for _ in range(2)]
+    k = min(x["kernel_ms"] for x in ks)
+    print(f"mixed radii {radii}: {sc.c.n_spheres} spheres, 6 windows vs oracle max |dlin| {worst:.2e}; 1920x1080 spp 128: {k:.1f} ms = {ks[0]['samples'] / k / 1e3:.0f} Msamples/s, "
+          f"segments/sample {ks[0]['segments'] / ks[0]['samples']:.2f}, exact tests/segment {ks[0]['exact_tests'] / ks[0]['segments']:.2f}, grid steps/segment {ks[0]['grid_steps'] / ks[0]['segments']:.2f}")
+    assert ks[0]["exact_tests"] / ks[0]["segments"] < 30.0     # (above 30 a second grid level for the medium spheres would be the next step: it is not)
+
+
 def _with_env(env, fn):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
