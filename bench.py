@@ -379,6 +379,12 @@ def run_ranks(args):
         args.gpus = world
     if not torch.cuda.is_available():
         raise BenchError("bench.py needs a GPU: the hot path has no CPU fallback")
+    n_visible = torch.cuda.device_count()
+    if local_rank >= n_visible:   # (a launcher that narrows HIP_VISIBLE_DEVICES per rank leaves every rank ONE device, ordinal 0)
+        if n_visible == 1:
+            local_rank = 0
+        else:
+            raise BenchError(f"LOCAL_RANK {local_rank} but {n_visible} device(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # RT_BENCH_FORCE_COLLECTIVE=1: a one-rank RCCL group still goes through init / gather / barrier — the N > 1
@@ -431,7 +437,10 @@ def run_ranks(args):
         gathered = [None] * world
         dist.all_gather_object(gathered, place)
         ranks_devices = gathered
-        assert len({(g["host"], g["uuid"], g["pci_bus_id"], g["local_rank"]) for g in gathered}) == world, f"ranks share a device: {gathered}"
+        shared = len({(g["host"], g["uuid"], g["pci_bus_id"], g["local_rank"]) for g in gathered}) != world
+        # (RT_BENCH_ALLOW_SHARED_DEVICE=1: a functional run of the process-per-GPU path with the ranks on ONE GPU — tests; the line says so)
+        if shared and os.environ.get("RT_BENCH_ALLOW_SHARED_DEVICE") != "1":
+            raise BenchError(f"ranks share a device: {gathered}")
 
     def fence():
         if collective:
@@ -578,6 +587,7 @@ def run_ranks(args):
             out["rccl_ranks"] = dist.get_world_size() if transport == "rccl" else 0
             out["visible_gpus"] = torch.cuda.device_count()
             out["rank_devices"] = [f"{g['host']}:{g['pci_bus_id'] or g['local_rank']}" for g in ranks_devices]
+            out["ranks_share_devices"] = len(set(out["rank_devices"])) != len(out["rank_devices"])   # (True only under RT_BENCH_ALLOW_SHARED_DEVICE=1: a functional check, not a scaling number)
             out["transport"] = transport
             out["transport_fallback"] = transport != "rccl"
             out["transport_fallback_reason"] = transport_note or None

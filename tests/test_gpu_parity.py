@@ -1004,6 +1004,35 @@ def test_frame_pipeline_through_rccl_one_rank(tmp_path):
     assert r.returncode == 0 and "RCCL_PIPELINE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+def test_bench_process_per_gpu_with_two_ranks_on_this_gpu():
+    """What the driver's scaling run launches — `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` — with N = 2
+    REAL processes on this box's one GPU (RT_BENCH_ALLOW_SHARED_DEVICE=1; RCCL refuses two ranks on one device, so the tiles
+    take the host-staged gloo route — the fall-back the run would take on a node whose RCCL does not come up): every line of
+    the world > 1 branch runs on a GPU — rendezvous, shards, the pipelined gathers, the blocking-frame latency, rank 0's N = 1
+    reference, the reductions, the per-rank arrays — and rank 0 prints ONE line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RT_BENCH_ALLOW_SHARED_DEVICE="1", RT_BENCH_FORCE_TRANSPORT="gloo")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "strong" and "error" not in d
+    assert d["transport"] == "gloo-host" and d["transport_fallback"] is True and d["ranks_share_devices"] is True
+    pr = d["per_rank"]
+    assert len(pr["kernel_ms"]) == 2 and min(pr["kernel_ms"]) > 0 and abs(sum(pr["samples_share"]) - 1.0) < 1e-3
+    samples = 1200 * 800 * 128
+    assert abs(d["value"] - samples / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * d["value"]
+    assert d["n1_kernel_ms"] > 0 and d["frame_latency_ms"] > 0 and d["segments_per_sample"] > 2.0
+    print(f"two ranks on one GPU (gloo-host): {d['value']:.0f} Msamples/s, {d['ms_per_step']:.2f} ms/step, per-rank kernel {pr['kernel_ms']}, frame latency {d['frame_latency_ms']:.2f} ms")
+
+
 def test_device_sphere_hit_matches_oracle_and_host_build(pkg, hostsim, oracle, abi, torch_cuda):
     """Sphere::hit pair by pair on the device (the kernel's own exact_hit_any_order) against the ORACLE's
     restatement of sphere.rs:46-78 (rt_oracle_sphere_hit) and against the CPU build of the kernel source: random pairs, rays tangent to the sphere (discriminant exactly 0 or in

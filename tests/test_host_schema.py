@@ -288,3 +288,27 @@ def test_unsupported_jpeg_kinds_say_so(host, abi):
     with pytest.raises(host.RtError) as e:
         host.jpeg_decode_mem(bytes(bad))
     assert e.value.code == abi.RT_ERR_TEXTURE and "SOF9" in str(e.value)
+
+
+def test_scene_load_timings(host, abi):
+    """rt_scene_load_timings: where a load went (read, JSON parse, longest JPEG decode, total) — what the CLI prints under
+    RT_STATS=1 and bench.py's `cli` object quotes.  The test scene decodes three JPEGs concurrently beside the parse."""
+    import ctypes as C
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    L = host.lib()
+    L.rt_scene_load_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.rt_scene_load_timings.restype = None
+    for path, wants_jpeg in ((os.path.join(root, "scenes", "cfg1_test_800x600_spp16.json"), True), (os.path.join(root, "scenes", "cfg2_cover_1200x800_spp128.json"), False)):
+        cwd = os.getcwd()
+        os.chdir(root)    # (texture paths resolve relative to the working directory, like the reference's)
+        try:
+            sc = host.Scene.load(path)
+        finally:
+            os.chdir(cwd)
+        out = (C.c_double * 4)()
+        L.rt_scene_load_timings(sc._h, out)
+        read_ms, json_ms, jpeg_ms, total_ms = list(out)
+        assert read_ms > 0 and json_ms > 0 and total_ms >= json_ms and total_ms >= jpeg_ms
+        assert (jpeg_ms > 1.0) == wants_jpeg, (path, jpeg_ms)
+        assert total_ms < 5000
