@@ -626,9 +626,17 @@ def run_ranks(args):
                                  "FIRST frame (what a one-shot rt_render_rgb8 gets): bottom row first; the measured order knows which tiles hold this seed's rare 50-segment paths, which no seed predicts (DESIGN.md §4.1)")
             out["git_head"] = _git_head()
         if world == 1 and headline and not args.no_other_configs:
-            out["other_configs"] = other_configs(pkg, torch, dev, stream)
-            out["mixed_radius_worlds"] = mixed_radius_worlds(pkg, torch, dev, stream)
-            out["cli"] = cli_wall_times()
+            # (the extras must never cost the line: whatever goes wrong in one of them is reported in its place)
+            def extra(fn, *a):
+                try:
+                    return fn(*a)
+                except BaseException as e:   # noqa: BLE001
+                    if isinstance(e, KeyboardInterrupt):
+                        raise
+                    return {"error": f"{type(e).__name__}: {e}"[:300]}
+            out["other_configs"] = extra(other_configs, pkg, torch, dev, stream)
+            out["mixed_radius_worlds"] = extra(mixed_radius_worlds, pkg, torch, dev, stream)
+            out["cli"] = extra(cli_wall_times)
         if world == 1 and not args.no_cpu_baseline:
             oracle = graft.load_oracle()
             cores = oracle.lib(abi).rt_oracle_threads()

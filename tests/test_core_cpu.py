@@ -552,3 +552,22 @@ def test_light_draw_words_and_the_open_high_word(hostsim, oracle, abi, host):
         assert_parity(rgb, lin, o_rgb, o_lin, f"seed {seed}")
         assert st["segments"] == o_st["segments"] - o_st["segments_discarded"]
     assert len(set(ldc.OPEN_SEEDS.values())) == 2
+
+
+def test_light_pool_index_arithmetic():
+    """The device's light pools (rt_core.h, round 5) use full-rate integer arithmetic where a division would be: the index of
+    the frame record at an LDS offset — (offset - first record) / 80 as ((x >> 4) * 13108) >> 16, exact because offsets are
+    multiples of 16 and (y * ceil(2^16 / 5)) >> 16 == y // 5 for y < 2^14 — and the start word of a bitmap search —
+    (16-bit hash * words) >> 16, which must land inside the bitmap for every word count a pool can have."""
+    y = np.arange(0, 1 << 14, dtype=np.uint64)
+    assert np.array_equal((y * 13108) >> 16, y // 5)
+    for base_slots in (0, 32, 288, 1024):
+        frames_off = 66592 + 256 + base_slots * 32          # any multiple of 16 does
+        slots = np.arange(0, 1024, dtype=np.uint64)
+        where = frames_off + slots * 80
+        assert (where % 16 == 0).all() and where.max() < (1 << 18)
+        assert np.array_equal((((where - frames_off) >> 4) * 13108) >> 16, slots)
+    h = np.arange(0, 1 << 16, dtype=np.uint64)
+    for words in range(1, 33):
+        w = (h * words) >> 16
+        assert w.min() == 0 and w.max() == words - 1

@@ -41,7 +41,9 @@ def main():
             gs.set_option("variant", variant)
             gs.set_option("tile_log2", [-1, 0, 1, 2, 3][seed % 5])
             gs.set_option("tile_batch", [0, 1, 2, 7, 64, 3, 0][seed % 7])       # tiles per queue atomic (the workgroup's stash)
-            gs.set_option("light_pool", [0, 32, 64, 0, 96, 0][seed % 6])   # lit worlds beyond the one-frame-per-lane budget: small pools force repeats
+            gs.set_option("light_pool", [0, 32, 64, 0, 96, 0][seed % 6])   # lit worlds: small frame pools force repeated segments and HBM overflows,
+            gs.set_option("light_base_pool", [0, 0, 32, 64, 0][seed % 5])   # small base pools repeats,
+            gs.set_option("light_nest_pool", [1, 1, 0][seed % 3])           # 0: every nested light activation through the HBM overflow
             rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
             lin = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
             gs.render(rgb.data_ptr(), lin.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
