@@ -170,8 +170,19 @@ int animate(RtSceneFile* sf, const char* prefix, int frames, double orbit_deg) {
 }
 }  // namespace
 
-int main(int argc, char** argv) {
+// The HIP runtime takes 50 - 200 ms to come up (its first call) — as long as the reference's three 2 - 3 MP JPEG textures take to
+// decode.  A thread makes that first call while the main thread reads and parses the scene (at 13 ms a frame the host
+// pipeline IS the wall time).
+std::thread g_hip_init;
+double g_hip_init_ms = 0.0;
+
+int run(int argc, char** argv) {
   const auto t_main = std::chrono::steady_clock::now();
+  g_hip_init = std::thread([]() {
+    const auto t0 = std::chrono::steady_clock::now();
+    (void)rt_hip_device_count();
+    g_hip_init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  });
   auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
   int frames = 0;
   double orbit = 0.0;
@@ -194,6 +205,7 @@ int main(int argc, char** argv) {
   RtScene* sc = rt_scene_get_mut(sf);
   if (const char* seed = std::getenv("RT_SEED")) sc->seed = std::strtoull(seed, nullptr, 0);
   if (frames > 0) {
+    if (g_hip_init.joinable()) g_hip_init.join();
     const int status = animate(sf, argv[2], frames, orbit_given ? orbit : 360.0 / frames);
     rt_scene_free(sf);
     return status;
@@ -204,8 +216,8 @@ int main(int argc, char** argv) {
   std::vector<uint8_t> pixels((size_t)sc->width * sc->height * 3);  // raytracer.rs:254
   RtStats st{};
   const auto t_hip = std::chrono::steady_clock::now();
-  (void)rt_hip_device_count();  // (the HIP runtime comes up with the first call into it: timed apart from the scene's own set-up)
-  const double hip_init_ms = ms_since(t_hip);
+  if (g_hip_init.joinable()) g_hip_init.join();  // (what of the runtime's start-up the load did not cover)
+  const double hip_wait_ms = ms_since(t_hip), hip_init_ms = g_hip_init_ms;
   rc = rt_render_rgb8(sc, pixels.data(), &st);
   if (rc != RT_OK) {
     std::fprintf(stderr, "render failed: %s: %s\n", rt_strerror(rc), rt_hip_last_error());
@@ -221,11 +233,11 @@ int main(int argc, char** argv) {
     rt_scene_load_timings(sf, lt);
     std::fprintf(stderr, "{\"samples\":%llu,\"segments\":%llu,\"sphere_tests\":%llu,\"exact_tests\":%llu,\"n_gpus\":%u,\"kernel_ms\":%.3f,"
                          "\"gather_ms\":%.3f,\"frame_ms\":%.3f,\"setup_ms\":%.3f,\"msamples_per_s\":%.3f,"
-                         "\"load_ms\":%.3f,\"read_ms\":%.3f,\"json_ms\":%.3f,\"jpeg_ms\":%.3f,\"hip_init_ms\":%.3f,\"png_ms\":%.3f,\"main_ms\":%.3f,"
+                         "\"load_ms\":%.3f,\"read_ms\":%.3f,\"json_ms\":%.3f,\"jpeg_ms\":%.3f,\"hip_init_ms\":%.3f,\"hip_wait_ms\":%.3f,\"png_ms\":%.3f,\"main_ms\":%.3f,"
                          "\"group_us\":[%.1f,%.1f,%.1f,%.1f,%.1f,%.1f,%.1f,%.1f]}\n",
                  (unsigned long long)st.samples, (unsigned long long)st.segments, (unsigned long long)st.sphere_tests,
                  (unsigned long long)st.exact_tests, st.n_gpus_used, st.kernel_ms, st.gather_ms, st.frame_ms, st.setup_ms,
-                 st.samples / (st.kernel_ms * 1e3), load_done_ms, lt[0], lt[1], lt[2], hip_init_ms, png_ms, ms_since(t_main),
+                 st.samples / (st.kernel_ms * 1e3), load_done_ms, lt[0], lt[1], lt[2], hip_init_ms, hip_wait_ms, png_ms, ms_since(t_main),
                  st.group_us[0], st.group_us[1], st.group_us[2], st.group_us[3], st.group_us[4], st.group_us[5], st.group_us[6], st.group_us[7]);
   }
   rt_scene_free(sf);
@@ -234,4 +246,17 @@ int main(int argc, char** argv) {
     return 101;
   }
   return 0;
+}
+
+// Everything the process owes the world is on disk or in the pipe when run() returns: stdout / stderr are flushed and the process
+// ends WITHOUT the HIP runtime's tear-down (static destructors: tens of milliseconds the reference's binary does not have).
+// RT_FAST_EXIT=0 takes the ordinary way out.
+int main(int argc, char** argv) {
+  const int status = run(argc, argv);
+  if (g_hip_init.joinable()) g_hip_init.join();
+  std::fflush(stdout);
+  std::fflush(stderr);
+  const char* fe = std::getenv("RT_FAST_EXIT");
+  if (!(fe && fe[0] == '0')) std::_Exit(status);
+  return status;
 }
