@@ -229,6 +229,10 @@ size_t rt_abi_sizeof(const char* struct_name);
 uint32_t rt_abi_version(void);
 
 int rt_hip_device_count(void);
+/* Bring the runtime up on `device` ahead of the first scene: its context, its queues, this library's code object — tens of
+ * milliseconds that rt_hip_scene_create otherwise pays for the first scene of a process.  Optional and idempotent; the CLI calls it
+ * on a thread while it reads the scene file. */
+int rt_hip_device_warm(int device);
 const char* rt_hip_last_error(void);
 /* Upload scene tables, textures and sky to HBM of `device`.  The caller may free the
  * RtScene and everything it points to as soon as this returns. */

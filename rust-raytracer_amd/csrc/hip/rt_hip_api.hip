@@ -139,6 +139,20 @@ extern "C" int rt_hip_device_count(void) {
   return n;
 }
 
+extern "C" int rt_hip_device_warm(int device) {
+  const int n = rt_hip_device_count();
+  if (n <= 0) return fail(RT_ERR_NO_DEVICE, rt_strerror(RT_ERR_NO_DEVICE));
+  if (device < 0 || device >= n) return fail(RT_ERR_INVALID, "device index out of range");
+  RT_HIP_TRY(hipSetDevice(device));
+  void* p = nullptr;
+  RT_HIP_TRY(hipMalloc(&p, 256));  // (the first allocation creates the device's context)
+  hipLaunchKernelGGL(rtk::rt_warm_up, dim3(1), dim3(64), 0, nullptr);  // (the first launch loads this library's code object)
+  RT_HIP_TRY(hipGetLastError());
+  RT_HIP_TRY(hipDeviceSynchronize());
+  (void)hipFree(p);
+  return RT_OK;
+}
+
 extern "C" void rt_hip_scene_destroy(RtHipScene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
@@ -169,10 +183,14 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   int n = rt_hip_device_count();
   if (n <= 0) return fail(RT_ERR_NO_DEVICE, rt_strerror(RT_ERR_NO_DEVICE));
   if (device < 0 || device >= n) return fail(RT_ERR_INVALID, "device index out of range");
+  static const bool trace = std::getenv("RT_GROUP_TRACE") != nullptr;  // (development: where a scene's creation time goes)
+  const auto t_create = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count(); };
   rtc::HostTables t;
   std::string why = rtc::build_tables(*scene, t);
   if (!why.empty()) return fail(RT_ERR_INVALID, why);
   rtc::build_texels(*scene, t);
+  const double t_tables = since();
   RT_HIP_TRY(hipSetDevice(device));
   RtHipScene* s = new RtHipScene;
   s->device = device;
@@ -249,8 +267,11 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   // ... and nothing a first frame should pay for is left for it: the code object on the device, the default configuration's
   // kernel attribute / occupancy / (lit scenes) overflow slots (a one-shot rt_render_rgb8 — the reference renders one frame per
   // process — reports this under setup_ms, outside its frame_ms window)
+  const double t_uploaded = since();
   if ((rc = warm_up(s)) != RT_OK) return bail(rc);
+  const double t_warm = since();
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(RT_ERR_HIP, "hipDeviceSynchronize failed"));
+  if (trace) std::fprintf(stderr, "[rt scene] create: tables %.2f ms, uploads + events done %.2f, warm_up (module, configuration, overflow) %.2f, device idle %.2f\n", t_tables, t_uploaded, t_warm, since());
   *out = s;
   return RT_OK;
 }

@@ -390,6 +390,7 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
   const bool emulate = emu && emu[0] == '1';
   if (G > (uint32_t)ndev && !emulate)
     return fail(RT_ERR_INVALID, "n_gpus = " + std::to_string(G) + " but only " + std::to_string(ndev) + " device(s) visible");
+  const auto t_group = std::chrono::steady_clock::now();
   RtHipGroup* g = new RtHipGroup;
   g->G = G; g->width = scene->width; g->height = scene->height;
   g->row_bytes = (size_t)scene->width * 3;
@@ -439,7 +440,9 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
         if (!ok) { g->rc[r] = RT_ERR_HIP; g->err[r] = "hipStreamCreate / hipEventCreate / hipMalloc(tiles) failed"; return; }
         // the rank's kernel once through the rank's own render stream (one scanline): the first frame finds a warm queue
         if (!std::getenv("RT_NO_KERNEL_WARMUP")) {
+          const auto tw = std::chrono::steady_clock::now();
           g->rc[r] = rt_hip_scene_warm(g->scene[r], g->stream[r]);
+          if (std::getenv("RT_GROUP_TRACE")) std::fprintf(stderr, "[rt group] rank %u kernel warm-up %.2f ms\n", r, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count());
           if (g->rc[r] != RT_OK) g->err[r] = rt_hip_last_error();
         }
       });
@@ -463,6 +466,7 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
     if (!why.empty()) rtg::use_peer_transport(g, why);
   } else if (g->gather) rtg::use_peer_transport(g, "");
   for (uint32_t r = 1; r < G; ++r) g->worker.emplace_back(rtg::worker_main, g, r);
+  if (std::getenv("RT_GROUP_TRACE")) std::fprintf(stderr, "[rt group] create: %.2f ms in all\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_group).count());
   *out = g;
   return RT_OK;
 }

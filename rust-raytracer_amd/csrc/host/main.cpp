@@ -180,7 +180,12 @@ int run(int argc, char** argv) {
   const auto t_main = std::chrono::steady_clock::now();
   g_hip_init = std::thread([]() {
     const auto t0 = std::chrono::steady_clock::now();
-    (void)rt_hip_device_count();
+    const int n = rt_hip_device_count();
+    // ... and the context + code object of every device the run will use (RT_GPUS, default 1): rt_hip_scene_create finds them up
+    const char* e = std::getenv("RT_GPUS");
+    long want = e ? std::strtol(e, nullptr, 10) : 1;
+    if (want < 1) want = 1;
+    for (int d = 0; d < n && d < want; ++d) (void)rt_hip_device_warm(d);
     g_hip_init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   });
   auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };

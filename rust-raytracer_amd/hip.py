@@ -37,6 +37,7 @@ def _bind(path, probes):
                     return _Stub()
         L = _Tolerant(L)
     L.rt_hip_device_count.restype = C.c_int
+    L.rt_hip_device_warm.argtypes = [C.c_int]
     L.rt_hip_last_error.restype = C.c_char_p
     L.rt_strerror.argtypes = [C.c_int]
     L.rt_strerror.restype = C.c_char_p
