@@ -185,7 +185,10 @@ int run(int argc, char** argv) {
     const char* e = std::getenv("RT_GPUS");
     long want = e ? std::strtol(e, nullptr, 10) : 1;
     if (want < 1) want = 1;
-    for (int d = 0; d < n && d < want; ++d) (void)rt_hip_device_warm(d);
+    std::vector<std::thread> per_device;  // (side by side: a context takes ~30 ms each)
+    for (int d = 1; d < n && d < want; ++d) per_device.emplace_back([d]() { (void)rt_hip_device_warm(d); });
+    if (n > 0) (void)rt_hip_device_warm(0);
+    for (auto& t : per_device) t.join();
     g_hip_init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   });
   auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };

@@ -32,4 +32,5 @@ int main(int argc,char**argv){
     if(rc==0){ ok++; size_t need=0; rt_scene_to_json(sf,jb,1<<22,&need); double cam[11]; rt_scene_camera(sf,cam); const RtScene* s=rt_scene_get(sf); volatile uint32_t x=s->n_spheres; (void)x; rt_scene_free(sf);} else err++;
     free(p);
   }
+  free(jb);
   printf("ok %d err %d\n",ok,err); return 0; }
