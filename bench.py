@@ -637,6 +637,8 @@ def run_ranks(args):
             out["other_configs"] = extra(other_configs, pkg, torch, dev, stream)
             out["mixed_radius_worlds"] = extra(mixed_radius_worlds, pkg, torch, dev, stream)
             out["cli"] = extra(cli_wall_times)
+            out["cli_note"] = ("median of 3 fresh processes each; the HIP runtime's start-up in a fresh process (hip_init_ms) varies 50 - 230 ms from run to run "
+                               "on these boxes and is most of the spread of wall_ms (profiles/r05_run14_cli_wall.log: 150 - 160 ms wall is the typical figure)")
         if world == 1 and not args.no_cpu_baseline:
             oracle = graft.load_oracle()
             cores = oracle.lib(abi).rt_oracle_threads()
