@@ -252,8 +252,8 @@ void rt_hip_scene_destroy(RtHipScene*);
  *     returned, or the caller drained that stream itself: hipStreamQuery says so).  Use one RtHipScene per concurrent stream
  *     (tables are ~100 KB + textures); distinct scenes and distinct devices are fully independent.
  *   - frames wider than 524 280 pixels or with more than 2^31 pixel tiles are RT_ERR_UNSUPPORTED.
- *   - any sphere count is accepted; above 65 535 spheres the uniform grid (u16 item lists) is not
- *     built and every ray tests every sphere, like the reference (raytracer.rs:52-57). */
+ *   - any sphere count is accepted (the reference scans a Vec<Sphere>, raytracer.rs:52-57); above 65 535 spheres the uniform
+ *     grid is built with 32-bit item lists ("wide" tables, rt_hip_scene_query "grid_wide") and stays in L2. */
 int rt_hip_render(RtHipScene*, const RtRowTiles* tiles, void* d_rgb8, void* d_linear, void* stream);
 /* Block until the last rt_hip_render on this scene finished; fill counters and the HIP-event
  * duration of its kernel (events are recorded on the stream the kernel was launched on). */
@@ -264,7 +264,7 @@ int rt_hip_wait(RtHipScene*, RtStats* stats);
  * rt_hip_group_set_option forwards to every rank's scene and takes "spin_us" itself. */
 int rt_hip_set_option(RtHipScene*, const char* key, int64_t value);
 /* What a resident scene was built into (diagnostics): "n_spheres", "n_lights", "grid_cells" (padded cell table, 8 B each),
- * "grid_items" (u16 each), "grid_large" (spheres every ray tests), "table_bytes" (geometry + material cores + cell table +
+ * "grid_items" (u16 each), "grid_wide" (1: more than 65 535 spheres — 16-byte cells, u32 items), "grid_large" (spheres every ray tests), "table_bytes" (geometry + material cores + cell table +
  * item lists: what a workgroup stages into LDS once per launch), "texel_bytes" (textures + sky as 4-byte texels in HBM);
  * of the last launch: "lds_bytes" (dynamic LDS of a workgroup), "lds_tables" (1: the tables were staged in LDS),
  * "light_pool_slots" / "light_base_slots" (lit scenes: records in the workgroup's pools of light frames / colour-map bases).

@@ -120,7 +120,7 @@ struct GridDesc {
   uint32_t n_cells;   // PADDED table size (n[0]+2)*(n[1]+2)*(n[2]+2)
   uint32_t n_items;
   float pull;         // 8 * grid_walk_eps(max n): how far the crossing planes are pulled back
-  float pad;
+  uint32_t wide;      // 1: 32-bit item lists (more than 65 535 spheres, or a cell / item count beyond the packed word): cell entries are four words (below)
   double nd[3];       // n[] as doubles (the slab test's far planes)
 };
 constexpr uint32_t GRID_MAX_AXIS = 256;        // cells per axis (bounds the f32 error of the walk)
@@ -130,6 +130,11 @@ constexpr uint32_t CELL_MAX_COUNT = 4095;
 // The cell table is padded by one layer of EXIT cells on every side: a walk that steps out of
 // the grid reads this word and stops — no per-axis range checks in the step.
 constexpr uint32_t CELL_EXIT = 0xFFFFFFFFu;
+// WIDE tables (GridDesc.wide): a cell entry is {first item, item count, index of the first item (0xFFFFFFFF = none), 0} and the
+// item list holds 32-bit sphere indices — no limit short of 2^32 on spheres, items or items per cell; EXIT cells have the
+// first word CELL_EXIT as above.  Such scenes never fit LDS: the kernel's instantiations for them (rt_kernel.hip, WIDE) gather
+// from L2 like every scene beyond the LDS budget.
+constexpr uint32_t CELL_NO_ITEM32 = 0xFFFFFFFFu;
 // Margins, in cells (DESIGN.md "Grid walk").  The walk is an incremental f32 DDA whose crossing
 // times are off by at most eps(n) = n(n+1)u + 6u(n+3) cells of ray travel (u = 2^-24, n = the
 // largest cell count of an axis; < 4.1e-3 for n <= 256).  It runs on crossing planes pulled
@@ -173,8 +178,8 @@ struct DevScene {
   float sky_wm1_f, sky_hm1_f;  // (float)(sky_w - 1), (float)(sky_h - 1) (raytracer.rs:149-150), converted once
   uint32_t light_base_slots;   // lit scenes with the short colour map: records in the workgroup's pool of colour-map bases (24 B each)
   GridDesc grid;
-  const uint32_t* cell_word;   // [n_cells][2]: {first item | count << 20, first two item indices (u16 | u16 << 16, 0xFFFF = none)}
-  const uint16_t* cell_items;  // [n_items] sphere indices, object order inside a cell
+  const uint32_t* cell_word;   // [n_cells][2]: {first item | count << 20, first two item indices (u16 | u16 << 16, 0xFFFF = none)}; grid.wide: [n_cells][4], see CELL_NO_ITEM32
+  const uint16_t* cell_items;  // [n_items] sphere indices, object order inside a cell (grid.wide: the same list as uint32_t, behind this pointer)
   const uint32_t* large;       // [n_large] sphere indices, object order
   const SphereGeom* large_geom;  // [n_large] their geometry, packed in the same order (streamed by scalar loads)
   const MatCore* matc;         // [n_spheres]
@@ -665,12 +670,13 @@ RT_HD void hit_world_grid(const DevScene& sc, const Tables& tb, V3 o, V3 d, doub
     return;
   }
   uint32_t last = 0xFFFFFFFFu;
+  const uint32_t* const items32 = reinterpret_cast<const uint32_t*>(sc.cell_items);
   for (;;) {
-    const uint32_t word = sc.cell_word[2 * w.lin];
+    const uint32_t word = sc.cell_word[(G.wide ? 4 : 2) * w.lin];
     if (word == CELL_EXIT) return;
-    const uint32_t first = word & CELL_START_MASK, count = word >> CELL_COUNT_SHIFT;
+    const uint32_t first = G.wide ? word : word & CELL_START_MASK, count = G.wide ? sc.cell_word[4 * w.lin + 1] : word >> CELL_COUNT_SHIFT;
     for (uint32_t k = 0; k < count; ++k) {
-      const uint32_t idx = sc.cell_items[first + k];
+      const uint32_t idx = G.wide ? items32[first + k] : sc.cell_items[first + k];
       if (idx == last) continue;  // the sphere tested last (large spheres span consecutive cells)
       last = idx;
       n_exact++;

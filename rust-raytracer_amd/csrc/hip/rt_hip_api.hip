@@ -216,7 +216,7 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   if ((rc = upload(&s->d_lights, t.lights)) != RT_OK) return bail(rc);
   if ((rc = upload(&s->d_matc, t.matc)) != RT_OK) return bail(rc);
   if ((rc = upload(&s->d_cell_word, t.cell_word)) != RT_OK) return bail(rc);
-  if ((rc = upload(&s->d_cell_items, t.cell_items)) != RT_OK) return bail(rc);
+  if ((rc = t.grid.wide ? upload(&s->d_cell_items, t.cell_items32) : upload(&s->d_cell_items, t.cell_items)) != RT_OK) return bail(rc);  // (wide tables: the 32-bit item lists)
   if ((rc = upload(&s->d_large, t.large)) != RT_OK) return bail(rc);
   if ((rc = upload(&s->d_large_geom, t.large_geom)) != RT_OK) return bail(rc);
   {
@@ -307,10 +307,10 @@ namespace {
 // launch's start event is recorded — a first frame used to carry the 147 MB hipMalloc of a lit scene and the runtime's
 // first look at the kernel inside its kernel_ms (one-shot CLI frames: 8.4 ms for a 0.9 ms kernel, profiles/r05_run5_cli_stats_before_warmup.log)
 // — and once at scene creation for the scene's default configuration (warm_up).
-template <bool HL, bool SIMPLE, bool LDS>
+template <bool HL, bool SIMPLE, bool LDS, bool WIDE>
 int prepare_grid_t(RtHipScene* s, size_t lds_bytes, hipStream_t stream) {
-  auto kern = rtk::rt_megakernel<HL, SIMPLE, LDS>;
-  const int key = (HL ? 4 : 0) | (SIMPLE ? 2 : 0) | (LDS ? 1 : 0);
+  auto kern = rtk::rt_megakernel<HL, SIMPLE, LDS, WIDE>;
+  const int key = (WIDE ? 8 : 0) | (HL ? 4 : 0) | (SIMPLE ? 2 : 0) | (LDS ? 1 : 0);
   if (s->cfg_key != key || s->cfg_lds != lds_bytes) {
     if (lds_bytes > 48 * 1024) RT_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     int per_cu_q = 0;
@@ -330,9 +330,9 @@ int prepare_grid_t(RtHipScene* s, size_t lds_bytes, hipStream_t stream) {
   }
   return RT_OK;
 }
-template <bool HL, bool SIMPLE, bool LDS>
+template <bool HL, bool SIMPLE, bool LDS, bool WIDE>
 int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka_in, size_t lds_bytes, uint32_t n_items, hipStream_t stream) {
-  auto kern = rtk::rt_megakernel<HL, SIMPLE, LDS>;
+  auto kern = rtk::rt_megakernel<HL, SIMPLE, LDS, WIDE>;
   // persistent: exactly the resident set, never more workgroups than there are wave-sized items
   uint32_t wgs = (uint32_t)s->cfg_per_cu * (uint32_t)s->num_cus;
   const uint32_t need = (n_items + rtk::WAVES - 1) / rtk::WAVES;
@@ -343,16 +343,20 @@ int launch_grid_t(RtHipScene* s, const rtk::KArgs& ka_in, size_t lds_bytes, uint
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(rtk::BLOCK), lds_bytes, stream, ka);
   return RT_OK;
 }
-// (lights, every albedo in [0, 1], tables in LDS) -> the instantiation's prepare / launch
-int dispatch_grid(RtHipScene* s, bool has_lights, bool lds_tables, bool prepare_only, const rtk::KArgs* ka, size_t lds_bytes, uint32_t n_items, hipStream_t stream) {
+// (lights, every albedo in [0, 1], tables in LDS, wide cell tables) -> the instantiation's prepare / launch
+int dispatch_grid(RtHipScene* s, bool has_lights, bool lds_tables, bool wide, bool prepare_only, const rtk::KArgs* ka, size_t lds_bytes, uint32_t n_items, hipStream_t stream) {
   int rc;
-#define RT_GO(HL, SIMPLE, LDS) rc = prepare_only ? prepare_grid_t<HL, SIMPLE, LDS>(s, lds_bytes, stream) : launch_grid_t<HL, SIMPLE, LDS>(s, *ka, lds_bytes, n_items, stream)
+#define RT_GO(HL, SIMPLE, LDS, WIDE) rc = prepare_only ? prepare_grid_t<HL, SIMPLE, LDS, WIDE>(s, lds_bytes, stream) : launch_grid_t<HL, SIMPLE, LDS, WIDE>(s, *ka, lds_bytes, n_items, stream)
   const bool simple = s->simple_colour;
-  if (has_lights) {
-    if (lds_tables) { if (simple) RT_GO(true, true, true); else RT_GO(true, false, true); }
-    else { if (simple) RT_GO(true, true, false); else RT_GO(true, false, false); }
-  } else if (lds_tables) { if (simple) RT_GO(false, true, true); else RT_GO(false, false, true); }
-  else { if (simple) RT_GO(false, true, false); else RT_GO(false, false, false); }
+  if (wide) {  // (the launch's grid has 32-bit item lists — more than 65 535 spheres; tables in L2: plan_lds never puts them in LDS)
+    if (lds_tables) return fail(RT_ERR_HIP, "wide cell tables cannot be staged in LDS");
+    if (has_lights) { if (simple) RT_GO(true, true, false, true); else RT_GO(true, false, false, true); }
+    else { if (simple) RT_GO(false, true, false, true); else RT_GO(false, false, false, true); }
+  } else if (has_lights) {
+    if (lds_tables) { if (simple) RT_GO(true, true, true, false); else RT_GO(true, false, true, false); }
+    else { if (simple) RT_GO(true, true, false, false); else RT_GO(true, false, false, false); }
+  } else if (lds_tables) { if (simple) RT_GO(false, true, true, false); else RT_GO(false, false, true, false); }
+  else { if (simple) RT_GO(false, true, false, false); else RT_GO(false, false, false, false); }
 #undef RT_GO
   return rc;
 }
@@ -392,7 +396,7 @@ int plan_lds(const RtHipScene* s, const rtc::GridDesc& G, bool has_lights, LdsPl
     return bytes(0.0) <= avail;  // (the smallest pools fit)
   };
   const rtk::LdsLayout no_pools = rtk::lds_layout(s->host.n_spheres, G.n_cells, G.n_items, true, false);
-  bool lds_tables = no_pools.total <= rtk::LDS_TABLES_MAX_BYTES;
+  bool lds_tables = !G.wide && no_pools.total <= rtk::LDS_TABLES_MAX_BYTES;
   if (has_lights) {
     const size_t fixed = rtc::LIGHT_CENTRES_LDS_MAX * 24u;
     double margin = 0.0;
@@ -417,7 +421,7 @@ int warm_up(RtHipScene* s) {
   LdsPlan plan;
   const int rc = plan_lds(s, s->dev.grid, s->has_lights, &plan);
   if (rc != RT_OK) return rc;
-  return dispatch_grid(s, s->has_lights, plan.lds_tables, true, nullptr, plan.lds_bytes, 0, nullptr);
+  return dispatch_grid(s, s->has_lights, plan.lds_tables, s->dev.grid.wide != 0u, true, nullptr, plan.lds_bytes, 0, nullptr);
 }
 
 }  // namespace
@@ -599,12 +603,12 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
 
   int rc;
   auto launch = [&](const rtk::KArgs& ka, uint32_t n_items) -> int {
-    const int rc = dispatch_grid(s, has_lights, lds_tables, false, &ka, lds_bytes, n_items, stream);
+    const int rc = dispatch_grid(s, has_lights, lds_tables, ka.sc.grid.wide != 0u, false, &ka, lds_bytes, n_items, stream);
     if (rc != RT_OK) return rc;
     RT_HIP_TRY(hipGetLastError());
     return RT_OK;
   };
-  if ((rc = dispatch_grid(s, has_lights, lds_tables, true, nullptr, lds_bytes, 0, stream)) != RT_OK) return rc;  // (host-side set-up: before the start event)
+  if ((rc = dispatch_grid(s, has_lights, lds_tables, ka.sc.grid.wide != 0u, true, nullptr, lds_bytes, 0, stream)) != RT_OK) return rc;  // (host-side set-up: before the start event)
   auto sort_tiles = [&]() -> int {
     hipLaunchKernelGGL(rtk::rt_order_tiles, dim3(1), dim3(1024), 0, stream, (const uint32_t*)s->d_tile_depth, s->d_tile_order, ka.n_tiles, ka.aff_group_log2);
     RT_HIP_TRY(hipGetLastError());
@@ -706,15 +710,16 @@ extern "C" int64_t rt_hip_scene_query(const RtHipScene* s, const char* key) {
   if (!s || !key) return -1;
   if (!std::strcmp(key, "n_spheres")) return (int64_t)s->host.n_spheres;
   if (!std::strcmp(key, "n_lights")) return (int64_t)s->dev.n_lights;
-  if (!std::strcmp(key, "grid_cells")) return (int64_t)s->grid.n_cells;       // padded cell table (8 B each)
-  if (!std::strcmp(key, "grid_items")) return (int64_t)s->grid.n_items;       // u16 each
+  if (!std::strcmp(key, "grid_cells")) return (int64_t)s->grid.n_cells;       // padded cell table (8 B each; wide tables: 16 B)
+  if (!std::strcmp(key, "grid_items")) return (int64_t)s->grid.n_items;       // u16 each (wide tables: u32)
+  if (!std::strcmp(key, "grid_wide")) return (int64_t)s->grid.wide;           // 1: 32-bit item lists (more than 65 535 spheres)
   if (!std::strcmp(key, "grid_large")) return (int64_t)s->grid.n_large;
   if (!std::strcmp(key, "texel_bytes")) return (int64_t)s->texel_bytes;       // 4-byte texels of textures + sky resident in HBM
   if (!std::strcmp(key, "light_pool_slots")) return (int64_t)s->last_pool_slots;  // of the last launch: records in the pools of light frames /
   if (!std::strcmp(key, "light_base_slots")) return (int64_t)s->last_base_slots;  // colour-map bases, the kernel's dynamic LDS, tables staged in LDS
   if (!std::strcmp(key, "lds_bytes")) return (int64_t)s->last_lds_bytes;
   if (!std::strcmp(key, "lds_tables")) return (int64_t)s->last_lds_tables;
-  if (!std::strcmp(key, "table_bytes")) return (int64_t)((size_t)s->host.n_spheres * (sizeof(rtc::SphereGeom) + sizeof(rtc::MatCore)) + (size_t)s->grid.n_cells * 8u + (size_t)s->grid.n_items * 2u);
+  if (!std::strcmp(key, "table_bytes")) return (int64_t)((size_t)s->host.n_spheres * (sizeof(rtc::SphereGeom) + sizeof(rtc::MatCore)) + (size_t)s->grid.n_cells * (s->grid.wide ? 16u : 8u) + (size_t)s->grid.n_items * (s->grid.wide ? 4u : 2u));
   return -1;
 }
 

@@ -293,8 +293,14 @@ struct LdsTables {  // per-lane gathers from the workgroup's LDS copies
   __device__ __forceinline__ MatCore mat(uint32_t i) const { return m[i]; }
 };
 
-template <bool HL, bool SIMPLE, bool LDS_TABLES>
+// WIDE: the wide cell-table format of rt_core.h (GridDesc.wide: four words per cell, u32 item lists, the first item inline) that
+// scenes of more than 65 535 spheres use, instead of the packed one (two words per cell, u16 items, the first TWO items inline).
+// The two forms stand side by side as `if constexpr` blocks in hit_world: the packed path is textually what it was before the
+// wide one existed, and compiles to the same code (helper functions over a common cell type did not: three instructions and a
+// different register assignment in every instantiation, +0.4 % on the headline frame, profiles/r05_run19_ab_wide_tables.log).
+template <bool HL, bool SIMPLE, bool LDS_TABLES, bool WIDE = false>
 __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs ka) {
+  static_assert(!(LDS_TABLES && WIDE), "wide tables (more than 65 535 spheres) never fit LDS");
   const DevScene& sc = ka.sc;
   const GridDesc& G = sc.grid;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -745,8 +751,13 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
       // `walking` flag costs a lane-mask AND per use and a VGPR round trip in the loop's exit vote.
       uint32_t it = 1, end = 0, pend = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
       if (walk0) {
-        const uint2 e = cell_word[lin];
-        it = e.x & CELL_START_MASK; end = it + (e.x >> CELL_COUNT_SHIFT); pend = e.y;
+        if constexpr (WIDE) {
+          const uint4 e = reinterpret_cast<const uint4*>(cell_word)[lin];
+          it = e.x; end = it + e.y; pend = e.z;
+        } else {
+          const uint2 e = cell_word[lin];
+          it = e.x & CELL_START_MASK; end = it + (e.x >> CELL_COUNT_SHIFT); pend = e.y;
+        }
       }
       for (;;) {
         if (!wave_any(it <= end)) break;
@@ -774,20 +785,38 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
               const float b0 = a0 + (bx_ ? dt0 : 0.0f), b1 = a1 + (by_ ? dt1 : 0.0f), b2 = a2 + (bz_ ? dt2 : 0.0f);
               int linB = linA + (bx_ ? dl0 : (by_ ? dl1 : dl2));
               linB = linB < 0 ? 0 : (linB > lin_max ? lin_max : linB);  // speculative address: keep it inside the table
-              const uint2 eA = cell_word[linA];
-              const uint2 eB = cell_word[linB];
-              n_steps++;
-              const bool exitA = eA.x == CELL_EXIT, emptyA = (eA.x >> CELL_COUNT_SHIFT) == 0u;
-              const bool doneA = hit && tc < tminB;  // the closest hit lies inside cell A
-              if (exitA || !emptyA || doneA) {  // stay in A (or stop there)
-                tm0 = a0; tm1 = a1; tm2 = a2; lin = linA;
-                it = eA.x & CELL_START_MASK; end = it + (eA.x >> CELL_COUNT_SHIFT); pend = eA.y;
-                if (exitA || emptyA) { it = 1; end = 0; }
-              } else {                           // A is empty: on to B
+              if constexpr (WIDE) {
+                const uint4 eA = reinterpret_cast<const uint4*>(cell_word)[linA];
+                const uint4 eB = reinterpret_cast<const uint4*>(cell_word)[linB];
                 n_steps++;
-                tm0 = b0; tm1 = b1; tm2 = b2; lin = linB;
-                it = eB.x & CELL_START_MASK; end = it + (eB.x >> CELL_COUNT_SHIFT); pend = eB.y;
-                if (eB.x == CELL_EXIT) { it = 1; end = 0; }
+                const bool exitA = eA.x == CELL_EXIT, emptyA = eA.y == 0u;
+                const bool doneA = hit && tc < tminB;  // the closest hit lies inside cell A
+                if (exitA || !emptyA || doneA) {  // stay in A (or stop there)
+                  tm0 = a0; tm1 = a1; tm2 = a2; lin = linA;
+                  it = eA.x; end = it + eA.y; pend = eA.z;
+                  if (exitA || emptyA) { it = 1; end = 0; }
+                } else {                           // A is empty: on to B
+                  n_steps++;
+                  tm0 = b0; tm1 = b1; tm2 = b2; lin = linB;
+                  it = eB.x; end = it + eB.y; pend = eB.z;
+                  if (eB.x == CELL_EXIT) { it = 1; end = 0; }
+                }
+              } else {
+                const uint2 eA = cell_word[linA];
+                const uint2 eB = cell_word[linB];
+                n_steps++;
+                const bool exitA = eA.x == CELL_EXIT, emptyA = (eA.x >> CELL_COUNT_SHIFT) == 0u;
+                const bool doneA = hit && tc < tminB;  // the closest hit lies inside cell A
+                if (exitA || !emptyA || doneA) {  // stay in A (or stop there)
+                  tm0 = a0; tm1 = a1; tm2 = a2; lin = linA;
+                  it = eA.x & CELL_START_MASK; end = it + (eA.x >> CELL_COUNT_SHIFT); pend = eA.y;
+                  if (exitA || emptyA) { it = 1; end = 0; }
+                } else {                           // A is empty: on to B
+                  n_steps++;
+                  tm0 = b0; tm1 = b1; tm2 = b2; lin = linB;
+                  it = eB.x & CELL_START_MASK; end = it + (eB.x >> CELL_COUNT_SHIFT); pend = eB.y;
+                  if (eB.x == CELL_EXIT) { it = 1; end = 0; }
+                }
               }
             }
           }
@@ -798,9 +827,16 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
           if (wave_any(testing)) cnt_w_test++;
 #endif
           if (testing) {
-            uint32_t idx = pend & 0xFFFFu;
-            if (idx == 0xFFFFu) idx = cell_items[it];  // third and later items of a cell: from the list
-            pend = (pend >> 16) | 0xFFFF0000u;
+            uint32_t idx;
+            if constexpr (WIDE) {  // (one inline item, the rest from the 32-bit list)
+              idx = pend;
+              if (idx == CELL_NO_ITEM32) idx = reinterpret_cast<const uint32_t*>(cell_items)[it];
+              pend = CELL_NO_ITEM32;
+            } else {
+              idx = pend & 0xFFFFu;
+              if (idx == 0xFFFFu) idx = cell_items[it];  // third and later items of a cell: from the list
+              pend = (pend >> 16) | 0xFFFF0000u;
+            }
             it++;
             if (idx != last) {  // a sphere spanning consecutive cells is not re-tested
               last = idx; n_exact++;

@@ -31,6 +31,7 @@ struct HostTables {
   GridDesc grid{};
   std::vector<uint32_t> cell_word;
   std::vector<uint16_t> cell_items;
+  std::vector<uint32_t> cell_items32;  // grid.wide: the item lists as 32-bit indices (cell_items is empty then)
   std::vector<uint32_t> large;
   std::vector<SphereGeom> large_geom;
 };
@@ -46,11 +47,15 @@ struct GridParams {
   uint32_t large_cell_limit = 512; // a sphere covering more cells than this -> `large` list
   uint32_t min_spheres = 24;       // fewer spheres than this: no grid, test them all
   uint32_t force_n[3] = {0, 0, 0}; // != 0: cells along that axis (development: anisotropic grids)
+  bool force_wide = false;         // the wide table format (GridDesc.wide) whatever the sphere count (tests: small worlds through the wide kernels)
 };
 // The shipped library takes the defaults above and reads NOTHING from the environment.  A/B builds and the analysis
 // tools (tools/ab_bench.py, tools/analysis/) compile with -DRT_DEV_KNOBS to sweep the grid's shape.
 inline GridParams grid_params_from_env() {
   GridParams p;
+#if defined(RT_DEV_KNOBS) || defined(RT_TEST_PROBES)  // (librt_hip_probe.so — tests only — can put any world through the wide format)
+  if (const char* e = std::getenv("RT_GRID_WIDE")) p.force_wide = std::atoi(e) != 0;
+#endif
 #ifdef RT_DEV_KNOBS
   if (const char* e = std::getenv("RT_GRID_CELLS_PER_SPHERE")) p.cells_per_sphere = std::atof(e);
   if (const char* e = std::getenv("RT_GRID_MIN_SPHERES")) p.min_spheres = (uint32_t)std::atoi(e);
@@ -64,18 +69,23 @@ inline GridParams grid_params_from_env() {
 // Uniform grid over the ordinary spheres; see GridDesc / 2*GridDesc.pull in rt_core.h for what the
 // walk relies on: sphere i is listed in every cell its bounding box, grown by 2*GridDesc.pull
 // cells, overlaps (cells farther from the centre than the radius are dropped again).
-inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
+// `wide`: the table format (GridDesc.wide).  Returns false — with nothing usable in `t` — when the PACKED format cannot hold this
+// grid (more than 65 535 spheres: its item indices are u16, 0xFFFF = none; more than 4 095 items in a cell; 2^20 items or more):
+// the caller builds it again wide.
+inline bool build_grid_as(const RtScene& sc, HostTables& t, const GridParams& gp, bool wide) {
   const uint32_t n = sc.n_spheres;
   GridDesc& G = t.grid;
   std::memset(&G, 0, sizeof G);
-  t.cell_word.clear(); t.cell_items.clear(); t.large.clear();
+  t.cell_word.clear(); t.cell_items.clear(); t.cell_items32.clear(); t.large.clear();
   auto all_large = [&]() {
     std::memset(&G, 0, sizeof G);
-    t.cell_word.clear(); t.cell_items.clear(); t.large.resize(n);
+    t.cell_word.clear(); t.cell_items.clear(); t.cell_items32.clear(); t.large.resize(n);
     for (uint32_t i = 0; i < n; ++i) t.large[i] = i;
     G.n_large = n;
   };
-  if (n < gp.min_spheres || n > 65535u) { all_large(); return; }  // item indices are u16, 0xFFFF = none
+  if (n < gp.min_spheres) { all_large(); return true; }
+  if (!wide && n > 65535u) return false;
+  if (n >= 0xFFFFFFFEu) { all_large(); return true; }
   std::vector<uint8_t> is_large(n, 0);
   std::vector<double> radii;
   for (uint32_t i = 0; i < n; ++i) {
@@ -83,7 +93,7 @@ inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
     const bool finite = std::isfinite(s.center[0]) && std::isfinite(s.center[1]) && std::isfinite(s.center[2]) && std::isfinite(s.radius);
     if (!finite) is_large[i] = 1; else radii.push_back(std::fabs(s.radius));
   }
-  if (radii.size() < gp.min_spheres) { all_large(); return; }
+  if (radii.size() < gp.min_spheres) { all_large(); return true; }
   std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
   const double r_med = radii[radii.size() / 2];
   double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -109,7 +119,7 @@ inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
       hi[k] = std::max(hi[k], s.center[k] + std::fabs(s.radius));
     }
   }
-  if (n_grid < gp.min_spheres) { all_large(); return; }
+  if (n_grid < gp.min_spheres) { all_large(); return true; }
   double ext[3], vol = 1.0;
   for (int k = 0; k < 3; ++k) {
     const double pad = 1e-3 * (hi[k] - lo[k]) + 1e-9 * (std::fabs(lo[k]) + std::fabs(hi[k])) + 1e-12;
@@ -176,20 +186,28 @@ inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
     const uint32_t ix = c % G.n[0], iy = (c / G.n[0]) % G.n[1], iz = c / (G.n[0] * G.n[1]);
     return (ix + 1) + px * ((iy + 1) + py * (iz + 1));
   };
+  const uint32_t cw = wide ? 4u : 2u;  // words per cell entry
   for (int pass = 0; pass < 2; ++pass) {
     std::vector<uint32_t> cursor;
     if (pass == 1) {
       uint64_t total = 0;
-      t.cell_word.assign(2 * (size_t)G.n_cells, CELL_EXIT);  // {word, first two items} per cell
+      t.cell_word.assign((size_t)cw * G.n_cells, 0u);
+      for (size_t c = 0; c < G.n_cells; ++c) {  // every padded cell is an EXIT cell until the inner ones are written
+        t.cell_word[cw * c] = CELL_EXIT;
+        t.cell_word[cw * c + 1] = wide ? 0u : CELL_EXIT;
+        if (wide) t.cell_word[cw * c + 2] = CELL_NO_ITEM32;
+      }
       cursor.resize(n_inner);
       for (uint32_t c = 0; c < n_inner; ++c) {
-        if (count[c] > CELL_MAX_COUNT || total >= CELL_START_MASK) { all_large(); return; }
-        t.cell_word[2 * padded(c)] = (uint32_t)total | (count[c] << CELL_COUNT_SHIFT);
+        if (!wide && (count[c] > CELL_MAX_COUNT || total >= CELL_START_MASK)) return false;
+        if (wide) { t.cell_word[4 * (size_t)padded(c)] = (uint32_t)total; t.cell_word[4 * (size_t)padded(c) + 1] = count[c]; }
+        else t.cell_word[2 * (size_t)padded(c)] = (uint32_t)total | (count[c] << CELL_COUNT_SHIFT);
         cursor[c] = (uint32_t)total;
         total += count[c];
+        if (total >= 0xFFFFFFFEull) { all_large(); return true; }
       }
-      if (total >= CELL_START_MASK) { all_large(); return; }
-      t.cell_items.resize(total);
+      if (!wide && total >= CELL_START_MASK) return false;
+      if (wide) t.cell_items32.resize(total); else t.cell_items.resize(total);
       G.n_items = (uint32_t)total;
     }
     for (uint32_t i = 0; i < n; ++i) {
@@ -200,18 +218,31 @@ inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
           for (int ix = rng[i].a[0]; ix <= rng[i].b[0]; ++ix) {
             if (!overlaps(s, ix, iy, iz)) continue;
             const uint32_t c = (uint32_t)ix + G.n[0] * ((uint32_t)iy + G.n[1] * (uint32_t)iz);
-            if (pass == 0) count[c]++; else t.cell_items[cursor[c]++] = (uint16_t)i;
+            if (pass == 0) count[c]++;
+            else if (wide) t.cell_items32[cursor[c]++] = i;
+            else t.cell_items[cursor[c]++] = (uint16_t)i;
           }
     }
   }
-  for (uint32_t c = 0; c < n_inner; ++c) {  // inline copy of each cell's first two items
+  for (uint32_t c = 0; c < n_inner; ++c) {  // inline copy of each cell's first two items (wide: of its first item)
+    if (wide) {
+      const uint32_t first = t.cell_word[4 * (size_t)padded(c)], cnt = t.cell_word[4 * (size_t)padded(c) + 1];
+      t.cell_word[4 * (size_t)padded(c) + 2] = cnt > 0 ? t.cell_items32[first] : CELL_NO_ITEM32;
+      continue;
+    }
     const uint32_t word = t.cell_word[2 * padded(c)];
     const uint32_t first = word & CELL_START_MASK, cnt = word >> CELL_COUNT_SHIFT;
     const uint32_t i0 = cnt > 0 ? t.cell_items[first] : 0xFFFFu, i1 = cnt > 1 ? t.cell_items[first + 1] : 0xFFFFu;
     t.cell_word[2 * padded(c) + 1] = i0 | (i1 << 16);
   }
+  G.wide = wide ? 1u : 0u;
   for (uint32_t i = 0; i < n; ++i) if (is_large[i]) t.large.push_back(i);
   G.n_large = (uint32_t)t.large.size();
+  return true;
+}
+inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
+  const bool wide = gp.force_wide || sc.n_spheres > 65535u;
+  if (!build_grid_as(sc, t, gp, wide)) build_grid_as(sc, t, gp, true);
 }
 
 // returns "" or a description of why the scene is invalid (RT_ERR_INVALID)

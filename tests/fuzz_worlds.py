@@ -101,3 +101,17 @@ def adversarial_scene(host, seed):
         sp[base + 1 + j].center[0], sp[base + 1 + j].center[2] = 0.5, 0.5
         sp[base + 1 + j].center[1], sp[base + 1 + j].radius = 0.3, 0.3
     return sc
+
+
+def big_flat_world_json(n, rng, width=12, height=8, spp=2, depth=6, half=60.0):
+    """n small spheres scattered over a ground sphere (the cover scene's layer, wider: a square of side 2 * half — the cover
+    scene has one sphere per unit of area): the world of the > 65 535-sphere tests"""
+    import json
+    objs = [{"center": {"x": 0.0, "y": -1000.0, "z": 0.0}, "radius": 1000.0, "material": {"Lambertian": {"albedo": [0.5, 0.5, 0.5]}}}]
+    xs, zs = rng.uniform(-half, half, n), rng.uniform(-half, half, n)
+    for i in range(n):
+        m = {"Lambertian": {"albedo": [0.3, 0.6, 0.2]}} if i % 3 else ({"Metal": {"albedo": [0.8, 0.8, 0.8], "fuzz": 0.1}} if i % 2 else {"Glass": {"index_of_refraction": 1.5}})
+        objs.append({"center": {"x": float(xs[i]), "y": 0.2, "z": float(zs[i])}, "radius": 0.2, "material": m})
+    return json.dumps({"width": width, "height": height, "samples_per_pixel": spp, "max_depth": depth, "sky": {"texture": ""},
+                       "camera": {"look_from": {"x": 13.0, "y": 2.0, "z": 3.0}, "look_at": {"x": 0.0, "y": 0.0, "z": 0.0}, "vup": {"x": 0.0, "y": 1.0, "z": 0.0},
+                                  "vfov": 20.0, "aspect": 1.5}, "objects": objs})

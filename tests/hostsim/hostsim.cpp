@@ -147,7 +147,7 @@ extern "C" int hostsim_render(const RtScene* scene, const RtRowTiles* tiles, uin
     if (scene->textures[i].nbytes) std::memcpy(&blob[t.tex_off[i]], scene->textures[i].rgb8, scene->textures[i].nbytes);
   ds.geom = t.geom.data(); ds.mat = t.mat.data(); ds.lights = t.lights.data();
   ds.tex = blob.data(); ds.sky = scene->sky_rgb8;
-  ds.matc = t.matc.data(); ds.cell_word = t.cell_word.data(); ds.cell_items = t.cell_items.data(); ds.large = t.large.data(); ds.large_geom = t.large_geom.data();
+  ds.matc = t.matc.data(); ds.cell_word = t.cell_word.data(); ds.cell_items = t.grid.wide ? reinterpret_cast<const uint16_t*>(t.cell_items32.data()) : t.cell_items.data(); ds.large = t.large.data(); ds.large_geom = t.large_geom.data();
   // +32: the SHORT colour maps the product kernel takes when every albedo lies in [0, 1] (rt_core.h FwdT<true>; lit scenes:
   // q in registers + the memory-resident base of lane_compose) instead of the general clamped-affine map — bit-identical
   const bool short_map = (use_cull & 32) != 0 && t.simple_colour;
@@ -187,6 +187,13 @@ extern "C" int hostsim_grid_info(const RtScene* scene, uint32_t out[6]) {
   return RT_OK;
 }
 
+// 1: the scene's grid is in the wide table format (GridDesc.wide: 32-bit item lists), 0: packed, < 0: error
+extern "C" int hostsim_grid_wide(const RtScene* scene) {
+  HostTables t;
+  if (!scene || !build_tables(*scene, t).empty()) return RT_ERR_INVALID;
+  return (int)t.grid.wide;
+}
+
 // one ray against one scene through the grid and by brute force (adversarial tests):
 // out = {best_grid, best_brute}, t_out = {t_grid, t_brute}
 extern "C" int hostsim_hit_world(const RtScene* scene, const double o[3], const double d[3], int out[2], double t_out[2]) {
@@ -194,7 +201,7 @@ extern "C" int hostsim_hit_world(const RtScene* scene, const double o[3], const 
   if (!scene || !build_tables(*scene, t).empty()) return RT_ERR_INVALID;
   DevScene ds;
   fill_dev_scene(*scene, t, ds);
-  ds.geom = t.geom.data(); ds.matc = t.matc.data(); ds.cell_word = t.cell_word.data(); ds.cell_items = t.cell_items.data();
+  ds.geom = t.geom.data(); ds.matc = t.matc.data(); ds.cell_word = t.cell_word.data(); ds.cell_items = t.grid.wide ? reinterpret_cast<const uint16_t*>(t.cell_items32.data()) : t.cell_items.data();
   ds.large = t.large.data(); ds.large_geom = t.large_geom.data();
   const GlobalTables tb{ds.geom, ds.matc};
   V3 oo = v3(o[0], o[1], o[2]), dd = v3(d[0], d[1], d[2]);

@@ -459,30 +459,56 @@ def test_fuzz_worlds_lane_logic_matches_the_oracle(hostsim, oracle, abi, host, k
     assert_parity(h_rgb, h_lin, o_rgb, o_lin, f"fuzz world {kind}", atol=pooled_atol(sc.c.samples_per_pixel), flip_frac=2e-3)
 
 
-def test_more_than_65535_spheres_fall_back_to_the_full_scan(hostsim, oracle, abi, host):
-    """the reference accepts any object count.  Above 65 535 spheres the u16 item lists of the uniform grid
-    cannot name a sphere: build_grid keeps every sphere in the `large` list (the reference's own scan over all objects,
-    raytracer.rs:52-57) and the frame still equals the oracle's."""
-    import json
-    rng = np.random.default_rng(3)
+def test_more_than_65535_spheres_take_the_wide_tables(hostsim, oracle, abi, host):
+    """The reference accepts any object count (a Vec<Sphere>, raytracer.rs:52-57).  Above 65 535 spheres the packed cell tables
+    (u16 item lists) cannot name a sphere: build_grid switches to the WIDE format — 32-bit item lists, four words per cell —
+    and the walk stays a walk (until round 5 such a scene fell back to the reference's full scan: 66 001 tests per segment).
+    Same closest hits as brute force per segment (audit mode), same frame as the oracle."""
     n = 66000
-    objs = [{"center": {"x": 0.0, "y": -1000.0, "z": 0.0}, "radius": 1000.0, "material": {"Lambertian": {"albedo": [0.5, 0.5, 0.5]}}}]
-    xs, zs = rng.uniform(-60, 60, n), rng.uniform(-60, 60, n)
-    for i in range(n):
-        m = {"Lambertian": {"albedo": [0.3, 0.6, 0.2]}} if i % 3 else ({"Metal": {"albedo": [0.8, 0.8, 0.8], "fuzz": 0.1}} if i % 2 else {"Glass": {"index_of_refraction": 1.5}})
-        objs.append({"center": {"x": float(xs[i]), "y": 0.2, "z": float(zs[i])}, "radius": 0.2, "material": m})
-    cfg = {"width": 12, "height": 8, "samples_per_pixel": 2, "max_depth": 6, "sky": {"texture": ""},
-           "camera": {"look_from": {"x": 13.0, "y": 2.0, "z": 3.0}, "look_at": {"x": 0.0, "y": 0.0, "z": 0.0}, "vup": {"x": 0.0, "y": 1.0, "z": 0.0},
-                      "vfov": 20.0, "aspect": 1.5}, "objects": objs}
-    sc = host.Scene.loads(json.dumps(cfg))
+    from fuzz_worlds import big_flat_world_json
+    sc = host.Scene.loads(big_flat_world_json(n, np.random.default_rng(3)))
     assert sc.c.n_spheres == n + 1 > 65535
     info = (C.c_uint32 * 6)()
     assert hostsim.hostsim_grid_info(sc.ptr, info) == 0
-    assert info[0] == 0 and info[3] == n + 1          # no grid; all spheres in the `large` list
+    assert info[0] > 1 and info[2] > 1 and info[3] <= 8 and info[5] >= n     # a grid; only the ground is `large`; every small sphere listed
+    assert hostsim.hostsim_grid_wide(sc.ptr) == 1
     o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
     rgb, lin, st = hostsim.render(sc.ptr, None, 3)
     assert_parity(rgb, lin, o_rgb, o_lin, "66001 spheres")
-    assert st["segments"] == o_st["segments"] and st["exact_tests"] == st["sphere_tests"]
+    assert st["segments"] == o_st["segments"] and st["exact_tests"] < 30 * st["segments"]   # (the full scan: 66 001 per segment)
+    _, _, st_audit = hostsim.render(sc.ptr, None, 4)
+    assert st_audit["kernel_ms"] == 0.0, "grid walk and brute force disagree on some segment"
+
+
+@pytest.fixture
+def wide_tables(monkeypatch):
+    """RT_GRID_WIDE=1: the CPU build of the table builder (tests/hostsim, -DRT_TEST_PROBES) puts ANY world into the wide format"""
+    monkeypatch.setenv("RT_GRID_WIDE", "1")
+
+
+@pytest.mark.parametrize("kind", range(6))
+def test_wide_tables_give_the_packed_tables_walk(hostsim, abi, host, kind, monkeypatch):
+    """The wide format is only another encoding of the same grid: on the fuzz worlds (and the cover scene below) the walk
+    visits the same cells and tests the same spheres — identical images, segment, test and step counts — and agrees with
+    brute force on every segment."""
+    from fuzz_worlds import fuzz_world_json
+    sc = host.Scene.loads(fuzz_world_json(np.random.default_rng(2000 + kind), kind))
+    assert hostsim.hostsim_grid_wide(sc.ptr) == 0
+    p_rgb, p_lin, p_st = hostsim.render(sc.ptr, mode=3 + 16)
+    monkeypatch.setenv("RT_GRID_WIDE", "1")
+    assert hostsim.hostsim_grid_wide(sc.ptr) == 1
+    w_rgb, w_lin, w_st = hostsim.render(sc.ptr, mode=3 + 16)
+    assert np.array_equal(p_rgb, w_rgb) and np.array_equal(p_lin, w_lin)
+    assert all(p_st[k] == w_st[k] for k in ("segments", "exact_tests", "grid_steps"))
+    _, _, st_audit = hostsim.render(sc.ptr, mode=4)
+    assert st_audit["kernel_ms"] == 0.0
+
+
+def test_wide_tables_on_the_cover_scene(hostsim, load_scene, wide_tables):
+    sc = load_scene("cover", 60, 40, 4, 50)
+    assert hostsim.hostsim_grid_wide(sc.ptr) == 1
+    _, _, st_audit = hostsim.render(sc.ptr, mode=4)
+    assert st_audit["kernel_ms"] == 0.0 and st_audit["grid_steps"] > 0
 
 
 TEXEL_RECORDS = [

@@ -40,13 +40,15 @@ def gpu_render(pkg, abi, torch_cuda):
     torch = torch_cuda
 
     def _render(scene, tiles=None, variant=0, want_linear=True, chunk_spp=None, tile_log2=None, tile_order=None, frames=1, tile_shape=None,
-                tile_affinity=None, opts=None):
+                tile_affinity=None, opts=None, library=None, query=None):
         """variant 0: the product kernel (grid walk, tile queue, exact fixed-point pixel sums);
         variant 1: same kernel, the reference's brute force over all spheres.  chunk_spp: samples of a
         pixel per work item; tile_log2: pixel tiles of 2^k x 2^k."""
         sc = scene.c
         rows = abi.tiles_local_rows(sc.height, tiles)
-        gs = pkg.hip.HipScene(scene.ptr, 0)
+        gs = pkg.hip.HipScene(scene.ptr, 0, library=library)   # (library: probe_lib() for the tests that force the wide table format)
+        if query is not None:
+            query.update({k: gs.query(k) for k in ("grid_wide", "grid_cells", "grid_items", "grid_large")})
         if variant:
             gs.set_option("variant", variant)
         if chunk_spp is not None:
@@ -444,24 +446,67 @@ def test_procedural_10k_spheres(gpu_render, oracle, abi, host):
 
 
 def test_more_than_65535_spheres(gpu_render, oracle, abi, host):
-    """any object count is accepted (the reference's Vec<Sphere> has no limit): above 65 535 spheres the grid's u16 item
-    lists cannot be built and the kernel scans every sphere like raytracer.rs:52-57 — slow, but the reference's frame"""
-    rng = np.random.default_rng(3)
+    """any object count is accepted (the reference's Vec<Sphere> has no limit): above 65 535 spheres the packed cell tables
+    (u16 item lists) cannot name a sphere and the scene takes the WIDE tables — 32-bit item lists, the kernel's wide
+    instantiations, tables in L2.  The oracle's frame, the brute-force variant's bits, and a walk instead of 66 001 tests
+    per segment (what such a scene cost until round 5)."""
+    from fuzz_worlds import big_flat_world_json
     n = 66000
-    objs = [{"center": {"x": 0.0, "y": -1000.0, "z": 0.0}, "radius": 1000.0, "material": {"Lambertian": {"albedo": [0.5, 0.5, 0.5]}}}]
-    xs, zs = rng.uniform(-60, 60, n), rng.uniform(-60, 60, n)
-    for i in range(n):
-        m = {"Lambertian": {"albedo": [0.3, 0.6, 0.2]}} if i % 3 else ({"Metal": {"albedo": [0.8, 0.8, 0.8], "fuzz": 0.1}} if i % 2 else {"Glass": {"index_of_refraction": 1.5}})
-        objs.append({"center": {"x": float(xs[i]), "y": 0.2, "z": float(zs[i])}, "radius": 0.2, "material": m})
-    cfg = {"width": 16, "height": 10, "samples_per_pixel": 2, "max_depth": 6, "sky": {"texture": ""},
-           "camera": {"look_from": {"x": 13.0, "y": 2.0, "z": 3.0}, "look_at": {"x": 0.0, "y": 0.0, "z": 0.0}, "vup": {"x": 0.0, "y": 1.0, "z": 0.0},
-                      "vfov": 20.0, "aspect": 1.6}, "objects": objs}
-    sc = host.Scene.loads(json.dumps(cfg))
+    sc = host.Scene.loads(big_flat_world_json(n, np.random.default_rng(3), width=16, height=10))
     assert sc.c.n_spheres == n + 1
     o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
-    rgb, lin, st = gpu_render(sc)
+    q = {}
+    rgb, lin, st = gpu_render(sc, query=q)
+    assert q["grid_wide"] == 1 and q["grid_large"] <= 8 and q["grid_items"] >= n
     assert_parity(rgb, lin, o_rgb, o_lin, "66001 spheres", atol=pooled_atol(2))
-    assert st["segments"] == o_st["segments"] and st["grid_steps"] == 0 and st["exact_tests"] == st["sphere_tests"]
+    assert st["segments"] == o_st["segments"] and st["grid_steps"] > 0 and st["exact_tests"] < 30 * st["segments"]
+    b_rgb, b_lin, b_st = gpu_render(sc, variant=1)
+    assert np.array_equal(rgb, b_rgb) and np.array_equal(lin, b_lin) and b_st["exact_tests"] == b_st["sphere_tests"]
+
+
+def test_200k_spheres_at_speed(gpu_render, host):
+    """2 x 10^5 spheres (three times the packed format's limit) at the cover scene's density, 640 x 360, spp 16: the frame takes
+    milliseconds, not the minutes of a full scan (2 x 10^5 tests per segment); printed for the record.  (A FLAT world of this size
+    is the grid's worst case: 256 cells per axis — the bound of the f32 walk's error analysis — leave 3 spheres per cell.)"""
+    from fuzz_worlds import big_flat_world_json
+    n = 200000
+    sc = host.Scene.loads(big_flat_world_json(n, np.random.default_rng(5), width=640, height=360, spp=16, depth=50, half=224.0))
+    q = {}
+    rgb, _, st = gpu_render(sc, want_linear=False, frames=2, query=q)
+    print(f"\n200k spheres 640x360 spp16: kernel {st['kernel_ms']:.2f} ms, {st['samples'] / st['kernel_ms'] / 1e3:.0f} Msamples/s, "
+          f"{st['exact_tests'] / st['segments']:.2f} exact tests/segment, {st['grid_steps'] / st['segments']:.2f} steps/segment, grid {q}")
+    assert q["grid_wide"] == 1 and st["exact_tests"] < 30 * st["segments"] and st["kernel_ms"] < 200.0
+    assert rgb.std() > 5      # (a picture: sky, ground, spheres)
+
+
+def test_wide_tables_render_the_packed_tables_frame(pkg, gpu_render, load_scene, monkeypatch):
+    """The wide format is another encoding of the same grid: the cover scene through librt_hip_probe.so with RT_GRID_WIDE=1
+    (the kernel's wide instantiation, tables in L2) gives the product's frame bit for bit, and its counters."""
+    sc = load_scene("cover", 150, 100, 4, 50)
+    rgb, lin, st = gpu_render(sc)
+    monkeypatch.setenv("RT_GRID_WIDE", "1")
+    q = {}
+    w_rgb, w_lin, w_st = gpu_render(sc, library=pkg.hip.probe_lib(), query=q)
+    assert q["grid_wide"] == 1
+    assert np.array_equal(rgb, w_rgb) and np.array_equal(lin, w_lin)
+    assert all(st[k] == w_st[k] for k in ("segments", "exact_tests", "grid_steps"))
+
+
+@pytest.mark.parametrize("kind", range(6))
+def test_wide_tables_on_the_fuzz_worlds(pkg, gpu_render, host, monkeypatch, kind):
+    """fuzz worlds (mixed materials, two lights, hollow shells, a camera inside glass) through the wide kernels: the
+    product's frame and counters, and the brute-force variant's frame"""
+    from fuzz_worlds import fuzz_world_json
+    sc = host.Scene.loads(fuzz_world_json(np.random.default_rng(3000 + kind), kind))
+    rgb, lin, st = gpu_render(sc)
+    monkeypatch.setenv("RT_GRID_WIDE", "1")
+    q = {}
+    w_rgb, w_lin, w_st = gpu_render(sc, library=pkg.hip.probe_lib(), query=q)
+    assert q["grid_wide"] == 1
+    assert np.array_equal(rgb, w_rgb) and np.array_equal(lin, w_lin)
+    assert all(st[k] == w_st[k] for k in ("segments", "exact_tests", "grid_steps"))
+    b_rgb, b_lin, _ = gpu_render(sc, library=pkg.hip.probe_lib(), variant=1)
+    assert np.array_equal(w_rgb, b_rgb) and np.array_equal(w_lin, b_lin)
 
 
 def test_host_buffer_entry_point(pkg, gpu_render, load_scene):

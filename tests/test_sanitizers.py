@@ -24,8 +24,8 @@ def _build(tmp_path, name, sources, extra=()):
     return exe
 
 
-def _run(cmd, timeout):
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=ENV)
+def _run(cmd, timeout, env=None):
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env or ENV)
     assert r.returncode == 0 and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, (r.stdout[-500:], r.stderr[-3000:])
     return r.stdout
 
@@ -48,6 +48,8 @@ def test_scene_schema_under_sanitizers(tmp_path):
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
 def test_tables_grid_and_walk_under_sanitizers(tmp_path):
-    exe = _build(tmp_path, "fuzz_tables", ["tools/fuzz/fuzz_tables.cpp", "tests/hostsim/hostsim.cpp"], extra=("-ffp-contract=off", "-fopenmp", "-lpthread"))
+    exe = _build(tmp_path, "fuzz_tables", ["tools/fuzz/fuzz_tables.cpp", "tests/hostsim/hostsim.cpp"], extra=("-ffp-contract=off", "-fopenmp", "-lpthread", "-DRT_TEST_PROBES"))
     out = _run([exe, "11", "10"], 600)
+    assert out.strip()
+    out = _run([exe, "12", "6"], 600, env=dict(ENV, RT_GRID_WIDE="1"))   # the same sets through the wide table format (32-bit item lists)
     assert out.strip()

@@ -19,10 +19,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 
 
 def demangle_mk(name):
-    m = re.match(r"_ZN3rtk13rt_megakernelILb(\d)ELb(\d)ELb(\d)EEEvNS_5KArgsE", name)
+    m = re.match(r"_ZN3rtk13rt_megakernelILb(\d)ELb(\d)ELb(\d)ELb(\d)EEEvNS_5KArgsE", name)
     if m:
-        hl, simple, lds = (int(x) for x in m.groups())
-        return f"rt_megakernel<lights={hl}, simple_colour={simple}, lds_tables={lds}>"
+        hl, simple, lds, wide = (int(x) for x in m.groups())
+        return f"rt_megakernel<lights={hl}, simple_colour={simple}, lds_tables={lds}" + (", wide_tables=1>" if wide else ">")
     out = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
     return out.split("(")[0] if out else name
 

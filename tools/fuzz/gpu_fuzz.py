@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Development tool (GPU box): many adversarial / random worlds through the megakernel — grid walk (variant 0) against
 the reference's brute force on the GPU (variant 1), bit for bit, and both against the CPU oracle's NaN mask and values.
-    python tools/fuzz/gpu_fuzz.py [first_seed] [n_seeds]"""
+    python tools/fuzz/gpu_fuzz.py [first_seed] [n_seeds]
+FUZZ_WIDE=1: every world through the WIDE cell tables (32-bit item lists — what scenes of more than 65 535 spheres use) and the
+kernel's wide instantiations: librt_hip_probe.so with RT_GRID_WIDE=1 (the product library reads nothing from the environment)."""
 import os
 import sys
 
@@ -24,6 +26,11 @@ def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
     bad = 0
+    wide = os.environ.get("FUZZ_WIDE") == "1"
+    library = None
+    if wide:
+        os.environ["RT_GRID_WIDE"] = "1"
+        library = hip.probe_lib()
     kinds = ["adversarial"] + [f"fuzz{k}" for k in range(6)]
     for seed in range(first, first + n):
         kind = kinds[seed % len(kinds)]
@@ -37,7 +44,9 @@ def main():
         h, w = sc.c.height, sc.c.width
         imgs = []
         for variant in (0, 1):
-            gs = hip.HipScene(sc.ptr, 0)
+            gs = hip.HipScene(sc.ptr, 0, library=library)
+            if wide and kind != "adversarial":
+                assert gs.query("grid_wide") == 1
             gs.set_option("variant", variant)
             gs.set_option("tile_log2", [-1, 0, 1, 2, 3][seed % 5])
             gs.set_option("tile_batch", [0, 1, 2, 7, 64, 3, 0][seed % 7])       # tiles per queue atomic (the workgroup's stash)
@@ -57,7 +66,7 @@ def main():
         if not (same and vs_oracle):
             bad += 1
             print(f"seed {seed} kind {kind}: grid==brute {same}, vs oracle {vs_oracle}", flush=True)
-    print(f"gpu_fuzz: seeds {first}..{first + n - 1}: {bad} mismatching worlds")
+    print(f"gpu_fuzz{' (wide tables)' if wide else ''}: seeds {first}..{first + n - 1}: {bad} mismatching worlds")
     return 1 if bad else 0
 
 
