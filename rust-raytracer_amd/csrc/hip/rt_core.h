@@ -603,8 +603,12 @@ RT_HD int grid_begin(const GridDesc& G, V3 o, V3 d, GridWalk& w) {
     tn = rt_slab_max(tn, rt_slab_min(t1, t2));
     tf = rt_slab_min(tf, rt_slab_max(t1, t2));
   }
-  // the slab parameters carry the f32 reciprocal's relative error (< 4e-7): decide with 2^-12 slack
-  const double slack = 1.0 / 4096.0;
+  // the slab parameters carry the f32 reciprocal's relative error (conversion + 1 ulp: < 2.4e-7 = 2^-22): decide with 2^-16 slack.
+  // (2^-12 until round 5: the entry point is taken that fraction of the way back towards the origin, and a ray whose origin is
+  //  more than 2 * 4096 cells from the grid — back from the far side of the r = 1000 ground into a grid with thin cells — then
+  //  lands more than two cells outside it, fails the `sane` test below and takes the FULL SCAN: one such ray in a frame of a
+  //  2 x 10^5-sphere world cost 100 ms, profiles/r05_run22_grid_shape_probe.log.  Now: 2 * 65 536 cells.)
+  const double slack = 1.0 / 65536.0;
   w.t0 = __builtin_fma(-tn, slack, tn);  // never later than the true entry; >= 0
   if (__builtin_fma(fabs(tf), slack, tf) < w.t0) return GRID_MISS;
   bool sane = true;

@@ -78,6 +78,7 @@ def hostsim(abi):
     L.hostsim_u01_53.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.hostsim_sample_to_fixed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.hostsim_grid_info.argtypes = [C.POINTER(abi.RtScene), C.POINTER(C.c_uint32)]
+    L.hostsim_grid_mode.argtypes = [C.POINTER(abi.RtScene), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.hostsim_hit_world.argtypes = [C.POINTER(abi.RtScene), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]
 
     def render(scene_ptr, tiles=None, mode=1):

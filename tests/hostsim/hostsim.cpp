@@ -194,6 +194,15 @@ extern "C" int hostsim_grid_wide(const RtScene* scene) {
   return (int)t.grid.wide;
 }
 
+// how the walk of one ray begins (rt_core.h grid_begin): 0 = misses the grid, 1 = walks, 2 = numerically unsafe -> full scan; < 0: error / no grid
+extern "C" int hostsim_grid_mode(const RtScene* scene, const double o[3], const double d[3]) {
+  HostTables t;
+  if (!scene || !build_tables(*scene, t).empty()) return RT_ERR_INVALID;
+  if (t.grid.n[0] == 0u) return -100;
+  GridWalk w;
+  return grid_begin(t.grid, v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]), w);
+}
+
 // one ray against one scene through the grid and by brute force (adversarial tests):
 // out = {best_grid, best_brute}, t_out = {t_grid, t_brute}
 extern "C" int hostsim_hit_world(const RtScene* scene, const double o[3], const double d[3], int out[2], double t_out[2]) {

@@ -369,6 +369,42 @@ def test_grid_walk_adversarial_rays(hostsim, abi):
     assert n_hits > 0.3 * n_rays
 
 
+def test_rays_from_far_away_walk_the_grid(hostsim, abi, monkeypatch):
+    """A ray that comes back from the far side of the r = 1000 ground (a Glass sphere touching the ground refracts rays into
+    it; they leave it 2 000 units away) enters the grid from ~10^4 cells away when the cells are thin.  The entry point is
+    taken a fraction `slack` of the way back towards the origin; at 2^-12 (until round 5) such a ray landed more than two
+    cells outside the grid and took the full scan over every sphere — correct, and 100 ms for ONE ray of a frame of a
+    2 x 10^5-sphere world on the GPU.  At 2^-16 it walks — and finds what brute force finds."""
+    rng = np.random.default_rng(17)
+    sc, spheres = _random_scene(abi, rng, n=900, spread=25.0, r_lo=0.2, r_hi=0.2, big=1000.0)
+    for i in range(900):
+        spheres[i].center[1] = 0.2
+        spheres[i].radius = 0.2
+    monkeypatch.setenv("RT_GRID_N", "60,4,60")   # (tests/hostsim is built with -DRT_TEST_PROBES: thin cells, 0.1 units high)
+    info = (C.c_uint32 * 6)()
+    assert hostsim.hostsim_grid_info(C.byref(sc), info) == 0 and info[1] == 4
+    out = (C.c_int * 2)()
+    t_out = (C.c_double * 2)()
+    n_hit = 0
+    for trial in range(600):
+        i = int(rng.integers(900))
+        c = np.array(spheres[i].center[:])
+        # origin on the ground sphere's far side (y ~ -1000 .. -2000) or 10^3 .. 10^4 units away in any direction
+        if trial % 2:
+            a = rng.uniform(0.0, 0.45 * np.pi); phi = rng.uniform(0, 2 * np.pi)
+            o = np.array([1000.0 * np.sin(a) * np.cos(phi), -1000.0 - 1000.0 * np.cos(a), 1000.0 * np.sin(a) * np.sin(phi)])
+        else:
+            nrm = rng.standard_normal(3); nrm /= np.linalg.norm(nrm)
+            o = c + nrm * 10.0 ** rng.uniform(3, 4)
+        d = (c + rng.uniform(-1, 1, 3) * 0.3) - o
+        d *= 10.0 ** rng.uniform(-3, 1)
+        assert hostsim.hostsim_grid_mode(C.byref(sc), dvec(*o), dvec(*d)) in (0, 1), "a far ray took the full scan"
+        assert hostsim.hostsim_hit_world(C.byref(sc), dvec(*o), dvec(*d), out, t_out) == 0
+        assert out[0] == out[1] and (out[0] < 0 or t_out[0] == t_out[1]), (trial, out[:], t_out[:])
+        n_hit += out[1] >= 0
+    assert n_hit > 100
+
+
 def test_any_order_hit_equals_object_order_scan(hostsim, abi):
     """coincident and duplicated spheres: ties in t must go to the lowest object index
     (raytracer.rs:52-57 keeps the first of equals), whatever order the cells list them in"""
