@@ -42,6 +42,15 @@ def build_hip(force=False):
     probe = os.path.join(HERE, "librt_hip_probe.so")
     src = _srcs("csrc/hip/rt_hip_api.hip")
     deps = _srcs(*HIP_DEPS) + [os.path.join(ROOT, "include/rt_abi.h"), os.path.join(ROOT, "include/rt_abi_test.h")]
+    # (beside the file times: the source hash the libraries on disk were built from — a checkout or a clock that does not move
+    #  forward leaves times that say nothing)
+    try:
+        import json
+        built_from = json.load(open(os.path.join(HERE, "BUILD_INFO.json"))).get("kernel_src_hash")
+    except Exception:
+        built_from = None
+    if os.path.exists(os.path.join(ROOT, ".git")) and built_from != kernel_src_hash():
+        force = True
     jobs = []
     if force or _newer(out, deps):
         jobs.append(["hipcc", *HIPFLAGS, "-shared", *src, "-o", out])

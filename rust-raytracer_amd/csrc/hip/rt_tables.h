@@ -55,13 +55,13 @@ inline GridParams grid_params_from_env() {
   GridParams p;
 #if defined(RT_DEV_KNOBS) || defined(RT_TEST_PROBES)  // (librt_hip_probe.so — tests only — can put any world through the wide format)
   if (const char* e = std::getenv("RT_GRID_WIDE")) p.force_wide = std::atoi(e) != 0;
-  if (const char* e = std::getenv("RT_GRID_N")) std::sscanf(e, "%u,%u,%u", &p.force_n[0], &p.force_n[1], &p.force_n[2]);
 #endif
 #ifdef RT_DEV_KNOBS
   if (const char* e = std::getenv("RT_GRID_CELLS_PER_SPHERE")) p.cells_per_sphere = std::atof(e);
   if (const char* e = std::getenv("RT_GRID_MIN_SPHERES")) p.min_spheres = (uint32_t)std::atoi(e);
   if (const char* e = std::getenv("RT_GRID_LARGE_RATIO")) p.large_radius_ratio = std::atof(e);
   if (const char* e = std::getenv("RT_GRID_LARGE_CELLS")) p.large_cell_limit = (uint32_t)std::atoi(e);
+  if (const char* e = std::getenv("RT_GRID_N")) std::sscanf(e, "%u,%u,%u", &p.force_n[0], &p.force_n[1], &p.force_n[2]);
 #endif
   return p;
 }

@@ -60,6 +60,7 @@ def hostsim(abi):
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mfma", "-fopenmp", "-Wno-unknown-pragmas",
                         "-DRT_TEST_PROBES",   # (rt_tables.h: RT_GRID_WIDE=1 in the environment puts any world through the wide table format)
+                        "-DRT_DEV_KNOBS",     # (RT_GRID_N: a forced grid shape — test_rays_from_far_away_walk_the_grid)
                         "-shared", src, "-o", so], check=True)
     L = C.CDLL(so)
     L.hostsim_render.argtypes = [C.POINTER(abi.RtScene), C.POINTER(abi.RtRowTiles), C.c_void_p, C.c_void_p,

@@ -380,7 +380,7 @@ def test_rays_from_far_away_walk_the_grid(hostsim, abi, monkeypatch):
     for i in range(900):
         spheres[i].center[1] = 0.2
         spheres[i].radius = 0.2
-    monkeypatch.setenv("RT_GRID_N", "60,4,60")   # (tests/hostsim is built with -DRT_TEST_PROBES: thin cells, 0.1 units high)
+    monkeypatch.setenv("RT_GRID_N", "60,4,60")   # (tests/hostsim is built with -DRT_DEV_KNOBS: thin cells, 0.1 units high)
     info = (C.c_uint32 * 6)()
     assert hostsim.hostsim_grid_info(C.byref(sc), info) == 0 and info[1] == 4
     out = (C.c_int * 2)()
