@@ -115,3 +115,21 @@ def big_flat_world_json(n, rng, width=12, height=8, spp=2, depth=6, half=60.0):
     return json.dumps({"width": width, "height": height, "samples_per_pixel": spp, "max_depth": depth, "sky": {"texture": ""},
                        "camera": {"look_from": {"x": 13.0, "y": 2.0, "z": 3.0}, "look_at": {"x": 0.0, "y": 0.0, "z": 0.0}, "vup": {"x": 0.0, "y": 1.0, "z": 0.0},
                                   "vfov": 20.0, "aspect": 1.5}, "objects": objs})
+
+
+def crowded_cell_world_json(n_crowd=4300, n_other=300, seed=9, width=24, height=16, spp=2, depth=6):
+    """More spheres in ONE cell than the packed cell word can count (4 095): n_crowd nearly coincident small spheres, n_other
+    ordinary ones around them.  build_grid gives such a scene the wide tables (until round 5: no grid at all)."""
+    rng = np.random.default_rng(seed)
+    objs = [{"center": {"x": 0.0, "y": -1000.0, "z": 0.0}, "radius": 1000.0, "material": {"Lambertian": {"albedo": [0.5, 0.5, 0.5]}}}]
+    for i in range(n_crowd):
+        c = rng.normal(0.0, 0.01, 3)
+        objs.append({"center": {"x": float(c[0]), "y": 0.5 + float(c[1]), "z": float(c[2])}, "radius": 0.3 + 1e-4 * (i % 50),
+                     "material": {"Lambertian": {"albedo": [0.2 + 0.6 * (i % 3 == 0), 0.3, 0.7]}} if i % 5 else {"Glass": {"index_of_refraction": 1.5}}})
+    xs, zs = rng.uniform(-8, 8, n_other), rng.uniform(-8, 8, n_other)
+    for i in range(n_other):
+        objs.append({"center": {"x": float(xs[i]), "y": 0.2, "z": float(zs[i])}, "radius": 0.2,
+                     "material": {"Metal": {"albedo": [0.8, 0.7, 0.6], "fuzz": 0.2}} if i % 2 else {"Lambertian": {"albedo": [0.6, 0.3, 0.2]}}})
+    return json.dumps({"width": width, "height": height, "samples_per_pixel": spp, "max_depth": depth, "sky": {"texture": ""},
+                       "camera": {"look_from": {"x": 6.0, "y": 1.5, "z": 2.0}, "look_at": {"x": 0.0, "y": 0.4, "z": 0.0}, "vup": {"x": 0.0, "y": 1.0, "z": 0.0},
+                                  "vfov": 30.0, "aspect": 1.5}, "objects": objs})

@@ -516,6 +516,22 @@ def test_more_than_65535_spheres_take_the_wide_tables(hostsim, oracle, abi, host
     assert st_audit["kernel_ms"] == 0.0, "grid walk and brute force disagree on some segment"
 
 
+def test_a_cell_with_more_items_than_the_packed_word_counts(hostsim, oracle, abi, host):
+    """4 300 nearly coincident spheres share their cells: more than the 4 095 items a packed cell word can count.  Such a scene
+    takes the wide tables too (until round 5: no grid, the full scan for every ray of the scene)."""
+    from fuzz_worlds import crowded_cell_world_json
+    sc = host.Scene.loads(crowded_cell_world_json())
+    info = (C.c_uint32 * 6)()
+    assert hostsim.hostsim_grid_info(sc.ptr, info) == 0 and info[0] > 1 and info[3] <= 8
+    assert hostsim.hostsim_grid_wide(sc.ptr) == 1 and sc.c.n_spheres < 65535
+    o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+    rgb, lin, st = hostsim.render(sc.ptr, None, 3)
+    assert_parity(rgb, lin, o_rgb, o_lin, "crowded cell")
+    assert st["segments"] == o_st["segments"] and st["exact_tests"] < st["sphere_tests"]
+    _, _, st_audit = hostsim.render(sc.ptr, None, 4)
+    assert st_audit["kernel_ms"] == 0.0
+
+
 @pytest.fixture
 def wide_tables(monkeypatch):
     """RT_GRID_WIDE=1: the CPU build of the table builder (tests/hostsim, -DRT_TEST_PROBES) puts ANY world into the wide format"""

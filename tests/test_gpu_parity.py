@@ -464,6 +464,21 @@ def test_more_than_65535_spheres(gpu_render, oracle, abi, host):
     assert np.array_equal(rgb, b_rgb) and np.array_equal(lin, b_lin) and b_st["exact_tests"] == b_st["sphere_tests"]
 
 
+def test_a_cell_with_more_items_than_the_packed_word_counts(gpu_render, oracle, abi, host):
+    """4 300 nearly coincident spheres in one cell (the packed cell word counts 4 095): wide tables, the oracle's frame, the
+    brute-force variant's bits"""
+    from fuzz_worlds import crowded_cell_world_json
+    sc = host.Scene.loads(crowded_cell_world_json())
+    o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+    q = {}
+    rgb, lin, st = gpu_render(sc, query=q)
+    assert q["grid_wide"] == 1 and q["grid_large"] <= 8
+    assert_parity(rgb, lin, o_rgb, o_lin, "crowded cell", atol=pooled_atol(2))
+    assert st["segments"] == o_st["segments"] and st["exact_tests"] < st["sphere_tests"]
+    b_rgb, b_lin, _ = gpu_render(sc, variant=1)
+    assert np.array_equal(rgb, b_rgb) and np.array_equal(lin, b_lin)
+
+
 def test_200k_spheres_at_speed(gpu_render, host):
     """2 x 10^5 spheres (three times the packed format's limit) at the cover scene's density, 640 x 360, spp 16: the frame takes
     milliseconds, not the minutes of a full scan (2 x 10^5 tests per segment); printed for the record.  (A FLAT world of this size
