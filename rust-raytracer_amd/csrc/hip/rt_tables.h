@@ -42,7 +42,7 @@ struct HostTables {
 constexpr size_t GRID_LDS_TABLE_BUDGET = 88u * 1024u;
 struct GridParams {
   double cells_per_sphere = 0.0;   // target cell count = this * gridded spheres; 0 = automatic (below)
-  double large_radius_ratio = 4;   // |r| > ratio * median |r|  ->  `large` list (the biggest `max_large_by_radius` of them)
+  double large_radius_ratio = 4;   // |r| > ratio * median |r|: a candidate for the `large` list (at most `max_large_by_radius`, see build_grid_as)
   uint32_t max_large_by_radius = 8;
   uint32_t large_cell_limit = 512; // a sphere covering more cells than this -> `large` list
   uint32_t min_spheres = 24;       // fewer spheres than this: no grid, test them all
@@ -102,13 +102,26 @@ inline bool build_grid_as(const RtScene& sc, HostTables& t, const GridParams& gp
   // are tested by every ray instead of being gridded: without them the grid hugs the bulk (one
   // flat layer of cells around the small spheres), rays from above enter it right where they
   // come down, and a walk is ~2 steps instead of ~10 (measured 21.1 -> 16.1 ms).  Each one costs a
-  // wave-uniform exact test per ray, so only the biggest few qualify.
+  // wave-uniform exact test per ray, so only the biggest few qualify — and only if taking them out LEAVES a smaller bulk:
+  // the k <= max_large_by_radius biggest, k the largest count after which the radii drop by half or more.  (Until round 5: the
+  // biggest eight whatever came after them.  A world whose radii spread over decades then paid eight tests per ray for eight
+  // spheres no different from the hundreds left in the grid: 15.1 -> 8.1 tests per ray on the log-uniform 10^4-sphere world,
+  // 13.9 -> 6.6 on the bimodal one, tools/analysis/levels_estimate.cpp; BASELINE's scenes keep their lists: 1000 | 1 1 1 | 0.2 ...)
   {
     std::vector<std::pair<double, uint32_t>> big;
-    for (uint32_t i = 0; i < n; ++i)
-      if (!is_large[i] && std::fabs(sc.spheres[i].radius) > gp.large_radius_ratio * r_med) big.push_back({std::fabs(sc.spheres[i].radius), i});
+    double r_rest = 0.0;  // the largest radius that is no candidate
+    for (uint32_t i = 0; i < n; ++i) {
+      if (is_large[i]) continue;
+      const double r = std::fabs(sc.spheres[i].radius);
+      if (r > gp.large_radius_ratio * r_med) big.push_back({r, i}); else r_rest = std::max(r_rest, r);
+    }
     std::sort(big.begin(), big.end(), [](const std::pair<double, uint32_t>& a, const std::pair<double, uint32_t>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
-    for (size_t k = 0; k < big.size() && k < gp.max_large_by_radius; ++k) is_large[big[k].second] = 1;
+    size_t k_take = 0;
+    for (size_t k = 1; k <= big.size() && k <= gp.max_large_by_radius; ++k) {
+      const double next = k < big.size() ? big[k].first : r_rest;  // the biggest sphere left in the grid if k are taken
+      if (big[k - 1].first >= 2.0 * next) k_take = k;
+    }
+    for (size_t k = 0; k < k_take; ++k) is_large[big[k].second] = 1;
   }
   for (uint32_t i = 0; i < n; ++i) {
     const RtSphere& s = sc.spheres[i];
