@@ -367,6 +367,27 @@ def _device_place(torch, local_rank):
     return {"pci_bus_id": pci, "numa_node": numa, "peer_to_root": peer, "uuid": str(getattr(prop, "uuid", "")), "host": os.uname().nodename, "local_rank": local_rank}
 
 
+def _pin_to_device(place):
+    """One process per GPU: keep this rank's host threads on the CPUs of its GPU's NUMA node (what rt_hip_group does for its
+    rank threads inside the library; RT_GROUP_PIN=0: not).  Returns the number of CPUs pinned to, 0 = left alone."""
+    if os.environ.get("RT_GROUP_PIN") == "0" or not place.get("pci_bus_id") or not hasattr(os, "sched_setaffinity"):
+        return 0
+    try:
+        cpus = set()
+        for part in open(f"/sys/bus/pci/devices/{place['pci_bus_id']}/local_cpulist").read().strip().split(","):
+            if not part:
+                continue
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return 0
+        os.sched_setaffinity(0, cpus)
+        return len(cpus)
+    except Exception:
+        return 0
+
+
 def run_ranks(args):
     import torch
     import torch.distributed as dist
@@ -433,6 +454,7 @@ def run_ranks(args):
     # every rank renders on its own GPU: collect (host, PCI bus id / uuid) of each rank's device and compare
     ranks_devices = None
     place = _device_place(torch, local_rank)
+    place["pinned_cpus"] = _pin_to_device(place) if world > 1 else 0
     if collective:
         gathered = [None] * world
         dist.all_gather_object(gathered, place)
@@ -593,7 +615,8 @@ def run_ranks(args):
             out["transport_fallback_reason"] = transport_note or None
             out["per_rank"] = {"kernel_ms": [p["kernel_ms"] for p in per_rank], "elapsed_ms": [p["elapsed_ms"] for p in per_rank],
                                "samples_share": [p["samples_share"] for p in per_rank], "pci_bus_id": [g["pci_bus_id"] for g in ranks_devices],
-                               "numa_node": [g["numa_node"] for g in ranks_devices], "peer_to_root": [g["peer_to_root"] for g in ranks_devices]}
+                               "numa_node": [g["numa_node"] for g in ranks_devices], "pinned_cpus": [g.get("pinned_cpus", 0) for g in ranks_devices],
+                               "peer_to_root": [g["peer_to_root"] for g in ranks_devices]}
             out["frame_latency_ms"] = round(lat_ms, 4)      # ONE frame: render (slowest rank) + gather + row permutation, no overlap
             out["frame_latency_msamples_per_s"] = round(samples / lat_ms / 1e3, 1)
             if n1_kernel_ms is not None:

@@ -1087,6 +1087,7 @@ def test_bench_process_per_gpu_with_two_ranks_on_this_gpu():
     assert d["transport"] == "gloo-host" and d["transport_fallback"] is True and d["ranks_share_devices"] is True
     pr = d["per_rank"]
     assert len(pr["kernel_ms"]) == 2 and min(pr["kernel_ms"]) > 0 and abs(sum(pr["samples_share"]) - 1.0) < 1e-3
+    assert len(pr["pinned_cpus"]) == 2 and all(c >= 0 for c in pr["pinned_cpus"])   # (each rank's host thread on its GPU's NUMA node when sysfs names one)
     samples = 1200 * 800 * 128
     assert abs(d["value"] - samples / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * d["value"]
     assert d["n1_kernel_ms"] > 0 and d["frame_latency_ms"] > 0 and d["segments_per_sample"] > 2.0
