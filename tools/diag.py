@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--lib", default="", help="alternative librt_hip .so (an A/B build)")
     ap.add_argument("--shard", default="", help="rank,world: render only that rank's interleaved 8-row tiles (multi-GPU emulation)")
     ap.add_argument("--procedural", type=int, default=0, help="use the procedural world with this `half` (50 -> ~10 000 spheres)")
+    ap.add_argument("--radii", default="uniform", help="procedural world: uniform | loguniform | bimodal (scenes/procedural.py)")
     a = ap.parse_args()
     import torch
     os.chdir(ROOT)
@@ -47,8 +48,8 @@ def main():
     if a.procedural:
         sys.path.insert(0, os.path.join(ROOT, "scenes"))
         import procedural
-        sc = pkg.host.Scene.loads(procedural.make_json(width=a.width or 3840, height=a.height or 2160, spp=a.spp or 8, half=a.procedural, seed=0))
-        a.scene = f"procedural_half{a.procedural}"
+        sc = pkg.host.Scene.loads(procedural.make_json(width=a.width or 3840, height=a.height or 2160, spp=a.spp or 8, half=a.procedural, seed=0, radii=a.radii))
+        a.scene = f"procedural_half{a.procedural}" + ("" if a.radii == "uniform" else "_" + a.radii)
     else:
         sc = pkg.host.Scene.load(a.scene)
     if a.width:
