@@ -516,6 +516,37 @@ def test_more_than_65535_spheres_take_the_wide_tables(hostsim, oracle, abi, host
     assert st_audit["kernel_ms"] == 0.0, "grid walk and brute force disagree on some segment"
 
 
+def test_the_every_ray_list_takes_big_spheres_only_when_a_radius_gap_follows(hostsim, abi, load_scene):
+    """rt_tables.h build_grid: the `large` list (spheres every ray tests instead of finding them in the grid) takes the k <= 8
+    biggest candidates, k the largest count after which the radii drop by half or more — the bulk left in the grid must be
+    smaller for the promotion to buy anything.  The cover scene keeps ground + three r = 1 spheres; a world whose big spheres
+    are a continuum keeps the ground only (until round 5: the biggest eight, eight tests per ray for nothing); outliers above
+    a crowd of medium spheres are taken, the crowd is not."""
+    info = (C.c_uint32 * 6)()
+    sc = load_scene("cover", 60, 40, 1, 5)
+    assert hostsim.hostsim_grid_info(sc.ptr, info) == 0 and info[3] == 4
+
+    def world(radii):
+        rng = np.random.default_rng(len(radii))
+        spheres = (abi.RtSphere * (len(radii) + 1))()
+        for i, r in enumerate(radii):
+            spheres[i].center[:] = [float(rng.uniform(-40, 40)), float(r), float(rng.uniform(-40, 40))]
+            spheres[i].radius = float(r)
+            spheres[i].kind = abi.RT_MAT_LAMBERTIAN
+        spheres[len(radii)].center[:] = [0.0, -1000.0, 0.0]
+        spheres[len(radii)].radius = 1000.0
+        scn = abi.RtScene(abi_version=abi.RT_ABI_VERSION, width=4, height=4, samples_per_pixel=1, max_depth=2, spheres=spheres, n_spheres=len(spheres))
+        assert hostsim.hostsim_grid_info(C.byref(scn), info) == 0 and info[0] > 0
+        return info[3]
+
+    bulk = [0.2] * 400
+    assert world(bulk + list(np.exp(np.random.default_rng(1).uniform(np.log(0.9), np.log(5.0), 60)))) == 1   # a continuum of big spheres: the ground only
+    assert world(bulk + [3.0] * 40) == 1                                # forty equal big spheres: none of them
+    assert world(bulk + [10.0] * 3 + [1.0] * 15) == 4                   # three outliers above a crowd of fifteen: ground + the three
+    assert world(bulk + [1.0] * 3) == 4                                 # the cover scene's shape
+    assert world(bulk + [1.0] * 9) == 1                                 # more candidates than the list holds and no gap inside them
+
+
 def test_a_cell_with_more_items_than_the_packed_word_counts(hostsim, oracle, abi, host):
     """4 300 nearly coincident spheres share their cells: more than the 4 095 items a packed cell word can count.  Such a scene
     takes the wide tables too (until round 5: no grid, the full scan for every ray of the scene)."""
