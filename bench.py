@@ -294,6 +294,16 @@ def run_group(args):
                      "peer_to_root": [r["peer_to_root"] for r in ranks]},
         "git_head": _git_head(),
     }
+    # the N > 1 line parses like the N = 1 line: the roofline of the dominant kernel per rank, and the CPU baseline (a pointer)
+    out["roofline"] = _group_roofline("cfg2", args.gpus, out["per_rank"]["kernel_ms"]) if headline else None
+    out["cpu_baseline"] = _n1_cpu_baseline_pointer()
+    if headline and not args.no_other_configs:
+        try:   # (the extra must never cost the line)
+            out["configs3_on_group"] = configs3_on_group_inlib(pkg, args.gpus, devs[0])
+        except BaseException as e:   # noqa: BLE001
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            out["configs3_on_group"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return json.dumps(out)
 
 
@@ -312,14 +322,23 @@ def _init_collective(torch, dist, rank, world, dev):
     if forced == "gloo":
         ok, why = 0, "RT_BENCH_FORCE_TRANSPORT=gloo"
     else:
-        os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")   # a collective that hangs raises after its timeout instead of taking the process down
+        # The self-test must not hang the run: its gather is issued asynchronously and POLLED against a deadline (a collective
+        # that never completes leaves is_completed() False and the ranks agree on the fall-back over gloo).  The timed loop keeps
+        # torch's default wait semantics — work.wait() enqueues a stream wait, the host runs on — which the two-deep pipeline of
+        # FramePipeline relies on (TORCH_NCCL_BLOCKING_WAIT, set process-wide until round 5, would have made every wait a host block).
         try:
             if os.environ.get("RT_BENCH_INJECT_NCCL_FAILURE") == "1":
                 raise RuntimeError("injected (RT_BENCH_INJECT_NCCL_FAILURE=1)")
             pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))   # nccl == RCCL on ROCm; communicators come up with the first collective
             probe = torch.full((4096,), rank + 1, dtype=torch.uint8, device=dev)
             outs = [torch.zeros(4096, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-            dist.gather(probe, outs, dst=0, group=pg)
+            work = dist.gather(probe, outs, dst=0, group=pg, async_op=True)
+            deadline = time.perf_counter() + float(os.environ.get("RT_BENCH_SELFTEST_TIMEOUT_S", "120"))
+            while not work.is_completed():
+                if time.perf_counter() > deadline:
+                    raise TimeoutError("self-test gather did not complete")
+                time.sleep(0.002)
+            work.wait()
             torch.cuda.synchronize()
             if rank == 0:
                 got = [int(o[-1].item()) for o in outs]
@@ -522,6 +541,16 @@ def run_ranks(args):
             n1_kernel_ms = sorted(ks[1:])[1]
         dist.barrier()
 
+    # ---- BASELINE configs[3] (the workload BASELINE.json names for the 8-GPU node) on the SAME ranks: 1 warm + 3 blocking frames
+    c3 = None
+    if world > 1 and headline and not args.no_other_configs:
+        try:
+            c3 = _configs3_on_ranks(torch, dist, pkg, rdist, rank, world, local_rank, dev, stream, data_group, transport)
+        except BaseException as e:   # noqa: BLE001 — (every rank raises or none: the calls inside are collective)
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            c3 = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     t = torch.tensor([elapsed, kernel_ms, float(st["segments"]), float(st["exact_tests"]), float(st["grid_steps"]), lat_ms or 0.0],
                      dtype=torch.float64)   # (CPU: the default group is gloo)
     per_rank = None
@@ -623,6 +652,12 @@ def run_ranks(args):
                 out["n1_kernel_ms"] = round(n1_kernel_ms, 4)                      # the whole frame on rank 0's GPU alone, same process
                 out["speedup_vs_n1_latency"] = round(n1_kernel_ms / lat_ms, 3)    # the north star's ">= 6x at 8 GPUs" figure
                 out["speedup_vs_n1_pipelined"] = round(n1_kernel_ms / ms_per_step, 3)
+            if world > 1:   # the N > 1 line parses like the N = 1 line
+                if headline:
+                    out["roofline"] = _group_roofline("cfg2", world, [p["kernel_ms"] for p in per_rank])
+                out["cpu_baseline"] = _n1_cpu_baseline_pointer()
+                if c3 is not None:
+                    out["configs3_on_group"] = c3
         if world == 1:
             # the frame as a host caller sees it with the scene resident — kernel + the 2.88 MB
             # device-to-host copy of the RGB8 frame (pageable numpy buffer) — reported beside `value`, never as it
@@ -660,6 +695,7 @@ def run_ranks(args):
             out["other_configs"] = extra(other_configs, pkg, torch, dev, stream)
             out["mixed_radius_worlds"] = extra(mixed_radius_worlds, pkg, torch, dev, stream)
             out["cli"] = extra(cli_wall_times)
+            out["animation"] = extra(animation_runs, kernel_ms, out["first_frame_kernel_ms"])
             out["cli_note"] = ("median of 3 fresh processes each; the HIP runtime's start-up in a fresh process (hip_init_ms) varies 50 - 230 ms from run to run "
                                "on these boxes and is most of the spread of wall_ms (profiles/r05_run14_cli_wall.log: 150 - 160 ms wall is the typical figure)")
         if world == 1 and not args.no_cpu_baseline:
@@ -742,9 +778,21 @@ def other_configs(pkg, torch, dev, stream):
         if pm is not None:
             m = pm[1].get("mean_per_launch", {})
             if "SQ_THREAD_CYCLES_VALU" in m:
-                rec["lane_slot_frac"] = round(m["SQ_THREAD_CYCLES_VALU"] / (k * 1e-3) / 1e12 / PEAK_LANE_SLOTS_T, 4)
+                # the counters' lane cycles over BOTH clocks: the counter passes' own kernel time (counters on: up to 19 % slower
+                # on the 1 ms test scene) and this run's — the first is the fraction that was measured, the second an upper bound
+                thr = m["SQ_THREAD_CYCLES_VALU"]
+                if pm[1].get("kernel_ms"):
+                    rec["lane_slot_frac_on_counter_clock"] = round(thr / (pm[1]["kernel_ms"] * 1e-3) / 1e12 / PEAK_LANE_SLOTS_T, 4)
+                    rec["counter_run_kernel_ms"] = pm[1]["kernel_ms"]
+                rec["lane_slot_frac_on_this_runs_clock"] = round(thr / (k * 1e-3) / 1e12 / PEAK_LANE_SLOTS_T, 4)
+                rec["lane_slot_frac"] = rec.get("lane_slot_frac_on_counter_clock", rec["lane_slot_frac_on_this_runs_clock"])
+                rec["same_kernel_sources"] = (pm[1].get("kernel_src_hash") == _build_info("kernel_src_hash")) if pm[1].get("kernel_src_hash") else None
             if pm[1].get("hbm_bytes_per_launch") is not None:
-                rec["traffic"] = pm[1]["hbm_bytes_per_launch"]
+                # FETCH_SIZE / WRITE_SIZE count the L2's fabric-side requests: L2 MISSES, whether the Infinity Cache (256 MiB: every
+                # texture of every BASELINE config fits) or HBM serves them — not HBM bytes (MI355X_MICROARCH.md, HBM section)
+                rec["l2_miss_bytes"] = pm[1]["hbm_bytes_per_launch"]
+                rec["hbm_bytes_compulsory"] = 3 * s.c.width * s.c.height + g.query("table_bytes") + g.query("texel_bytes")
+                rec["l2_miss_note"] = "fabric-side L2 requests (FETCH_SIZE x 2 + WRITE_SIZE); the working set (texels + framebuffer) fits the 256 MiB Infinity Cache, so HBM sees about hbm_bytes_compulsory"
             if pm[1].get("l2_hit_rate") is not None:
                 rec["l2_hit_rate"] = pm[1]["l2_hit_rate"]
             rec["counters_source"] = os.path.relpath(pm[0], ROOT)
@@ -818,6 +866,190 @@ def cli_wall_times():
                     "hip_init_ms": round(m["hip_init_ms"], 1), "hip_wait_ms": round(m.get("hip_wait_ms", m["hip_init_ms"]), 1), "setup_ms": round(m["setup_ms"], 1), "frame_ms": round(m["frame_ms"], 2),
                     "kernel_ms": round(m["kernel_ms"], 2), "png_ms": round(m["png_ms"], 2), "runs": len(runs)})
     return res
+
+
+def animation_runs(steady_kernel_ms, first_frame_kernel_ms, frames=32, orbit=3.0):
+    """SURVEY §8 f4 — the reference's headline workflow (README.md:43-57 `anim/frame_%03d.png`, main.rs:17): `raytracer <scene>
+    <prefix> --frames 32 --orbit 3` in a FRESH process for the headline config and the reference's test scene: frames per second
+    from the first submit to the last PNG on disk, the per-frame kernel times under a MOVING camera (the tile-queue order is
+    learned per view: does a 3 degree step keep it?), the PNG writer's times, and what bounds the run:
+    overlap_efficiency = frames/s x max(kernel, png) — 1.0 = the slower of the two stages is never idle."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "rust-raytracer_amd", "raytracer")
+    res = []
+    if not os.path.exists(exe):
+        return res
+    med = lambda v: sorted(v)[len(v) // 2]   # noqa: E731
+    for name, scene, steady, first in (("cfg2 cover 1200x800 spp128", HEADLINE, steady_kernel_ms, first_frame_kernel_ms),
+                                       ("cfg1 test_scene 800x600 spp16 (lights, textures)", "scenes/cfg1_test_800x600_spp16.json", None, None)):
+        with tempfile.TemporaryDirectory() as td:
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, scene, os.path.join(td, "frame"), "--frames", str(frames), "--orbit", str(orbit)], capture_output=True, text=True,
+                               cwd=ROOT, env=dict(os.environ, RT_STATS="1"), timeout=300)
+            wall = time.perf_counter() - t0
+            n_png = len([f for f in os.listdir(td) if f.endswith(".png")])
+            png_bytes = sum(os.path.getsize(os.path.join(td, f)) for f in os.listdir(td))
+        if r.returncode != 0:
+            res.append({"scene": name, "error": r.stderr[-300:]})
+            continue
+        st = json.loads([l for l in r.stderr.splitlines() if l.startswith('{"animation"')][-1])
+        k, pz = st["kernel_ms"], st["png_ms"]
+        moving = k[2:] if len(k) > 4 else k          # (frames 0, 1: no previous frame's order yet)
+        rec = {"scene": name, "command": f"raytracer {scene} <prefix> --frames {frames} --orbit {orbit:g}", "frames": st["frames"], "pngs_on_disk": n_png,
+               "frames_per_s": round(st["frames_per_s"], 2), "ms_per_frame": round(1e3 / st["frames_per_s"], 3),
+               "process_wall_s": round(wall, 3), "frames_per_s_incl_process_startup": round(st["frames"] / wall, 2), "setup_ms": round(st["setup_ms"], 1),
+               "kernel_ms_moving_camera": {"median": round(med(moving), 3), "min": round(min(moving), 3), "max": round(max(moving), 3), "first_frame": round(k[0], 3)},
+               "kernel_ms_series": [round(x, 2) for x in k],
+               "png_ms": {"median": round(med(pz), 2), "max": round(max(pz), 2)}, "png_writers": st.get("png_writers"), "png_mb_per_frame": round(png_bytes / max(1, n_png) / 1e6, 3),
+               "bound_by": "kernel" if med(moving) >= med(pz) / max(1, st.get("png_writers") or 1) else "png",
+               "overlap_efficiency": round(st["frames_per_s"] * max(med(moving), med(pz) / max(1, st.get("png_writers") or 1)) / 1e3, 3)}
+        if steady:
+            rec["steady_state_kernel_ms_same_view"] = round(steady, 3)
+            rec["moving_over_steady"] = round(med(moving) / steady, 4)
+            rec["first_frame_kernel_ms_fixed_order"] = first
+        res.append(rec)
+    return res
+
+
+def _n1_cpu_baseline_pointer():
+    """N > 1 lines: the CPU baseline of the newest committed N = 1 bench line (profiles/rNN_runM_bench.json) — a pointer, not a second
+    20 s oracle run inside a scaling measurement"""
+    def run_key(p):
+        b = os.path.basename(p)
+        run = re.search(r"run(\d+)", b)
+        return (b.split("_")[0], int(run.group(1)) if run else -1)
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")), key=run_key, reverse=True):
+        try:
+            j = json.loads(open(p).read().strip().splitlines()[-1])
+        except Exception:
+            continue
+        cb = j.get("cpu_baseline")
+        if j.get("n_gpus") == 1 and isinstance(cb, dict) and cb.get("value"):
+            return {"value": cb["value"], "unit": cb.get("unit", "Msamples/s"), "cores": cb.get("cores"), "kind": cb.get("kind", "port"),
+                    "sample": cb.get("sample"), "source": os.path.relpath(p, ROOT),
+                    "note": "pointer to the N = 1 line's measurement (same C oracle, that box's host cores); not re-timed inside the scaling run"}
+    return None
+
+
+def _group_roofline(key, n_ranks, rank_kernel_ms):
+    """N > 1 lines: the executed-basis roofline per RANK — the counters of the whole frame's launch (profiles/, one GPU) split evenly
+    over the ranks (interleaved 2-scanline tiles: within +-2 %), each over ITS kernel time of this run"""
+    pm = _latest_pmc() if key == "cfg2" else (_scene_pmc(key) or (None, None))
+    roof = {"bound": "valu", "kernel": "rt_megakernel", "unit": "T lane-slots/s", "peak": round(PEAK_LANE_SLOTS_T, 2), "achieved": None, "frac": None, "traffic": None,
+            "note": "per rank: SQ_THREAD_CYCLES_VALU of the whole frame's launch (rocprofv3 --pmc, one GPU, profiles/) / n_ranks / that rank's kernel time of THIS run; "
+                    "frac = the slowest rank's (the one the frame waits for); peak per GPU"}
+    if pm is None or pm[1] is None or not rank_kernel_ms:
+        return roof
+    m = pm[1].get("mean_per_launch", {})
+    thr = m.get("SQ_THREAD_CYCLES_VALU")
+    if not thr:
+        return roof
+    per_rank = [thr / n_ranks / (k * 1e-3) / 1e12 / PEAK_LANE_SLOTS_T if k > 0 else None for k in rank_kernel_ms]
+    slow = max(rank_kernel_ms)
+    roof["achieved"] = round(thr / n_ranks / (slow * 1e-3) / 1e12, 3)
+    roof["frac"] = round(thr / n_ranks / (slow * 1e-3) / 1e12 / PEAK_LANE_SLOTS_T, 4)
+    roof["per_rank_frac"] = [round(x, 4) if x is not None else None for x in per_rank]
+    roof["counters"] = {"SQ_THREAD_CYCLES_VALU_whole_frame": thr, "source": os.path.relpath(pm[0], ROOT), "kernel_ms_of_that_run": pm[1].get("kernel_ms"),
+                        "same_kernel_sources": (pm[1].get("kernel_src_hash") == _build_info("kernel_src_hash")) if pm[1].get("kernel_src_hash") else None}
+    if pm[1].get("hbm_bytes_per_launch") is not None:
+        roof["traffic"] = pm[1]["hbm_bytes_per_launch"] / n_ranks
+    return roof
+
+
+def _configs3_on_ranks(torch, dist, pkg, rdist, rank, world, local_rank, dev, stream, data_group, transport):
+    """process-per-GPU form of configs3_on_group_inlib: every rank renders its interleaved tiles of BASELINE configs[3], ONE gather
+    per frame on the run's data group; frame time = barrier -> frame assembled on rank 0 -> barrier (max over ranks)."""
+    sc = pkg.host.Scene.load(CONFIGS3)
+    W, H, SPP = sc.c.width, sc.c.height, sc.c.samples_per_pixel
+    gs = pkg.hip.HipScene(sc.ptr, local_rank)
+    tiles = rdist.shard(rank, world)
+    pipe = rdist.FramePipeline(H, W, rank, world, dev, group=data_group, host_staged=transport == "gloo-host")
+    fr, kn = [], []
+    frame0 = None
+    for i in range(4):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        buf, _ = pipe.begin(i)
+        gs.render(buf.data_ptr(), 0, tiles, stream.cuda_stream)
+        pipe.submit(i)
+        frames = pipe.drain()
+        torch.cuda.synchronize()
+        dist.barrier()
+        fr.append((time.perf_counter() - t0) * 1e3)
+        kn.append(gs.wait()["kernel_ms"])
+        if rank == 0:
+            frame0 = frames[0]
+    my = {"kernel_ms": sorted(kn[1:])[1], "frame_ms": sorted(fr[1:])[1]}
+    allr = [None] * world
+    dist.all_gather_object(allr, my)
+    n1, identical = None, None
+    if rank == 0:
+        full = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+        for _ in range(2):
+            gs.render(full.data_ptr(), 0, None, stream.cuda_stream)
+            n1 = gs.wait()["kernel_ms"]
+        identical = bool(torch.equal(frame0.to(full.device), full))
+    dist.barrier()
+    gs.close()
+    if rank != 0:
+        return None
+    frame_ms = max(a["frame_ms"] for a in allr)
+    per_rank = [round(a["kernel_ms"], 3) for a in allr]
+    rec = {"workload": f"{os.path.basename(CONFIGS3)}: {W}x{H} spp {SPP} depth {sc.c.max_depth}, {sc.c.n_spheres} spheres, earth/moon + sky textures (BASELINE configs[3])",
+           "frames": "1 warm + 3 blocking (median)", "frame_ms": round(frame_ms, 3), "kernel_ms": max(per_rank), "msamples_per_s": round(W * H * SPP / frame_ms / 1e3, 1),
+           "n1_kernel_ms": round(n1, 3), "speedup_vs_n1": round(n1 / frame_ms, 3), "per_rank": {"kernel_ms": per_rank}, "transport": transport,
+           "frame_identical_to_n1": identical, "roofline": _group_roofline("cfg4", world, per_rank)}
+    if not identical:
+        rec["error"] = "the assembled frame differs from the single launch"
+    return rec
+
+
+CONFIGS3 = "scenes/cfg4_cover_4k_textured_spp512.json"   # BASELINE configs[3]: cover 3840x2160 spp 512 textured, row-tiled across the GPUs
+
+
+def configs3_on_group_inlib(pkg, n_gpus, first_device):
+    """BASELINE configs[3] — the workload BASELINE.json names for 8 GPUs — on an in-library group of the SAME ranks: 1 warm + 3
+    blocking frames (submit -> assembled in HBM of the first device), the slowest rank's kernel, every rank's kernel, and the
+    whole frame in ONE launch on the first device (second of two frames) for the speed-up."""
+    hip, host = pkg.hip, pkg.host
+    sc = host.Scene.load(CONFIGS3)
+    W, H, SPP = sc.c.width, sc.c.height, sc.c.samples_per_pixel
+    samples = W * H * SPP
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        grp = hip.HipGroup(sc.ptr, n_gpus)
+    finally:
+        _flush_c_stdio()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+    grp.render()
+    fr, kn, per_rank = [], [], None
+    for _ in range(3):
+        st = grp.render()
+        fr.append(st["frame_ms"]); kn.append(st["kernel_ms"])
+        per_rank = [round(r["kernel_ms"], 3) for r in grp.ranks()]
+    info = grp.info()
+    frame, _ = grp.render_to_host()
+    grp.close()
+    one = hip.HipScene(sc.ptr, first_device)
+    one.render_to_host()
+    ref, st1 = one.render_to_host()
+    one.close()
+    import numpy as np
+    identical = bool(np.array_equal(frame, ref))
+    med = lambda v: sorted(v)[len(v) // 2]   # noqa: E731
+    rec = {"workload": f"{os.path.basename(CONFIGS3)}: {W}x{H} spp {SPP} depth {sc.c.max_depth}, {sc.c.n_spheres} spheres, earth/moon + sky textures (BASELINE configs[3])",
+           "frames": "1 warm + 3 blocking (median)", "frame_ms": round(med(fr), 3), "kernel_ms": round(med(kn), 3), "msamples_per_s": round(samples / med(fr) / 1e3, 1),
+           "n1_kernel_ms": round(st1["kernel_ms"], 3), "speedup_vs_n1": round(st1["kernel_ms"] / med(fr), 3), "per_rank": {"kernel_ms": per_rank},
+           "transport": info["transport"], "frame_identical_to_n1": identical,
+           "roofline": _group_roofline("cfg4", n_gpus, per_rank)}
+    if not identical:
+        rec["error"] = f"the {n_gpus}-rank frame differs from the single launch in {int((frame != ref).sum())} bytes"
+    return rec
 
 
 if __name__ == "__main__":

@@ -12,11 +12,13 @@
 // [--orbit DEG]` renders N frames to `<output_prefix>_%03d.png` — the file naming main.rs:17
 // keeps commented out and README.md:43-57 / "Make animation" feed to ffmpeg — turning the camera
 // around look_at by DEG per frame (default 360/N).  The scene is uploaded once and stays in HBM;
-// the PNG of frame i is encoded on a host thread while the GPU renders frame i+1.  With RT_GPUS=G every frame is sharded
+// the PNG of frame i is encoded on writer threads (RT_ANIM_WRITERS, default 2) while the GPU renders frame i+1.  With RT_GPUS=G every frame is sharded
 // over the G devices and frames are pipelined two deep (RT_ANIM=sharded, default), or the frames are distributed over the
-// devices, each rendering whole frames (RT_ANIM=frames); RT_STATS=1 prints frames per second to stderr.
+// devices, each rendering whole frames (RT_ANIM=frames); RT_STATS=1 prints frames per second and the per-frame kernel / frame / PNG
+// times to stderr (one JSON line).
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,56 +49,138 @@ std::string frame_name(const char* prefix, int f) {
   std::snprintf(name, sizeof name, "%s_%03d.png", prefix, f);  // main.rs:17
   return name;
 }
-void report(const char* mode, int frames, unsigned gpus, double wall_s) {
-  if (std::getenv("RT_STATS"))
-    std::fprintf(stderr, "{\"animation\":\"%s\",\"frames\":%d,\"n_gpus\":%u,\"wall_s\":%.4f,\"frames_per_s\":%.3f}\n", mode, frames, gpus, wall_s,
-                 frames / wall_s);
+double ms_between(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+
+// What an animation run reports under RT_STATS=1 (one JSON line on stderr): frames per second disk to disk, and per frame the
+// kernel (slowest rank), the frame as the reference times it, and its PNG — which of the two bounds the run is then on the line.
+struct AnimStats {
+  std::mutex mu;
+  std::vector<double> kernel_ms, frame_ms, png_ms;
+  explicit AnimStats(int n) : kernel_ms(n, 0.0), frame_ms(n, 0.0), png_ms(n, 0.0) {}
+  void report(const char* mode, int frames, unsigned gpus, unsigned writers, double wall_s, double setup_ms) {
+    if (!std::getenv("RT_STATS")) return;
+    std::string s;
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "{\"animation\":\"%s\",\"frames\":%d,\"n_gpus\":%u,\"png_writers\":%u,\"setup_ms\":%.3f,\"wall_s\":%.4f,\"frames_per_s\":%.3f", mode, frames, gpus,
+                  writers, setup_ms, wall_s, frames / wall_s);
+    s = buf;
+    auto arr = [&](const char* key, const std::vector<double>& v) {
+      s += std::string(",\"") + key + "\":[";
+      for (int i = 0; i < frames && i < (int)v.size(); ++i) { std::snprintf(buf, sizeof buf, "%s%.3f", i ? "," : "", v[i]); s += buf; }
+      s += "]";
+    };
+    arr("kernel_ms", kernel_ms); arr("frame_ms", frame_ms); arr("png_ms", png_ms);
+    s += "}\n";
+    std::fputs(s.c_str(), stderr);
+  }
+};
+
+// PNG writers of an animation: W threads (RT_ANIM_WRITERS, default 2) take finished frames off a queue; a frame's host buffer
+// goes back to the free list when its file is on disk.  A frame's PNG is itself deflated in parallel bands (scene.cpp), so one
+// writer keeps up with the headline frame; the second one is for frames whose kernel is shorter than their PNG (the
+// reference's 1 ms test scene).
+struct PngWriters {
+  struct Job { int frame; uint8_t* px; };
+  std::mutex mu;
+  std::condition_variable cv_job, cv_free;
+  std::vector<Job> jobs;            // FIFO (few entries)
+  std::vector<uint8_t*> free_bufs;
+  std::vector<std::thread> th;
+  bool quit = false;
+  int write_rc = RT_OK;
+  std::string write_err;
+  PngWriters(unsigned W, const char* prefix, uint32_t w, uint32_t h, AnimStats* stats) {
+    for (unsigned i = 0; i < W; ++i)
+      th.emplace_back([this, prefix, w, h, stats]() {
+        for (;;) {
+          Job j;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_job.wait(lk, [&] { return quit || !jobs.empty(); });
+            if (jobs.empty()) return;
+            j = jobs.front(); jobs.erase(jobs.begin());
+          }
+          const auto t0 = std::chrono::steady_clock::now();
+          const int rc = rt_png_write_rgb8(frame_name(prefix, j.frame).c_str(), j.px, w, h);
+          const double ms = ms_between(t0, std::chrono::steady_clock::now());
+          { std::lock_guard<std::mutex> lk(stats->mu); if (j.frame < (int)stats->png_ms.size()) stats->png_ms[j.frame] = ms; }
+          std::lock_guard<std::mutex> lk(mu);
+          if (rc != RT_OK && write_rc == RT_OK) { write_rc = rc; write_err = rt_host_last_error(); }
+          free_bufs.push_back(j.px);
+          cv_free.notify_one();
+        }
+      });
+  }
+  uint8_t* take_buffer() {  // blocks while every buffer is in flight or waiting for its PNG
+    std::unique_lock<std::mutex> lk(mu);
+    cv_free.wait(lk, [&] { return !free_bufs.empty(); });
+    uint8_t* b = free_bufs.back(); free_bufs.pop_back();
+    return b;
+  }
+  void give_buffer(uint8_t* b) { std::lock_guard<std::mutex> lk(mu); free_bufs.push_back(b); }
+  void push(int frame, uint8_t* px) { { std::lock_guard<std::mutex> lk(mu); jobs.push_back({frame, px}); } cv_job.notify_one(); }
+  bool failed() { std::lock_guard<std::mutex> lk(mu); return write_rc != RT_OK; }
+  void finish() {
+    { std::lock_guard<std::mutex> lk(mu); quit = true; }
+    cv_job.notify_all();
+    for (auto& t : th) t.join();
+    th.clear();
+  }
+};
+unsigned anim_writers() {
+  const char* e = std::getenv("RT_ANIM_WRITERS");
+  const long v = e ? std::strtol(e, nullptr, 10) : 2;
+  return v < 1 ? 1u : (v > 16 ? 16u : (unsigned)v);
 }
 
 // Every frame SHARDED over the RT_GPUS devices (rt_hip_group_*), frames pipelined two deep: frame f+1 is submitted before
 // frame f is collected, so f's gather + de-interleave + device-to-host copy run under f+1's kernels, and f's PNG is encoded
-// on a host thread meanwhile.  Three host buffers: two frames in flight + one being written.
+// on the writer threads meanwhile.  2 + W host buffers: two frames in flight + one per writer.
 int animate_sharded(RtSceneFile* sf, const char* prefix, int frames, double orbit_deg) {
   RtScene* sc = rt_scene_get_mut(sf);
   RtHipGroup* hs = nullptr;  // the scene resident on RT_GPUS devices (default 1)
+  const auto t_create = std::chrono::steady_clock::now();
   int rc = rt_hip_group_create(sc, 0, &hs);
   if (rc != RT_OK) { std::fprintf(stderr, "render failed: %s: %s\n", rt_strerror(rc), rt_hip_last_error()); return 101; }
   const auto t_begin = std::chrono::steady_clock::now();
   double cam[11];
   rt_scene_camera(sf, cam);
   const size_t bytes = (size_t)sc->width * sc->height * 3;
-  std::vector<uint8_t> buf[3] = {std::vector<uint8_t>(bytes), std::vector<uint8_t>(bytes), std::vector<uint8_t>(bytes)};
-  std::thread writer;
-  int write_rc = RT_OK, status = 0;
-  const uint32_t w = sc->width, h = sc->height;
-  auto finish = [&](int f) -> bool {  // collect frame f, print its two lines, hand its pixels to the PNG writer
+  const unsigned W = anim_writers();
+  std::vector<std::vector<uint8_t>> store(2 + W, std::vector<uint8_t>(bytes));
+  AnimStats stats(frames);
+  PngWriters writers(W, prefix, sc->width, sc->height, &stats);
+  for (auto& b : store) writers.give_buffer(b.data());
+  int status = 0;
+  std::vector<uint8_t*> in_flight;  // oldest first
+  auto finish = [&](int f) -> bool {  // collect frame f, print its two lines, hand its pixels to the PNG writers
     RtStats st{};
     const int rc = rt_hip_group_collect(hs, &st);
     if (rc != RT_OK) { std::fprintf(stderr, "render failed: %s: %s\n", rt_strerror(rc), rt_hip_last_error()); status = 101; return false; }
-    const std::string fname = frame_name(prefix, f);
-    std::printf("\nRendering %s\nFrame time: %lldms\n", fname.c_str(), (long long)st.frame_ms);
-    if (writer.joinable()) writer.join();
-    if (write_rc != RT_OK) return false;
-    const uint8_t* px = buf[f % 3].data();
-    writer = std::thread([fname, px, w, h, &write_rc]() { write_rc = rt_png_write_rgb8(fname.c_str(), px, w, h); });
-    return true;
+    std::printf("\nRendering %s\nFrame time: %lldms\n", frame_name(prefix, f).c_str(), (long long)st.frame_ms);
+    stats.kernel_ms[f] = st.kernel_ms; stats.frame_ms[f] = st.frame_ms;
+    uint8_t* px = in_flight.front();
+    in_flight.erase(in_flight.begin());
+    writers.push(f, px);
+    return !writers.failed();
   };
   int submitted = 0, collected = 0;
-  for (int f = 0; f < frames && status == 0 && write_rc == RT_OK; ++f) {
+  for (int f = 0; f < frames && status == 0 && !writers.failed(); ++f) {
     double out[13];
     orbit_camera(cam, orbit_deg, f, out);
     rt_hip_group_set_camera(hs, out, out + 3, out + 6, out + 9);
-    // (buf[f % 3] held frame f - 3, whose PNG is out: the writer of frame f - 2 was started after joining that of f - 3)
-    rc = rt_hip_group_submit(hs, buf[f % 3].data());
+    uint8_t* buf = writers.take_buffer();
+    rc = rt_hip_group_submit(hs, buf);
     if (rc != RT_OK) { std::fprintf(stderr, "render failed: %s: %s\n", rt_strerror(rc), rt_hip_last_error()); status = 101; break; }
+    in_flight.push_back(buf);
     submitted++;
     if (submitted - collected == 2) { if (!finish(collected)) break; collected++; }
   }
-  while (status == 0 && write_rc == RT_OK && collected < submitted) { if (!finish(collected)) break; collected++; }
-  if (writer.joinable()) writer.join();
-  report("sharded", collected, rt_hip_group_size(hs), std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+  while (status == 0 && !writers.failed() && collected < submitted) { if (!finish(collected)) break; collected++; }
+  writers.finish();
+  stats.report("sharded", collected, rt_hip_group_size(hs), W, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), ms_between(t_create, t_begin));
   rt_hip_group_destroy(hs);
-  if (write_rc != RT_OK) { std::fprintf(stderr, "error writing image: %s\n", rt_host_last_error()); status = 101; }
+  if (writers.write_rc != RT_OK) { std::fprintf(stderr, "error writing image: %s\n", writers.write_err.c_str()); status = 101; }
   return status;
 }
 
@@ -119,6 +203,7 @@ int animate_frames(RtSceneFile* sf, const char* prefix, int frames, double orbit
   const uint32_t w = sc->width, h = sc->height;
   std::mutex out_mu;
   std::vector<int> status(G, 0);
+  AnimStats stats(frames);
   const auto t_begin = std::chrono::steady_clock::now();
   std::vector<std::thread> th;
   for (unsigned g = 0; g < G; ++g)
@@ -142,16 +227,21 @@ int animate_frames(RtSceneFile* sf, const char* prefix, int frames, double orbit
           else std::printf("\nRendering %s\nFrame time: %lldms\n", fname.c_str(), (long long)st.frame_ms);
         }
         if (rc != RT_OK) break;
+        stats.kernel_ms[f] = st.kernel_ms; stats.frame_ms[f] = st.frame_ms;  // (distinct elements per thread)
         if (writer.joinable()) writer.join();
         const uint8_t* px = buf[i & 1].data();
-        writer = std::thread([fname, px, w, h, &write_rc]() { write_rc = rt_png_write_rgb8(fname.c_str(), px, w, h); });
+        writer = std::thread([fname, px, w, h, f, &write_rc, &stats]() {
+          const auto t0 = std::chrono::steady_clock::now();
+          write_rc = rt_png_write_rgb8(fname.c_str(), px, w, h);
+          stats.png_ms[f] = ms_between(t0, std::chrono::steady_clock::now());
+        });
       }
       if (writer.joinable()) writer.join();
       if (write_rc != RT_OK) { std::lock_guard<std::mutex> lk(out_mu); std::fprintf(stderr, "error writing image: %s\n", rt_host_last_error()); status[g] = 101; }
       rt_hip_scene_destroy(hs);
     });
   for (auto& t : th) t.join();
-  report("frames", frames, G, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+  stats.report("frames", frames, G, 1, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), 0.0);
   for (int s : status) if (s) return s;
   return 0;
 }

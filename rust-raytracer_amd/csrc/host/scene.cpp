@@ -443,61 +443,105 @@ extern "C" int rt_scene_to_json(const RtSceneFile* sf, char* buf, size_t cap, si
   return (buf && cap > s.size()) || !buf ? RT_OK : RT_ERR_INVALID;
 }
 
-// reference raytracer.rs:33-42 write_image: PNG, 8-bit RGB, non-interlaced.
-// The renderer needs ~15 ms for the headline frame; a single-threaded zlib pass over it takes ~135 ms
-// (1.2 s at 4K) and would be what an animation waits for.  The scanlines are therefore
-// filtered and deflated in independent bands on the host's cores (raw deflate, each band closed by a sync flush
-// so that it ends on a byte boundary; the last one finishes the stream) and stitched into ONE zlib stream:
-// header, the bands back to back, and the Adler-32 of the whole filtered image combined from the bands'.
+// reference raytracer.rs:33-42 write_image: PNG, 8-bit RGB, non-interlaced.  The reference's encoder output (image 0.13 /
+// png crate) is not a byte contract — the decoded pixels are; this writer produces them from any thread count.
+//
+// The renderer needs 12.7 ms for the headline frame; a single-threaded zlib level-6 pass over it takes ~135 ms (1.2 s at
+// 4K), and the banded level-6 writer of rounds 1 - 5 still 20 ms on the GPU box — LONGER than the kernel, so the frame rate
+// of an animation (README.md:43-57) was the PNG writer's.  Round 6:
+//   * a path-traced frame is noise on gradients: after the Sub filter nearly all of deflate's gain is the Huffman coding
+//     of small residuals plus runs of equal bytes; LZ77 matching beyond distance 1 buys 2.6 % of file size for 4.7 x the time
+//     (measured on the headline frame: level 6 1.260 MB / 220 ms of one core, Z_RLE 1.293 MB / 47 ms).  Default strategy:
+//     Z_RLE (RT_PNG_DEFLATE=default gives the old level-6 files, =huffman Huffman only);
+//   * the scanlines are filtered and deflated in independent bands of ~48 KB on the host's cores (raw deflate, each band
+//     closed by a sync flush so that it ends on a byte boundary, the last one finishes the stream) — with distance-1 matches
+//     a band loses nothing by starting with an empty window — and every band is its OWN IDAT chunk, CRC computed by the
+//     thread that made it (consecutive IDAT chunks are one zlib stream: PNG spec 11.2.4); the stream's Adler-32 is combined
+//     from the bands' and travels in a last 4-byte IDAT chunk;
+//   * one z_stream and one scratch buffer per thread (deflateReset between bands), the filter loop vectorised.
 namespace {
 struct PngBand {
-  std::vector<uint8_t> z;
+  std::vector<uint8_t> chunk;  // complete IDAT chunk: length, "IDAT", deflate bytes, CRC
   uLong adler = 1;
   size_t raw_len = 0;
   bool ok = false;
 };
-void png_deflate_band(const uint8_t* rgb8, uint32_t w, uint32_t y0, uint32_t y1, bool last, PngBand& out) {
-  const size_t stride = size_t(w) * 3;
-  std::vector<uint8_t> raw((stride + 1) * (y1 - y0));
-  for (uint32_t y = y0; y < y1; ++y) {  // filter type 1 (Sub) compresses rendered images well
-    uint8_t* dst = &raw[(stride + 1) * (y - y0)];
-    const uint8_t* src = rgb8 + stride * y;
-    dst[0] = 1;
-    for (size_t i = 0; i < stride; ++i) dst[1 + i] = uint8_t(src[i] - (i >= 3 ? src[i - 3] : 0));
-  }
-  out.raw_len = raw.size();
-  out.adler = adler32(adler32(0L, Z_NULL, 0), raw.data(), uInt(raw.size()));
+void put_be32(uint8_t* p, uint32_t v) { p[0] = uint8_t(v >> 24); p[1] = uint8_t(v >> 16); p[2] = uint8_t(v >> 8); p[3] = uint8_t(v); }
+
+// filter type 1 (Sub): residual against the pixel to the left — compresses rendered images well, and (unlike Up / Paeth) a band
+// needs no scanline of its neighbour
+__attribute__((optimize("tree-vectorize"))) void png_filter_sub(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t stride) {
+  dst[0] = 1;
+  const size_t head = stride < 3 ? stride : 3;
+  for (size_t i = 0; i < head; ++i) dst[1 + i] = src[i];
+  for (size_t i = 3; i < stride; ++i) dst[1 + i] = uint8_t(src[i] - src[i - 3]);
+}
+
+struct PngWorker {   // per thread: a deflate state and the band's filtered bytes, reused from band to band
   z_stream zs;
-  std::memset(&zs, 0, sizeof zs);
-  if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return;  // -15: raw deflate, no zlib wrapper
-  out.z.resize(deflateBound(&zs, uLong(raw.size())) + 16);
-  zs.next_in = raw.data(); zs.avail_in = uInt(raw.size());
-  zs.next_out = out.z.data(); zs.avail_out = uInt(out.z.size());
-  const int rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
-  out.ok = (last ? rc == Z_STREAM_END : rc == Z_OK) && zs.avail_in == 0;
-  out.z.resize(out.z.size() - zs.avail_out);
-  deflateEnd(&zs);
+  bool live = false;
+  std::vector<uint8_t> raw;
+  ~PngWorker() { if (live) deflateEnd(&zs); }
+  bool begin(int level, int strategy) {
+    if (live) return deflateReset(&zs) == Z_OK;
+    std::memset(&zs, 0, sizeof zs);
+    // -15: raw deflate, no zlib wrapper (the wrapper is written once for the whole stream)
+    live = deflateInit2(&zs, level, Z_DEFLATED, -15, 8, strategy) == Z_OK;
+    return live;
+  }
+};
+void png_deflate_band(PngWorker& wk, int level, int strategy, const uint8_t* rgb8, uint32_t w, uint32_t y0, uint32_t y1, bool first, bool last, PngBand& out) {
+  const size_t stride = size_t(w) * 3;
+  wk.raw.resize((stride + 1) * (y1 - y0));
+  for (uint32_t y = y0; y < y1; ++y) png_filter_sub(rgb8 + stride * y, &wk.raw[(stride + 1) * (y - y0)], stride);
+  out.raw_len = wk.raw.size();
+  out.adler = adler32(adler32(0L, Z_NULL, 0), wk.raw.data(), uInt(wk.raw.size()));
+  if (!wk.begin(level, strategy)) return;
+  const size_t head = 8 + (first ? 2 : 0);  // chunk length + type (+ the zlib header in the first band)
+  out.chunk.resize(head + deflateBound(&wk.zs, uLong(wk.raw.size())) + 16 + 4);
+  wk.zs.next_in = wk.raw.data(); wk.zs.avail_in = uInt(wk.raw.size());
+  wk.zs.next_out = out.chunk.data() + head; wk.zs.avail_out = uInt(out.chunk.size() - head - 4);
+  const int rc = deflate(&wk.zs, last ? Z_FINISH : Z_SYNC_FLUSH);
+  out.ok = (last ? rc == Z_STREAM_END : rc == Z_OK) && wk.zs.avail_in == 0;
+  const size_t zlen = out.chunk.size() - head - 4 - wk.zs.avail_out, data_len = zlen + (first ? 2 : 0);
+  out.chunk.resize(8 + data_len + 4);
+  put_be32(out.chunk.data(), uint32_t(data_len));
+  std::memcpy(out.chunk.data() + 4, "IDAT", 4);
+  if (first) { out.chunk[8] = 0x78; out.chunk[9] = 0x9C; }  // zlib header: deflate, 32 KB window, default level, no dictionary
+  put_be32(out.chunk.data() + 8 + data_len, uint32_t(crc32(0L, out.chunk.data() + 4, uInt(4 + data_len))));
 }
 }  // namespace
 
 extern "C" int rt_png_write_rgb8(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h) {
   if (!path || !rgb8 || !w || !h) return set_err(RT_ERR_INVALID, "bad png arguments");
   const size_t stride = size_t(w) * 3;
-  if ((stride + 1) * size_t(h) > 0x7FFFFFFFu) return set_err(RT_ERR_PNG, "image too large for one IDAT chunk");
-  // bands of >= 128 KB of scanlines, at most 4 per hardware thread
+  if ((stride + 1) * size_t(h) > 0x7FFFFFFFu) return set_err(RT_ERR_PNG, "image too large");
+  int level = 1, strategy = Z_RLE;
+  if (const char* e = std::getenv("RT_PNG_DEFLATE")) {
+    if (!std::strcmp(e, "default")) { level = 6; strategy = Z_DEFAULT_STRATEGY; }
+    else if (!std::strcmp(e, "huffman")) strategy = Z_HUFFMAN_ONLY;
+    else if (std::strcmp(e, "rle")) return set_err(RT_ERR_INVALID, "RT_PNG_DEFLATE must be rle (default), default or huffman");
+  }
+  // threads: the host's cores, at most RT_PNG_THREADS (default 32: beyond that starting the threads costs what they save)
   unsigned hw = std::thread::hardware_concurrency();
   if (hw == 0) hw = 4;
-  uint32_t rows_per_band = uint32_t((size_t(128) * 1024 + stride) / (stride + 1));
+  unsigned cap = 32;
+  if (const char* e = std::getenv("RT_PNG_THREADS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 1024) cap = unsigned(v); }
+  hw = std::min(hw, cap);
+  // bands of >= 48 KB of scanlines (128 KB with LZ77 matching: a band starts with an empty window), at most 8 per thread
+  const size_t band_bytes = strategy == Z_DEFAULT_STRATEGY ? size_t(128) * 1024 : size_t(48) * 1024;
+  uint32_t rows_per_band = uint32_t((band_bytes + stride) / (stride + 1));
   if (rows_per_band == 0) rows_per_band = 1;
   uint32_t n_bands = (h + rows_per_band - 1) / rows_per_band;
-  if (n_bands > 4 * hw) { n_bands = 4 * hw; rows_per_band = (h + n_bands - 1) / n_bands; n_bands = (h + rows_per_band - 1) / rows_per_band; }
+  if (n_bands > 8 * hw) { n_bands = 8 * hw; rows_per_band = (h + n_bands - 1) / n_bands; n_bands = (h + rows_per_band - 1) / rows_per_band; }
   std::vector<PngBand> bands(n_bands);
   {
     std::atomic<uint32_t> next{0};
     auto work = [&]() {
+      PngWorker wk;
       for (uint32_t b; (b = next.fetch_add(1)) < n_bands;) {
         const uint32_t y0 = b * rows_per_band, y1 = std::min(h, y0 + rows_per_band);
-        png_deflate_band(rgb8, w, y0, y1, b + 1 == n_bands, bands[b]);
+        png_deflate_band(wk, level, strategy, rgb8, w, y0, y1, b == 0, b + 1 == n_bands, bands[b]);
       }
     };
     const unsigned n_threads = std::min<unsigned>(hw, n_bands);
@@ -506,30 +550,33 @@ extern "C" int rt_png_write_rgb8(const char* path, const uint8_t* rgb8, uint32_t
     work();
     for (auto& t : pool) t.join();
   }
-  std::vector<uint8_t> z;
-  z.push_back(0x78); z.push_back(0x9C);  // zlib header: deflate, 32 KB window, default level, no dictionary
+  size_t total = 8 + 25 + 16 + 12;  // signature, IHDR, the Adler-32's IDAT, IEND
   uLong adler = adler32(0L, Z_NULL, 0);
   for (const PngBand& b : bands) {
     if (!b.ok) return set_err(RT_ERR_PNG, "error writing image (deflate)");
-    z.insert(z.end(), b.z.begin(), b.z.end());
+    total += b.chunk.size();
     adler = adler32_combine(adler, b.adler, z_off_t(b.raw_len));
   }
-  z.push_back(uint8_t(adler >> 24)); z.push_back(uint8_t(adler >> 16)); z.push_back(uint8_t(adler >> 8)); z.push_back(uint8_t(adler));
-  const uLongf zlen = uLongf(z.size());
-  FILE* f = std::fopen(path, "wb");
-  if (!f) return set_err(RT_ERR_PNG, std::string("error writing image: ") + std::strerror(errno));
-  auto be32 = [](uint8_t* p, uint32_t v) { p[0] = uint8_t(v >> 24); p[1] = uint8_t(v >> 16); p[2] = uint8_t(v >> 8); p[3] = uint8_t(v); };
+  std::vector<uint8_t> file(total);
+  uint8_t* p = file.data();
   auto chunk = [&](const char* type, const uint8_t* data, uint32_t n) {
-    uint8_t hdr[8]; be32(hdr, n); std::memcpy(hdr + 4, type, 4);
-    uLong crc = crc32(0L, hdr + 4, 4);
-    if (n) crc = crc32(crc, data, n);
-    uint8_t tail[4]; be32(tail, uint32_t(crc));
-    return std::fwrite(hdr, 1, 8, f) == 8 && (!n || std::fwrite(data, 1, n, f) == n) && std::fwrite(tail, 1, 4, f) == 4;
+    put_be32(p, n); std::memcpy(p + 4, type, 4);
+    if (n) std::memcpy(p + 8, data, n);
+    put_be32(p + 8 + n, uint32_t(crc32(0L, p + 4, 4 + n)));
+    p += 12 + n;
   };
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
-  uint8_t ihdr[13]; be32(ihdr, w); be32(ihdr + 4, h);
+  std::memcpy(p, sig, 8); p += 8;
+  uint8_t ihdr[13]; put_be32(ihdr, w); put_be32(ihdr + 4, h);
   ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
-  bool ok = std::fwrite(sig, 1, 8, f) == 8 && chunk("IHDR", ihdr, 13) && chunk("IDAT", z.data(), uint32_t(zlen)) && chunk("IEND", nullptr, 0);
+  chunk("IHDR", ihdr, 13);
+  for (const PngBand& b : bands) { std::memcpy(p, b.chunk.data(), b.chunk.size()); p += b.chunk.size(); }
+  uint8_t tail[4]; put_be32(tail, uint32_t(adler));
+  chunk("IDAT", tail, 4);
+  chunk("IEND", nullptr, 0);
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return set_err(RT_ERR_PNG, std::string("error writing image: ") + std::strerror(errno));
+  bool ok = std::fwrite(file.data(), 1, total, f) == total;
   ok = (std::fclose(f) == 0) && ok;
   return ok ? RT_OK : set_err(RT_ERR_PNG, "error writing image");
 }

@@ -554,23 +554,10 @@ def test_cli_contract(tmp_path, gpu_render, load_scene):
     assert r.returncode == 101 and "Unable to read config file." in r.stderr
 
 
-def test_animation_driver(tmp_path, pkg, host, load_scene):
-    """`raytracer <config> <prefix> --frames N --orbit DEG` (the reference's anim/frame_%03d.png
-    workflow, README.md:43-57, main.rs:17): the scene stays resident, only the camera moves; every
-    frame equals a render of the resident scene with that camera through the C ABI."""
+def _orbit_cameras(host, sc, n, deg):
+    """the camera vectors (origin, lower-left, horizontal, vertical) of frames 0..n-1 of `--orbit deg`: look_from turned about
+    vup around look_at (Rodrigues), then Camera::new (camera.rs:45-77) — the CLI's orbit_camera restated"""
     import math
-    from PIL import Image
-    exe = os.path.join(ROOT, "rust-raytracer_amd", "raytracer")
-    cfg = json.load(open(os.path.join(ROOT, "scenes", "cfg1_test_800x600_spp16.json")))
-    cfg.update(width=72, height=54, samples_per_pixel=3)
-    p = tmp_path / "s.json"
-    p.write_text(json.dumps(cfg))
-    prefix = tmp_path / "frame"
-    r = subprocess.run([exe, str(p), str(prefix), "--frames", "3", "--orbit", "25"], capture_output=True, text=True, cwd=ROOT)
-    assert r.returncode == 0, r.stderr
-    assert r.stdout.count("\nRendering ") == 3 and r.stdout.count("Frame time: ") == 3
-    sc = load_scene(str(p))
-    gs = pkg.hip.HipScene(sc.ptr, 0)
     cam = (C.c_double * 11)()
     host.lib().rt_scene_camera.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     host.lib().rt_scene_camera.restype = None
@@ -578,9 +565,9 @@ def test_animation_driver(tmp_path, pkg, host, load_scene):
     lf, la, up = list(cam[0:3]), list(cam[3:6]), list(cam[6:9])
     kl = math.sqrt(up[0] * up[0] + up[1] * up[1] + up[2] * up[2])
     k = [u / kl for u in up]
-    frames = []
-    for f in range(3):
-        th = 25.0 * f * (3.14159265358979323846264338327950288 / 180.0)
+    cams = []
+    for f in range(n):
+        th = deg * f * (3.14159265358979323846264338327950288 / 180.0)
         c, s_ = math.cos(th), math.sin(th)
         v = [lf[i] - la[i] for i in range(3)]
         kv = k[0] * v[0] + k[1] * v[1] + k[2] * v[2]
@@ -588,13 +575,80 @@ def test_animation_driver(tmp_path, pkg, host, load_scene):
         frm = [la[i] + v[i] * c + kx[i] * s_ + k[i] * kv * (1.0 - c) for i in range(3)]
         out = (C.c_double * 13)()
         host.lib().rt_camera_derive((C.c_double * 3)(*frm), (C.c_double * 3)(*la), (C.c_double * 3)(*up), cam[9], cam[10], out)
-        gs.set_camera(out[0:3], out[3:6], out[6:9], out[9:12])
-        rgb, st = gs.render_to_host()
-        assert st["samples"] == 72 * 54 * 3
+        cams.append((list(out[0:3]), list(out[3:6]), list(out[6:9]), list(out[9:12])))
+    return cams
+
+
+def _oracle_with_camera(oracle, abi, sc, cam):
+    """the ORACLE's frame of the scene seen through `cam` (its RtScene camera fields overwritten, then restored)"""
+    keep = [list(sc.c.cam_origin), list(sc.c.cam_lower_left), list(sc.c.cam_horizontal), list(sc.c.cam_vertical)]
+    try:
+        for i in range(3):
+            sc.c.cam_origin[i], sc.c.cam_lower_left[i], sc.c.cam_horizontal[i], sc.c.cam_vertical[i] = cam[0][i], cam[1][i], cam[2][i], cam[3][i]
+        return oracle.render(abi, sc.ptr)
+    finally:
+        for i in range(3):
+            sc.c.cam_origin[i], sc.c.cam_lower_left[i], sc.c.cam_horizontal[i], sc.c.cam_vertical[i] = keep[0][i], keep[1][i], keep[2][i], keep[3][i]
+
+
+@pytest.mark.parametrize("anim_env", [{}, {"RT_GPUS": "3", "RT_GPUS_EMULATE": "1"}, {"RT_ANIM": "frames", "RT_GPUS": "2", "RT_GPUS_EMULATE": "1"}])
+def test_animation_driver(tmp_path, pkg, host, oracle, abi, torch_cuda, load_scene, anim_env):
+    """`raytracer <config> <prefix> --frames N --orbit DEG` (the reference's anim/frame_%03d.png workflow, README.md:43-57,
+    main.rs:17): the scene stays resident, only the camera moves (rt_hip_set_camera / rt_hip_group_set_camera).  Every frame's
+    PNG is checked against the ORACLE rendering the scene through that frame's camera (camera.rs:45-84) — and the same
+    moved-camera frame rendered through the device API (linear radiance: the full parity bar) and through a 3-rank group."""
+    from PIL import Image
+    torch = torch_cuda
+    exe = os.path.join(ROOT, "rust-raytracer_amd", "raytracer")
+    cfg = json.load(open(os.path.join(ROOT, "scenes", "cfg1_test_800x600_spp16.json")))
+    W, H, SPP = 72, 54, 3
+    cfg.update(width=W, height=H, samples_per_pixel=SPP)
+    p = tmp_path / "s.json"
+    p.write_text(json.dumps(cfg))
+    prefix = tmp_path / "frame"
+    r = subprocess.run([exe, str(p), str(prefix), "--frames", "3", "--orbit", "25"], capture_output=True, text=True, cwd=ROOT,
+                       env=dict(os.environ, RT_STATS="1", **anim_env))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("\nRendering ") == 3 and r.stdout.count("Frame time: ") == 3
+    rep = json.loads([l for l in r.stderr.splitlines() if l.startswith('{"animation"')][-1])
+    assert rep["frames"] == 3 and rep["frames_per_s"] > 0 and len(rep["kernel_ms"]) == 3 and len(rep["png_ms"]) == 3
+    assert all(k > 0 for k in rep["kernel_ms"]) and all(k > 0 for k in rep["png_ms"])
+    sc = load_scene(str(p))
+    cams = _orbit_cameras(host, sc, 3, 25.0)
+    gs = pkg.hip.HipScene(sc.ptr, 0)
+    rgb_d = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0")
+    lin_d = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    grp = None
+    if not anim_env:
+        os.environ["RT_GPUS_EMULATE"] = "1"
+        try:
+            grp = pkg.hip.HipGroup(sc.ptr, 3)
+        finally:
+            del os.environ["RT_GPUS_EMULATE"]
+    frames = []
+    for f in range(3):
+        o_rgb, o_lin, o_st = _oracle_with_camera(oracle, abi, sc, cams[f])
+        gs.set_camera(*cams[f])
+        gs.render(rgb_d.data_ptr(), lin_d.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        st = gs.wait()
+        rgb = rgb_d.cpu().numpy()
+        # the moved-camera frame against the oracle: linear radiance, RGB8, path count
+        assert_parity(rgb, lin_d.cpu().numpy(), o_rgb, o_lin, f"frame {f} (rt_hip_set_camera)", atol=pooled_atol(SPP), flip_frac=2e-3)
+        assert st["samples"] == W * H * SPP and st["segments"] == o_st["segments"] - o_st["segments_discarded"]
+        # the CLI's PNG of that frame: the same bytes, hence the oracle's within the RGB8 bar
         got = np.asarray(Image.open(f"{prefix}_{f:03d}.png"))
-        assert np.array_equal(got, rgb), f"frame {f}"
+        assert np.array_equal(got, rgb), f"frame {f}: PNG differs from the device API's frame"
+        d = np.abs(got.astype(np.int16) - o_rgb.astype(np.int16))
+        assert d.max() <= 1 and int((d != 0).sum()) <= max(2, int(2e-3 * d.size)), f"frame {f}: PNG vs oracle"
+        if grp is not None:   # rt_hip_group_set_camera, 3 emulated ranks: the same frame, hence the oracle's
+            grp.set_camera(*cams[f])
+            g_rgb, g_st = grp.render_to_host()
+            assert np.array_equal(g_rgb, rgb), f"frame {f}: 3-rank group after rt_hip_group_set_camera"
+            assert g_st["segments"] == o_st["segments"] - o_st["segments_discarded"]
         frames.append(rgb)
     gs.close()
+    if grp is not None:
+        grp.close()
     assert not np.array_equal(frames[0], frames[1]) and not np.array_equal(frames[1], frames[2])  # the camera did move
 
 
@@ -987,6 +1041,20 @@ def test_bench_line_contract(force_rccl):
         oc = d["other_configs"]
         assert len(oc) == 4 and all(c["kernel_ms"] > 0 and c["msamples_per_s"] > 0 for c in oc)
         assert oc[3]["n_spheres"] == 10001 and "configs[2]" in oc[1]["config"]
+        for c in oc:   # counters of a config (when committed) are priced on BOTH clocks: the counter passes' own and this run's
+            if "counters_source" in c and "lane_slot_frac" in c:
+                assert 0 < c["lane_slot_frac_on_this_runs_clock"] <= 1
+                if "lane_slot_frac_on_counter_clock" in c:
+                    assert c["lane_slot_frac"] == c["lane_slot_frac_on_counter_clock"] and c["counter_run_kernel_ms"] > 0
+            assert "traffic" not in c   # (FETCH_SIZE / WRITE_SIZE are L2 misses, not HBM bytes: l2_miss_bytes + hbm_bytes_compulsory)
+        # the animation workflow in fresh processes — frames/s disk to disk, moving-camera kernel times, PNG times
+        an = d["animation"]
+        assert len(an) == 2 and all("error" not in a for a in an), an
+        for a in an:
+            assert a["frames"] == 32 and a["pngs_on_disk"] == 32 and a["frames_per_s"] > 0 and len(a["kernel_ms_series"]) == 32
+            assert a["kernel_ms_moving_camera"]["median"] > 0 and a["png_ms"]["median"] > 0 and a["bound_by"] in ("kernel", "png")
+            assert 0 < a["overlap_efficiency"] <= 1.05
+        assert an[0]["moving_over_steady"] > 0.8
 
 
 @pytest.mark.parametrize("kind", range(6))
@@ -1091,6 +1159,7 @@ def test_bench_process_per_gpu_with_two_ranks_on_this_gpu():
     samples = 1200 * 800 * 128
     assert abs(d["value"] - samples / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * d["value"]
     assert d["n1_kernel_ms"] > 0 and d["frame_latency_ms"] > 0 and d["segments_per_sample"] > 2.0
+    _check_multi_gpu_line_extras(d, 2)
     print(f"two ranks on one GPU (gloo-host): {d['value']:.0f} Msamples/s, {d['ms_per_step']:.2f} ms/step, per-rank kernel {pr['kernel_ms']}, frame latency {d['frame_latency_ms']:.2f} ms")
 
 
@@ -1307,6 +1376,46 @@ def test_bench_multi_gpu_without_torchrun_runs_the_in_library_group():
     samples = 1200 * 800 * 128
     assert abs(d["value"] - samples / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * d["value"]
     assert d["kernel_ms"] > 0 and d["frame_latency_ms"] >= d["kernel_ms"] * 0.9 and d["n1_kernel_ms"] > 0
+    _check_multi_gpu_line_extras(d, 4)
+
+
+def _check_multi_gpu_line_extras(d, n):
+    """an N > 1 line parses like the N = 1 line (roofline per rank, cpu_baseline pointer) and carries BASELINE
+    configs[3] — the workload BASELINE.json names for the 8-GPU node — timed on the same ranks"""
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "valu"
+    if rf["frac"] is not None:
+        assert 0 < rf["frac"] <= 1 and len(rf["per_rank_frac"]) == n and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 2e-3
+    cb = d["cpu_baseline"]
+    if cb is not None:    # (a committed N = 1 line exists under profiles/)
+        for k in ("value", "unit", "cores", "kind", "sample", "source"):
+            assert k in cb, k
+        assert cb["value"] > 0 and cb["source"].startswith("profiles/")
+    c3 = d["configs3_on_group"]
+    assert "error" not in c3, c3
+    assert "BASELINE configs[3]" in c3["workload"] and "3840x2160 spp 512" in c3["workload"]
+    assert c3["frame_ms"] >= c3["kernel_ms"] * 0.9 and c3["kernel_ms"] > 0 and c3["n1_kernel_ms"] > 0 and c3["speedup_vs_n1"] > 0
+    assert abs(c3["msamples_per_s"] - 3840 * 2160 * 512 / c3["frame_ms"] / 1e3) < 1e-2 * c3["msamples_per_s"]
+    assert len(c3["per_rank"]["kernel_ms"]) == n and min(c3["per_rank"]["kernel_ms"]) > 0 and c3["frame_identical_to_n1"] is True
+    assert "roofline" in c3 and c3["roofline"]["bound"] == "valu"
+
+
+def test_bench_gpus_8_emulated_carries_configs3_on_the_group():
+    """`python bench.py --gpus 8` — the command of the driver's scaling run — with the 8 ranks on this box's GPU: value as
+    before, + BASELINE configs[3] on the 8-rank group, roofline and the cpu_baseline pointer."""
+    r = _run_bench(["--gpus", "8", "--steps", "3", "--warmup", "1"], {"RT_GPUS_EMULATE": "1"}, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and "error" not in d and d["frame_identical_to_n1"] is True
+    samples = 1200 * 800 * 128
+    assert abs(d["value"] - samples / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * d["value"]
+    _check_multi_gpu_line_extras(d, 8)
+    c3 = d["configs3_on_group"]
+    print(f"8 emulated ranks: cfg2 {d['value']:.0f} Msamples/s; configs[3] frame {c3['frame_ms']:.1f} ms ({c3['msamples_per_s']:.0f} Msamples/s), n1 {c3['n1_kernel_ms']:.1f} ms")
 
 
 def test_bench_more_gpus_than_visible_is_a_json_error_line():

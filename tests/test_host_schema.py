@@ -141,6 +141,97 @@ def test_png_write_roundtrip(host, tmp_path):
     assert back.mode == "RGB" and back.size == (53, 37) and np.array_equal(np.asarray(back), img)
 
 
+def _png_decode_by_hand(path):
+    """stdlib-only decoder of 8-bit RGB non-interlaced PNGs: every chunk's CRC, consecutive IDAT chunks as ONE zlib stream
+    (Adler-32 checked by zlib), the five filter types"""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr, kinds = 8, [], None, []
+    while pos < len(data):
+        n, = struct.unpack(">I", data[pos:pos + 4])
+        kind, body = data[pos + 4:pos + 8], data[pos + 8:pos + 8 + n]
+        crc, = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert zlib.crc32(kind + body) == crc, kind
+        kinds.append(kind)
+        if kind == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        elif kind == b"IDAT":
+            idat.append(body)
+        pos += 12 + n
+    assert kinds[0] == b"IHDR" and kinds[-1] == b"IEND" and set(kinds[1:-1]) == {b"IDAT"}   # IDAT chunks consecutive
+    w, h, depth, colour, comp, filt, lace = ihdr
+    assert (depth, colour, comp, filt, lace) == (8, 2, 0, 0, 0)
+    raw = zlib.decompress(b"".join(idat))
+    stride = w * 3
+    assert len(raw) == (stride + 1) * h
+    out = np.zeros((h, stride), np.uint8)
+    for y in range(h):
+        f, line = raw[y * (stride + 1)], np.frombuffer(raw, np.uint8, stride, y * (stride + 1) + 1).astype(np.int32)
+        prev = out[y - 1].astype(np.int32) if y else np.zeros(stride, np.int32)
+        cur = np.zeros(stride, np.int32)
+        if f == 0:
+            cur = line
+        elif f == 2:
+            cur = (line + prev) & 255
+        else:
+            assert f in (1, 3, 4)
+            for i in range(stride):
+                a = cur[i - 3] if i >= 3 else 0
+                b, c = prev[i], (prev[i - 3] if i >= 3 else 0)
+                if f == 1:
+                    pr = a
+                elif f == 3:
+                    pr = (a + b) >> 1
+                else:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[i] = (line[i] + pr) & 255
+        out[y] = cur
+    return out.reshape(h, w, 3), len(idat)
+
+
+@pytest.mark.parametrize("deflate", [None, "rle", "default", "huffman"])
+@pytest.mark.parametrize("threads", [None, "1", "3"])
+def test_png_writer_bands_strategies_threads(host, tmp_path, monkeypatch, deflate, threads):
+    """rt_png_write_rgb8 (raytracer.rs:33-42: what counts is the DECODED pixels): frames of several bands (one IDAT chunk each + the
+    Adler-32's), every RT_PNG_DEFLATE strategy and thread count — decoded by PIL and by a stdlib-only decoder that checks every
+    chunk CRC and the stream's Adler-32; the file does not depend on the thread count."""
+    from PIL import Image
+    if deflate:
+        monkeypatch.setenv("RT_PNG_DEFLATE", deflate)
+    if threads:
+        monkeypatch.setenv("RT_PNG_THREADS", threads)
+    rng = np.random.default_rng(1)
+    y, x = np.mgrid[0:150, 0:421]
+    smooth = np.stack([x * 255 // 421, y * 255 // 150, (x + y) * 255 // 571], -1).astype(np.int16)
+    for name, img in (("noise_on_gradient", np.clip(smooth + rng.integers(-9, 10, smooth.shape), 0, 255).astype(np.uint8)),
+                      ("flat", np.full((150, 421, 3), 7, np.uint8)), ("one_row", rng.integers(0, 256, (1, 5, 3), dtype=np.uint8)),
+                      ("one_column", rng.integers(0, 256, (300, 1, 3), dtype=np.uint8))):
+        p = str(tmp_path / f"{name}.png")
+        host.png_write(p, img)
+        assert np.array_equal(np.asarray(Image.open(p)), img), name
+        back, n_idat = _png_decode_by_hand(p)
+        assert np.array_equal(back, img), name
+        if name == "noise_on_gradient":
+            assert n_idat >= 3      # (several bands + the Adler-32's chunk)
+            ref = tmp_path / "ref.png"
+            monkeypatch.setenv("RT_PNG_THREADS", "2")
+            host.png_write(str(ref), img)
+            if threads:
+                monkeypatch.setenv("RT_PNG_THREADS", threads)
+            else:
+                monkeypatch.delenv("RT_PNG_THREADS")
+            assert open(p, "rb").read() == ref.read_bytes()   # band layout depends on the thread CAP only through "at most 8 bands per thread": not here
+
+
+def test_png_writer_rejects_an_unknown_strategy(host, tmp_path, monkeypatch):
+    monkeypatch.setenv("RT_PNG_DEFLATE", "zopfli")
+    with pytest.raises(Exception):
+        host.png_write(str(tmp_path / "x.png"), np.zeros((2, 2, 3), np.uint8))
+
+
 def _baseline_jpeg(w=40, h=24, subsampling=2, restart=0):
     import io
     from PIL import Image
