@@ -234,6 +234,11 @@ int rt_hip_device_count(void);
  * on a thread while it reads the scene file. */
 int rt_hip_device_warm(int device);
 const char* rt_hip_last_error(void);
+/* Where set-up time went: the stages of the most recent rt_hip_group_create / rt_render_rgb8 of this process (rank 0's scene —
+ * table build, texel conversion, uploads, kernel configuration — and the group's own work: streams, frame buffers, transport,
+ * pinned staging) as one JSON object {"stage": milliseconds, ...}.  Diagnostics (the CLI prints it under RT_STATS=1); the
+ * pointer is valid until the calling thread's next call. */
+const char* rt_hip_setup_profile(void);
 /* Upload scene tables, textures and sky to HBM of `device`.  The caller may free the
  * RtScene and everything it points to as soon as this returns. */
 int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene** out);

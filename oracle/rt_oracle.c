@@ -2,7 +2,8 @@
  * rt_oracle.c — CPU restatement of the reference's ray_color hot path (see rt_oracle.h).
  * TEST INFRASTRUCTURE ONLY — never linked into, loaded by, or called from the product.
  *
- * Build: gcc -O2 -std=c11 -ffp-contract=off -fno-fast-math -fopenmp (oracle/Makefile).
+ * Build: gcc -O3 -march=x86-64-v3 -std=c11 -ffp-contract=off -fno-fast-math -fopenmp (oracle/Makefile; x86-64-v3 — AVX2, no FMA
+ * contraction — instead of -march=native: the library is built in the CPU container and SHIPS to the GPU box, whose host CPU differs).
  * -ffp-contract=off matters: rustc never fuses a*b+c, so neither may we.
  *
  * Every function cites the reference lines it follows (paths relative to

@@ -6,6 +6,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <mutex>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -34,6 +35,37 @@ int fail(int code, const std::string& m) { g_err = m; return code; }
 struct RtHipScene;
 namespace { int warm_up(RtHipScene* s); }
 
+// Where set-up time goes (rt_hip_setup_profile): the stages of the most recent scene / group creation and one-shot render of
+// this process, in milliseconds — rank 0's scene and the group's own work; other ranks' scenes are created beside it.
+namespace rtp {
+std::mutex g_mu;
+std::vector<std::pair<std::string, double>> g_stages;
+thread_local bool tl_record = true;     // (the group's upload threads of ranks >= 1 switch it off)
+thread_local std::string tl_text;
+void reset() { std::lock_guard<std::mutex> lk(g_mu); g_stages.clear(); }
+void add(const char* name, double ms) { if (!tl_record) return; std::lock_guard<std::mutex> lk(g_mu); g_stages.emplace_back(name, ms); }
+struct Clock {   // mark("x") books the time since the previous mark under x
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void mark(const char* name) {
+    const auto n = std::chrono::steady_clock::now();
+    add(name, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+}  // namespace rtp
+extern "C" const char* rt_hip_setup_profile(void) {
+  std::lock_guard<std::mutex> lk(rtp::g_mu);
+  std::string& s = rtp::tl_text;
+  s = "{";
+  char buf[96];
+  for (size_t i = 0; i < rtp::g_stages.size(); ++i) {
+    std::snprintf(buf, sizeof buf, "%s\"%s\":%.3f", i ? "," : "", rtp::g_stages[i].first.c_str(), rtp::g_stages[i].second);
+    s += buf;
+  }
+  s += "}";
+  return s.c_str();
+}
+
 constexpr uint32_t RT_TIMELINE_WAVES = 8192;  // profile builds: {start, end} wall clock per wave behind the counters
 
 struct RtHipScene {
@@ -43,6 +75,14 @@ struct RtHipScene {
   bool has_lights = false, simple_colour = false;
   void* d_geom = nullptr; void* d_mat = nullptr; void* d_lights = nullptr;
   void* d_tex = nullptr; void* d_sky = nullptr; void* d_tex4 = nullptr; void* d_sky4 = nullptr;
+  // The host copies of the BIG uploads (texels: 29 MB for the reference's test scene) live as long as the scene.  hipMemcpy from
+  // pageable memory pins the source pages for the device (a userptr mapping the runtime caches); giving such memory back to
+  // the OS (free -> munmap) fires the driver's MMU notifier, which EVICTS the process's hardware queues and restores them
+  // 10 - 25 ms later — the next kernel launch waits for that.  Found in round 6 as a one-shot frame of the test scene whose
+  // first launch started 20 ms late in two runs of three (profiles/r06_run5_first_launch_wait.log); with the buffers kept,
+  // 12 of 12 runs start in 0.07 ms.  They are freed with the scene, when nothing waits for the queues.
+  rtc::TexelVec keep_tex4, keep_sky4;
+  std::vector<uint8_t> keep_tex_rgb8, keep_sky_rgb8;
   size_t texel_bytes = 0;
   void* d_matc = nullptr; void* d_cell_word = nullptr; void* d_cell_items = nullptr; void* d_large = nullptr;
   void* d_all = nullptr;   // 0..n-1: the `large` list of the brute-force arm (variant 1)
@@ -148,6 +188,10 @@ extern "C" int rt_hip_device_warm(int device) {
   RT_HIP_TRY(hipMalloc(&p, 256));  // (the first allocation creates the device's context)
   hipLaunchKernelGGL(rtk::rt_warm_up, dim3(1), dim3(64), 0, nullptr);  // (the first launch loads this library's code object)
   RT_HIP_TRY(hipGetLastError());
+  if (!std::getenv("RT_NO_SCRATCH_WARMUP")) {
+    hipLaunchKernelGGL(rtk::rt_warm_up_scratch, dim3(1), dim3(64), 0, nullptr, (uint32_t*)nullptr, 1u);  // (... and gives the NULL stream's queue its scratch memory)
+    RT_HIP_TRY(hipGetLastError());
+  }
   RT_HIP_TRY(hipDeviceSynchronize());
   (void)hipFree(p);
   return RT_OK;
@@ -168,9 +212,9 @@ extern "C" void rt_hip_scene_destroy(RtHipScene* s) {
 }
 
 namespace {
-template <typename T>
-int upload(void** dst, const std::vector<T>& v) {
-  size_t bytes = v.size() * sizeof(T);
+template <typename V>
+int upload(void** dst, const V& v) {
+  size_t bytes = v.size() * sizeof(typename V::value_type);
   RT_HIP_TRY(hipMalloc(dst, bytes ? bytes : 16));
   if (bytes) RT_HIP_TRY(hipMemcpy(*dst, v.data(), bytes, hipMemcpyHostToDevice));
   return RT_OK;
@@ -186,10 +230,13 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   static const bool trace = std::getenv("RT_GROUP_TRACE") != nullptr;  // (development: where a scene's creation time goes)
   const auto t_create = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count(); };
+  rtp::Clock pc;
   rtc::HostTables t;
   std::string why = rtc::build_tables(*scene, t);
   if (!why.empty()) return fail(RT_ERR_INVALID, why);
+  pc.mark("scene.tables_and_grid");
   rtc::build_texels(*scene, t);
+  pc.mark("scene.texels_rgbx");
   const double t_tables = since();
   RT_HIP_TRY(hipSetDevice(device));
   RtHipScene* s = new RtHipScene;
@@ -209,6 +256,7 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
     const size_t dev_lds = prop.sharedMemPerBlock > prop.maxSharedMemoryPerMultiProcessor ? prop.sharedMemPerBlock : prop.maxSharedMemoryPerMultiProcessor;
     s->lds_cap = std::max<size_t>(rtk::LDS_TABLES_MAX_BYTES, std::min<size_t>(dev_lds, 160u * 1024u));
   }
+  pc.mark("scene.device_properties");
   int rc;
   auto bail = [&](int code) { rt_hip_scene_destroy(s); return code; };
   if ((rc = upload(&s->d_geom, t.geom)) != RT_OK) return bail(rc);
@@ -224,23 +272,27 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
     for (uint32_t i = 0; i < scene->n_spheres; ++i) all[i] = i;
     if ((rc = upload(&s->d_all, all)) != RT_OK) return bail(rc);
   }
+  pc.mark("scene.upload_tables");
   // textures and sky: resident as 4-byte texels (rt_tables.h build_texels; one dword load per fetch); the caller's RGB8
   // bytes are uploaded too only if some record is outside that path's range (rt_core.h texels_fast)
   s->texel_bytes = (t.tex4.size() + t.sky4.size()) * 4u;
   if ((rc = upload(&s->d_tex4, t.tex4)) != RT_OK) return bail(rc);
   if ((rc = upload(&s->d_sky4, t.sky4)) != RT_OK) return bail(rc);
   {
-    std::vector<uint8_t> blob(t.need_rgb8 ? t.tex_bytes : 0);
+    std::vector<uint8_t>& blob = s->keep_tex_rgb8;
+    blob.assign(t.need_rgb8 ? t.tex_bytes : 0, 0);
     if (t.need_rgb8)
       for (uint32_t i = 0; i < scene->n_textures; ++i)
         if (scene->textures[i].nbytes) std::memcpy(&blob[t.tex_off[i]], scene->textures[i].rgb8, scene->textures[i].nbytes);
     if ((rc = upload(&s->d_tex, blob)) != RT_OK) return bail(rc);
   }
   {
-    std::vector<uint8_t> sky;
+    std::vector<uint8_t>& sky = s->keep_sky_rgb8;
     if (scene->sky_mode == RT_SKY_TEXTURE && !t.sky_fast) sky.assign(scene->sky_rgb8, scene->sky_rgb8 + scene->sky_w * scene->sky_h * 3);
     if ((rc = upload(&s->d_sky, sky)) != RT_OK) return bail(rc);
   }
+  if (!std::getenv("RT_FREE_HOST_TEXELS")) { s->keep_tex4.swap(t.tex4); s->keep_sky4.swap(t.sky4); }  // (the variable: the round-5 behaviour, for the A/B)
+  pc.mark("scene.upload_texels");
   if (hipMalloc((void**)&s->d_counters, (32 + 4 * RT_TIMELINE_WAVES) * sizeof(unsigned long long)) != hipSuccess)
     return bail(fail(RT_ERR_HIP, "hipMalloc(counters) failed"));
   for (auto& sl : s->slot) {
@@ -267,10 +319,13 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   // ... and nothing a first frame should pay for is left for it: the code object on the device, the default configuration's
   // kernel attribute / occupancy / (lit scenes) overflow slots (a one-shot rt_render_rgb8 — the reference renders one frame per
   // process — reports this under setup_ms, outside its frame_ms window)
+  pc.mark("scene.counters_events_pinned_words");
   const double t_uploaded = since();
   if ((rc = warm_up(s)) != RT_OK) return bail(rc);
+  pc.mark("scene.kernel_configuration");
   const double t_warm = since();
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(RT_ERR_HIP, "hipDeviceSynchronize failed"));
+  pc.mark("scene.device_idle");
   if (trace) std::fprintf(stderr, "[rt scene] create: tables %.2f ms, uploads + events done %.2f, warm_up (module, configuration, overflow) %.2f, device idle %.2f\n", t_tables, t_uploaded, t_warm, since());
   *out = s;
   return RT_OK;
@@ -771,7 +826,9 @@ int rt_hip_scene_warm(RtHipScene* s, hipStream_t stream) {
   s->order_mode = 1;  // (nothing measured, nothing sorted)
   const RtRowTiles first_row{1u, 0u, s->host.height};
   int rc = rt_hip_render(s, &first_row, row, nullptr, stream);
-  if (rc == RT_OK) rc = rt_hip_wait(s, nullptr);
+  RtStats wst;
+  if (rc == RT_OK) rc = rt_hip_wait(s, &wst);
+  if (rc == RT_OK) rtp::add("rank0.warm_up_kernel_ms_by_events", wst.kernel_ms);
   s->order_mode = saved_order;
   s->n_launches = 0; s->in_flight = false; s->last_stream = nullptr; s->last_waves = 0;
   s->order_key = RtHipScene::OrderKey(); s->order_ready = false; s->order_age = 0;

@@ -148,6 +148,8 @@ struct RtHipGroup {
   std::atomic<uint32_t> n_done{0};
   int cur = 0;                       // the Frame the workers are enqueuing
   bool quit = false;
+  bool own_streams = true;           // false: a one-shot group of one rank runs on the device's NULL stream (rt_render_rgb8: no queue of its own to create)
+  int inject = 0;                    // probe build only (RT_RCCL_INJECT, read once at creation): 1 = the self-test gather delivers wrong bytes, 2 = the second frame's gather fails to enqueue
   std::atomic<int> spin_us{0};       // "spin_us" option: a worker polls for the next frame this long before it sleeps on the condition variable
   std::vector<int> rc;
   std::vector<std::string> err;
@@ -273,7 +275,9 @@ std::string try_rccl(RtHipGroup* g) {
     if (hipMemcpy(&got[r], static_cast<const uint8_t*>(f.d_stacked) + (size_t)r * probe + (probe - 1), 1, hipMemcpyDeviceToHost) != hipSuccess) {
       (void)hipGetLastError(); drop_comms(false); return "self-test: reading the gathered bytes back failed";
     }
-  if (const char* inj = std::getenv("RT_RCCL_INJECT")) if (!std::strcmp(inj, "selftest")) got[G - 1] = 0;  // (test hook: the self-test sees wrong bytes)
+#ifdef RT_TEST_PROBES  // fault injection exists in the probe build only: a stray environment variable cannot switch the product's transport
+  if (g->inject == 1) got[G - 1] = 0;  // (test hook RT_RCCL_INJECT=selftest: the self-test sees wrong bytes)
+#endif
   for (uint32_t r = 0; r < G; ++r)
     if (got[r] != (uint8_t)(r + 1u)) { drop_comms(false); return "self-test gather delivered rank " + std::to_string(r) + "'s bytes as " + std::to_string((int)got[r]); }
   return "";
@@ -351,7 +355,7 @@ extern "C" void rt_hip_group_destroy(RtHipGroup* g) {
   for (auto& t : g->worker) if (t.joinable()) t.join();
   for (uint32_t r = 0; r < g->scene.size(); ++r) {  // nothing of ours may be running when buffers and communicators go
     (void)hipSetDevice(g->device[r]);
-    if (r < g->stream.size() && g->stream[r]) (void)hipStreamSynchronize(g->stream[r]);
+    if (r < g->stream.size() && (g->stream[r] || !g->own_streams)) (void)hipStreamSynchronize(g->stream[r]);
     if (r < g->xstream.size() && g->xstream[r]) (void)hipStreamSynchronize(g->xstream[r]);
   }
   for (uint32_t r = 0; r < g->comm.size(); ++r)
@@ -364,8 +368,8 @@ extern "C" void rt_hip_group_destroy(RtHipGroup* g) {
       if (r < f.ev_sent.size() && f.ev_sent[r]) (void)hipEventDestroy(f.ev_sent[r]);
     }
     if (g->scene[r]) rt_hip_scene_destroy(g->scene[r]);
-    if (r < g->stream.size() && g->stream[r]) (void)hipStreamDestroy(g->stream[r]);
-    if (r < g->xstream.size() && g->xstream[r]) (void)hipStreamDestroy(g->xstream[r]);
+    if (g->own_streams && r < g->stream.size() && g->stream[r]) (void)hipStreamDestroy(g->stream[r]);
+    if (g->own_streams && r < g->xstream.size() && g->xstream[r]) (void)hipStreamDestroy(g->xstream[r]);
   }
   if (!g->device.empty()) (void)hipSetDevice(g->device[0]);
   for (auto& f : g->frame) {
@@ -378,7 +382,17 @@ extern "C" void rt_hip_group_destroy(RtHipGroup* g) {
   delete g;
 }
 
+namespace rtg {
+// one_shot: the group renders ONE frame and goes (rt_render_rgb8 — the reference's one frame per process, main.rs:7-20).  Every
+// stream of its own is a hardware queue the runtime has to create (7.8 ms each on MI355X, serialised: tools/microbench/
+// setup_costs.hip, profiles/r06_run3_setup_costs.log) and buys a single blocking frame nothing: a one-rank one-shot group
+// renders, assembles and copies on the device's NULL stream, whose queue exists since the device was warmed.
+int group_create(const RtScene* scene, uint32_t n_gpus, RtHipGroup** out, bool one_shot);
+}
 extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipGroup** out) {
+  return rtg::group_create(scene, n_gpus, out, false);
+}
+int rtg::group_create(const RtScene* scene, uint32_t n_gpus, RtHipGroup** out, bool one_shot) {
   if (!scene || !out) return fail(RT_ERR_INVALID, "null argument");
   *out = nullptr;
   const int ndev = rt_hip_device_count();
@@ -391,13 +405,19 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
   if (G > (uint32_t)ndev && !emulate)
     return fail(RT_ERR_INVALID, "n_gpus = " + std::to_string(G) + " but only " + std::to_string(ndev) + " device(s) visible");
   const auto t_group = std::chrono::steady_clock::now();
+  rtp::reset();
+  rtp::Clock pc;
   RtHipGroup* g = new RtHipGroup;
   g->G = G; g->width = scene->width; g->height = scene->height;
+  g->own_streams = !(one_shot && G == 1 && !std::getenv("RT_ONE_SHOT_STREAMS"));
   g->row_bytes = (size_t)scene->width * 3;
   g->device.resize(G); g->scene.assign(G, nullptr); g->stream.assign(G, nullptr); g->xstream.assign(G, nullptr);
   g->tiles.resize(G); g->rc.assign(G, RT_OK); g->err.resize(G); g->t_wake_us.assign(G, 0.0); g->t_enq_us.assign(G, 0.0);
   g->place.resize(G); g->kernel_ms_last.assign(G, 0.0);
   { const char* pin = std::getenv("RT_GROUP_PIN"); g->pin_threads = !(pin && pin[0] == '0'); }
+#ifdef RT_TEST_PROBES
+  if (const char* inj = std::getenv("RT_RCCL_INJECT")) g->inject = !std::strcmp(inj, "selftest") ? 1 : (!std::strcmp(inj, "gather") ? 2 : 0);
+#endif
   for (auto& f : g->frame) { f.d_tiles.assign(G, nullptr); f.ev_done.assign(G, nullptr); f.ev_sent.assign(G, nullptr); f.slot.assign(G, 0); }
   bool& shared_device = g->shared_device;
   for (uint32_t r = 0; r < G; ++r) {
@@ -422,22 +442,27 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
     g->place[r].peer_to_root = can;
   }
   auto bail = [&](int code, const std::string& m) { rt_hip_group_destroy(g); return fail(code, m); };
+  pc.mark("group.locate_devices");
   // scene replicas: one thread per rank (table upload + texture copy run in parallel)
   {
     std::vector<std::thread> th;
     for (uint32_t r = 0; r < G; ++r)
       th.emplace_back([g, scene, r]() {
+        rtp::tl_record = r == 0;
+        rtp::Clock rc_clock;
         rtg::pin_to_rank(g, r);  // (the replica's pinned counter words and staging copies are first touched on the device's node)
         g->rc[r] = rt_hip_scene_create(scene, g->device[r], &g->scene[r]);
         if (g->rc[r] != RT_OK) { g->err[r] = rt_hip_last_error(); return; }
-        bool ok = hipStreamCreateWithFlags(&g->stream[r], hipStreamNonBlocking) == hipSuccess &&
-                  hipStreamCreateWithFlags(&g->xstream[r], hipStreamNonBlocking) == hipSuccess;
+        rc_clock.t = std::chrono::steady_clock::now();   // (the scene's own stages are booked by rt_hip_scene_create)
+        bool ok = !g->own_streams || (hipStreamCreateWithFlags(&g->stream[r], hipStreamNonBlocking) == hipSuccess &&
+                                      hipStreamCreateWithFlags(&g->xstream[r], hipStreamNonBlocking) == hipSuccess);
         for (auto& f : g->frame) {
           ok = ok && hipEventCreateWithFlags(&f.ev_done[r], hipEventDisableTiming) == hipSuccess &&
                hipEventCreateWithFlags(&f.ev_sent[r], hipEventDisableTiming) == hipSuccess;
           if (ok && r != 0 && hipMalloc(&f.d_tiles[r], g->pad_bytes ? g->pad_bytes : 16) != hipSuccess) ok = false;
         }
         if (!ok) { g->rc[r] = RT_ERR_HIP; g->err[r] = "hipStreamCreate / hipEventCreate / hipMalloc(tiles) failed"; return; }
+        rc_clock.mark("rank0.streams_events_tile_buffers");
         // the rank's kernel once through the rank's own render stream (one scanline): the first frame finds a warm queue
         if (!std::getenv("RT_NO_KERNEL_WARMUP")) {
           const auto tw = std::chrono::steady_clock::now();
@@ -445,8 +470,10 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
           if (std::getenv("RT_GROUP_TRACE")) std::fprintf(stderr, "[rt group] rank %u kernel warm-up %.2f ms\n", r, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count());
           if (g->rc[r] != RT_OK) g->err[r] = rt_hip_last_error();
         }
+        rc_clock.mark("rank0.kernel_warm_up_one_scanline");
       });
     for (auto& t : th) t.join();
+    pc.mark("group.replicas_total_incl_scene_and_rank0_stages");
     for (uint32_t r = 0; r < G; ++r)
       if (g->rc[r] != RT_OK) return bail(g->rc[r], "rank " + std::to_string(r) + ": " + g->err[r]);
   }
@@ -461,11 +488,14 @@ extern "C" int rt_hip_group_create(const RtScene* scene, uint32_t n_gpus, RtHipG
       return bail(RT_ERR_HIP, "hipEventCreate failed");
   }
   g->last = &g->frame[0];
+  pc.mark("group.frame_buffers_events");
   if (g->rccl) {  // never fatal: whatever RCCL cannot do here, peer copies can (the frame is the same bytes either way)
     const std::string why = rtg::try_rccl(g);
     if (!why.empty()) rtg::use_peer_transport(g, why);
   } else if (g->gather) rtg::use_peer_transport(g, "");
+  pc.mark("group.transport");
   for (uint32_t r = 1; r < G; ++r) g->worker.emplace_back(rtg::worker_main, g, r);
+  pc.mark("group.rank_threads");
   if (std::getenv("RT_GROUP_TRACE")) std::fprintf(stderr, "[rt group] create: %.2f ms in all\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_group).count());
   *out = g;
   return RT_OK;
@@ -558,12 +588,14 @@ bool out_is_pinned(const void* p) {
   return a.type == hipMemoryTypeHost;
 }
 // the staging buffers of both frames in flight, ahead of time (rt_render_rgb8: outside its frame_ms window)
-void prepare_staging(RtHipGroup* g) {
+void prepare_staging(RtHipGroup* g, int n_frames) {
   const size_t bytes = (size_t)g->height * g->row_bytes;
   if (!bytes) return;
   (void)hipSetDevice(g->device[0]);
-  for (auto& f : g->frame)
+  for (int i = 0; i < n_frames && i < 2; ++i) {
+    auto& f = g->frame[i];
     if (!f.h_stage && hipHostMalloc((void**)&f.h_stage, bytes, hipHostMallocDefault) != hipSuccess) { f.h_stage = nullptr; (void)hipGetLastError(); }
+  }
   // ... and the copy path itself: the runtime sets its device-to-host machinery up with the first copy of a process (measured:
   // the first hipMemcpyAsync of a one-shot frame kept submit for ~8 ms — seven times the reference's test-scene kernel,
   // profiles/r05_run7_cli_warm_spin.log): one copy of the frame's size through the frame's own stream and buffers, here
@@ -618,9 +650,11 @@ int group_submit(RtHipGroup* g, uint8_t* out_rgb8) {
     if (g->gather) {
       if (g->rccl) {  // ONE gather over xGMI: every rank's packed tiles -> rank 0's `stacked`, each rank's side behind its kernel's event
         ncclResult_t nr = ncclSuccess;
-        const char* inj = std::getenv("RT_RCCL_INJECT");
-        if (inj && !std::strcmp(inj, "gather") && g->n_submitted == 1) nr = ncclInternalError;  // (test hook: the SECOND frame's gather fails to enqueue)
-        else {
+#ifdef RT_TEST_PROBES
+        if (g->inject == 2 && g->n_submitted == 1) nr = ncclInternalError;  // (test hook RT_RCCL_INJECT=gather: the SECOND frame's gather fails to enqueue)
+        else
+#endif
+        {
           nr = g->api.GroupStart();
           for (uint32_t r = 0; r < G && nr == ncclSuccess; ++r)
             nr = g->api.Gather(f.d_tiles[r], f.d_stacked, g->pad_bytes, ncclUint8, 0, g->comm[r], g->xstream[r]);
@@ -761,12 +795,14 @@ extern "C" int rt_render_rgb8(const RtScene* scene, uint8_t* out_rgb8, RtStats* 
   if (!scene || !out_rgb8) return fail(RT_ERR_INVALID, "null argument");
   const auto t0 = std::chrono::steady_clock::now();
   RtHipGroup* g = nullptr;
-  int rc = rt_hip_group_create(scene, 0, &g);
+  int rc = rtg::group_create(scene, 0, &g, true);
   if (rc != RT_OK) return rc;
   // one frame per scene: no later frame could use a queue order learned from this one (tile_order 2 would measure
   // the tile depths and run rt_order_tiles inside frame_ms for nothing) — bottom row first
   (void)rt_hip_group_set_option(g, "tile_order", 1);
-  rtg::prepare_staging(g);  // (the caller's buffer is pageable as a rule: its pinned staging buffer is made before the window opens)
+  rtp::Clock pc;
+  rtg::prepare_staging(g, 1);  // (the caller's buffer is pageable as a rule: its pinned staging buffer — ONE: one frame — is made before the window opens)
+  pc.mark("render.pinned_staging_and_copy_warm_up");
   const double setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   RtStats st;
   rc = rt_hip_group_render_to_host(g, out_rgb8, &st);

@@ -910,6 +910,7 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     int status = LANE_CONTINUE;
     if (has_ray) {
       status = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u, HL ? &light_u : nullptr);
+      if constexpr (HL) { if (status == LANE_REPEAT) L.n_tex_oob = 0u; }  // (the hit is shaded again next iteration: its out-of-range texel counts THEN, once — RtStats.tex_oob equals the oracle's)
       flush_oob();
     }
     const bool finished = status == LANE_FINISHED;
@@ -989,6 +990,15 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
 // Launched once when a scene is created: the runtime loads a module's code object onto the device with the first launch of ANY
 // of its kernels — milliseconds that would otherwise sit inside the first frame.
 __global__ void rt_warm_up() {}
+// ... and the first launch on a queue of a kernel that needs SCRATCH makes the runtime give that queue its scratch memory (every
+// megakernel instantiation has 64 - 112 B per lane: the by-value arguments of its cold calls, a few spilled registers).  Measured
+// on one-shot frames (round 6, profiles/r06_run5_first_launch_wait.log): 0.2 ms when it happens on a fresh device, 13 - 25 ms when
+// 30 MB of textures were uploaded first — so the device warm-up asks for it, with the largest footprint any instantiation has.
+__global__ void rt_warm_up_scratch(uint32_t* out, uint32_t n) {
+  volatile uint32_t pad[32];   // 128 B per lane of private memory, indexed at run time: stays in scratch
+  for (uint32_t i = 0; i < 32u; ++i) pad[(i + n) & 31u] = i * n;
+  if (out && n == 0xFFFFFFFFu) out[threadIdx.x] = pad[threadIdx.x & 31u];   // (never true: keeps the array alive)
+}
 
 // --------------------------------------------------------------------------- queue order for the next frame
 // tile_order <- the tiles sorted by descending tile_depth (counting sort over 64 depth buckets, one workgroup; the

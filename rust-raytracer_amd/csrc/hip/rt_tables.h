@@ -2,16 +2,29 @@
 // rt_core.h::DevScene.  Plain host C++; used by rt_hip_api.hip (upload) and tests/hostsim.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "rt_core.h"
 
 namespace rtc {
+
+// a vector whose resize() leaves new elements uninitialised (they are all written right after: no 29 MB zero fill)
+template <typename T>
+struct DefaultInitAlloc : std::allocator<T> {
+  template <typename U> struct rebind { using other = DefaultInitAlloc<U>; };
+  template <typename U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
+  template <typename U, typename... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+using TexelVec = std::vector<uint32_t, DefaultInitAlloc<uint32_t>>;
 
 struct HostTables {
   std::vector<SphereGeom> geom;
@@ -21,7 +34,7 @@ struct HostTables {
   std::vector<uint64_t> tex_off;  // per RtTexture, byte offset in the blob
   uint64_t tex_bytes = 0;
   // the 4-byte-texel copies the device reads (build_texels): every texture whose records are in texels_fast()'s range, and the sky
-  std::vector<uint32_t> tex4, sky4;
+  TexelVec tex4, sky4;
   bool need_rgb8 = false;            // some Texture sphere takes the general path: the RGB8 blob must be resident too
   bool sky_fast = false;
   uint32_t n_pairs = 0;           // real pairs (cull.size() includes chunk padding)
@@ -354,24 +367,53 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
 // (texture k's first texel = the texel count of textures 0..k-1, as build_tables wrote into SphereMat::texel_off).  The
 // C ABI takes the caller's RGB8 (materials.rs:213-219, config.rs:36-47); this is a device-resident re-layout of the same
 // values.  Only as many textures as fit 2^31 texels are expanded (the records beyond take the RGB8 path).
+// Textures and sky as 4-byte texels (one aligned dword load per fetch, rt_core.h).  29 MB for the reference's test scene: the
+// conversion was 8 ms of a one-shot run's set-up on one core (round 5) — the buffers are now allocated once, never zero-filled
+// (TexelVec) and filled by up to 8 threads in runs of 256 K texels.
 inline void build_texels(const RtScene& sc, HostTables& t) {
-  auto expand = [](const uint8_t* p, uint64_t n_px, std::vector<uint32_t>& out) {
-    const size_t at = out.size();
-    out.resize(at + n_px);
-    for (uint64_t i = 0; i < n_px; ++i) out[at + i] = (uint32_t)p[3 * i] | ((uint32_t)p[3 * i + 1] << 8) | ((uint32_t)p[3 * i + 2] << 16);
-  };
   t.tex4.clear(); t.sky4.clear();
-  uint64_t before = 0;
-  for (uint32_t k = 0; k < sc.n_textures; ++k) {
+  struct Span { const uint8_t* src; uint32_t* dst; uint64_t n; };
+  std::vector<Span> spans;
+  uint64_t total = 0;
+  uint32_t n_tex = 0;
+  for (; n_tex < sc.n_textures; ++n_tex) {
+    const uint64_t n_px = sc.textures[n_tex].nbytes / 3;
+    if (total + n_px >= (1ull << 31)) break;
+    total += n_px;
+  }
+  t.tex4.resize(total);
+  uint64_t at = 0;
+  for (uint32_t k = 0; k < n_tex; ++k) {
     const uint64_t n_px = sc.textures[k].nbytes / 3;
-    if (before + n_px >= (1ull << 31)) break;
-    expand(sc.textures[k].rgb8, n_px, t.tex4);
-    before += n_px;
+    if (n_px) spans.push_back(Span{sc.textures[k].rgb8, t.tex4.data() + at, n_px});
+    at += n_px;
   }
   // (sky_w strictly below 2^24: sky_color() forms y * sky_w with a 24-bit multiply, which keeps only the low 24 bits of each
   //  operand — at sky_w == 2^24 the device product would be 0; y <= sky_h - 1 < 2^24 either way)
   t.sky_fast = sc.sky_mode == RT_SKY_TEXTURE && sc.sky_w < (1ull << 24) && sc.sky_h <= (1ull << 24) && sc.sky_w * sc.sky_h < (1ull << 31);
-  if (t.sky_fast) expand(sc.sky_rgb8, sc.sky_w * sc.sky_h, t.sky4);
+  if (t.sky_fast) {
+    t.sky4.resize(sc.sky_w * sc.sky_h);
+    if (!t.sky4.empty()) spans.push_back(Span{sc.sky_rgb8, t.sky4.data(), sc.sky_w * sc.sky_h});
+    total += sc.sky_w * sc.sky_h;
+  }
+  constexpr uint64_t RUN = 1ull << 18;
+  std::vector<Span> runs;
+  for (const Span& sp : spans)
+    for (uint64_t o = 0; o < sp.n; o += RUN) runs.push_back(Span{sp.src + 3 * o, sp.dst + o, std::min(RUN, sp.n - o)});
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    for (size_t i; (i = next.fetch_add(1)) < runs.size();) {
+      const uint8_t* p = runs[i].src;
+      uint32_t* out = runs[i].dst;
+      for (uint64_t k = 0; k < runs[i].n; ++k) out[k] = (uint32_t)p[3 * k] | ((uint32_t)p[3 * k + 1] << 8) | ((uint32_t)p[3 * k + 2] << 16);
+    }
+  };
+  unsigned hw = std::thread::hardware_concurrency();
+  const unsigned n_threads = (unsigned)std::min<size_t>(std::min<unsigned>(hw ? hw : 1u, 8u), runs.size());
+  std::vector<std::thread> pool;
+  for (unsigned i = 1; i < n_threads; ++i) pool.emplace_back(work);
+  work();
+  for (auto& th : pool) th.join();
 }
 
 inline void fill_dev_scene(const RtScene& sc, const HostTables& t, DevScene& d) {

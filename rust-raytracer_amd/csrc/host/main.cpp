@@ -268,6 +268,25 @@ double g_hip_init_ms = 0.0;
 
 int run(int argc, char** argv) {
   const auto t_main = std::chrono::steady_clock::now();
+  int frames = 0;
+  double orbit = 0.0;
+  bool orbit_given = false, bad_args = argc < 3;
+  for (int i = 3; i < argc && !bad_args; ++i) {
+    if (!std::strcmp(argv[i], "--frames") && i + 1 < argc) frames = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--orbit") && i + 1 < argc) { orbit = std::atof(argv[++i]); orbit_given = true; }
+    else bad_args = true;
+  }
+  if (bad_args || (argc > 3 && frames <= 0)) {  // main.rs:9-12: usage line, normal return
+    std::printf("Usage: %s <config_file> <output_file>\n", argv[0]);
+    return 0;
+  }
+  // One frame per process (the reference's way, main.rs:7-20): the runtime's copy engines are hardware queues it creates at
+  // their FIRST use — 7.8 ms for the first host-to-device copy, 7.8 ms for the first device-to-host copy on MI355X
+  // (tools/microbench/setup_costs.hip) — to move 80 KB of tables in and 2.9 MB of pixels out once.  With HSA_ENABLE_SDMA=0 the
+  // runtime copies with kernels on the compute queue that exists anyway (same copy times at these sizes, measured).  Only here:
+  // an animation keeps the engines — its copies run UNDER the next frame's kernel, which leaves a copy kernel no registers.
+  // A value the user set is left alone.
+  if (frames == 0) setenv("HSA_ENABLE_SDMA", "0", 0);
   g_hip_init = std::thread([]() {
     const auto t0 = std::chrono::steady_clock::now();
     const int n = rt_hip_device_count();
@@ -282,18 +301,6 @@ int run(int argc, char** argv) {
     g_hip_init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   });
   auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-  int frames = 0;
-  double orbit = 0.0;
-  bool orbit_given = false, bad_args = argc < 3;
-  for (int i = 3; i < argc && !bad_args; ++i) {
-    if (!std::strcmp(argv[i], "--frames") && i + 1 < argc) frames = std::atoi(argv[++i]);
-    else if (!std::strcmp(argv[i], "--orbit") && i + 1 < argc) { orbit = std::atof(argv[++i]); orbit_given = true; }
-    else bad_args = true;
-  }
-  if (bad_args || (argc > 3 && frames <= 0)) {  // main.rs:9-12: usage line, normal return
-    std::printf("Usage: %s <config_file> <output_file>\n", argv[0]);
-    return 0;
-  }
   RtSceneFile* sf = nullptr;
   int rc = rt_scene_load_file(argv[1], &sf);
   if (rc != RT_OK) {
@@ -332,11 +339,12 @@ int run(int argc, char** argv) {
     std::fprintf(stderr, "{\"samples\":%llu,\"segments\":%llu,\"sphere_tests\":%llu,\"exact_tests\":%llu,\"n_gpus\":%u,\"kernel_ms\":%.3f,"
                          "\"gather_ms\":%.3f,\"frame_ms\":%.3f,\"setup_ms\":%.3f,\"msamples_per_s\":%.3f,"
                          "\"load_ms\":%.3f,\"read_ms\":%.3f,\"json_ms\":%.3f,\"jpeg_ms\":%.3f,\"hip_init_ms\":%.3f,\"hip_wait_ms\":%.3f,\"png_ms\":%.3f,\"main_ms\":%.3f,"
-                         "\"group_us\":[%.1f,%.1f,%.1f,%.1f,%.1f,%.1f,%.1f,%.1f]}\n",
+                         "\"group_us\":[%.1f,%.1f,%.1f,%.1f,%.1f,%.1f,%.1f,%.1f],\"setup_profile\":%s}\n",
                  (unsigned long long)st.samples, (unsigned long long)st.segments, (unsigned long long)st.sphere_tests,
                  (unsigned long long)st.exact_tests, st.n_gpus_used, st.kernel_ms, st.gather_ms, st.frame_ms, st.setup_ms,
                  st.samples / (st.kernel_ms * 1e3), load_done_ms, lt[0], lt[1], lt[2], hip_init_ms, hip_wait_ms, png_ms, ms_since(t_main),
-                 st.group_us[0], st.group_us[1], st.group_us[2], st.group_us[3], st.group_us[4], st.group_us[5], st.group_us[6], st.group_us[7]);
+                 st.group_us[0], st.group_us[1], st.group_us[2], st.group_us[3], st.group_us[4], st.group_us[5], st.group_us[6], st.group_us[7],
+                 rt_hip_setup_profile());
   }
   rt_scene_free(sf);
   if (rc != RT_OK) {

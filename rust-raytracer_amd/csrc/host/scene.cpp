@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <future>
+#include <initializer_list>
 #include <map>
 #include <memory>
 #include <string>
@@ -32,15 +33,10 @@ int set_err(int code, const std::string& m) { g_err = m; return code; }
 
 struct SchemaError { std::string msg; };
 [[noreturn]] void bad(const std::string& m) { throw SchemaError{m}; }
+struct UnsupportedError { std::string msg; };  // the document is what serde would accept, this build cannot hold it (RT_ERR_UNSUPPORTED)
 
 using rtjson::Value;
 
-const Value& field(const Value& obj, const char* key, const char* where) {
-  if (obj.kind != Value::Object) bad(std::string("expected object for ") + where);
-  const Value* v = obj.find(key);
-  if (!v) bad(std::string("missing field `") + key + "` in " + where);
-  return *v;
-}
 double as_f64(const Value& v, const char* what) {
   if (v.kind != Value::Number) bad(std::string("expected number for ") + what);
   const double x = std::strtod(v.text.c_str(), nullptr);
@@ -62,10 +58,49 @@ uint64_t as_u64(const Value& v, const char* what, uint64_t max) {
   if (errno == ERANGE || x > max) bad(std::string("integer out of range for ") + what);
   return x;
 }
+// A serde-derive struct (point3d.rs:10-15, camera.rs:29-36, sphere.rs:18-23, materials.rs:56-57/71-76/97-103/131-134/201-211,
+// config.rs:20-28/66-75): serde_json's deserialize_struct takes it as a MAP — unknown keys ignored, a known key twice is the
+// error "duplicate field", a missing one "missing field" (an Option field: None) — or as a SEQUENCE of exactly its fields in
+// declaration order ("center":[0,0,0], "Light":[]).  out[i] = the value of keys[i]; nullptr only for a missing optional field.
+void struct_fields(const Value& v, const char* name, std::initializer_list<const char*> keys, const Value** out,
+                   std::initializer_list<bool> optional = {}) {
+  const size_t n = keys.size();
+  for (size_t i = 0; i < n; ++i) out[i] = nullptr;
+  if (v.kind == Value::Array) {
+    if (v.items.size() != n)
+      bad("invalid length " + std::to_string(v.items.size()) + ", expected struct " + name + " with " + std::to_string(n) + " element" + (n == 1 ? "" : "s"));
+    for (size_t i = 0; i < n; ++i) out[i] = v.items[i].get();
+    return;
+  }
+  if (v.kind != Value::Object) bad(std::string("invalid type: expected struct ") + name);
+  for (auto& m : v.members) {
+    size_t i = 0;
+    for (const char* k : keys) {
+      if (m.first == k) {
+        if (out[i]) bad(std::string("duplicate field `") + k + "`");
+        out[i] = m.second.get();
+        break;
+      }
+      ++i;
+    }
+  }
+  size_t i = 0;
+  for (const char* k : keys) {
+    const bool opt = i < optional.size() && *(optional.begin() + i);
+    if (!out[i] && !opt) bad(std::string("missing field `") + k + "` in " + name);
+    ++i;
+  }
+}
 void as_point(const Value& v, const char* what, double out[3]) {
-  out[0] = as_f64(field(v, "x", what), what);
-  out[1] = as_f64(field(v, "y", what), what);
-  out[2] = as_f64(field(v, "z", what), what);
+  const Value* f[3];
+  struct_fields(v, "Point3D", {"x", "y", "z"}, f);
+  for (int i = 0; i < 3; ++i) out[i] = as_f64(*f[i], what);
+}
+// usize fields of Config (config.rs:67-70): serde takes any u64; a frame side beyond u32 is valid JSON this build cannot render
+uint32_t as_frame_u32(const Value& v, const char* what) {
+  const uint64_t x = as_u64(v, what, ~0ull);
+  if (x > 0xFFFFFFFFull) throw UnsupportedError{std::string(what) + " = " + v.text + " does not fit 32 bits"};
+  return uint32_t(x);
 }
 
 }  // namespace
@@ -209,22 +244,30 @@ void parse_albedo(const Value& v, float out[3]) {
 }
 
 void build_scene(const Value& root, RtSceneFile& sf) {
-  if (root.kind != Value::Object) bad("expected a Config object");
+  const Value* cf[7];
+  struct_fields(root, "Config", {"width", "height", "samples_per_pixel", "max_depth", "sky", "camera", "objects"}, cf,
+                {false, false, false, false, true, false, false});
   RtScene& sc = sf.scene;
   sc.abi_version = RT_ABI_VERSION;
-  sc.width = uint32_t(as_u64(field(root, "width", "Config"), "width", 0xFFFFFFFFull));
-  sc.height = uint32_t(as_u64(field(root, "height", "Config"), "height", 0xFFFFFFFFull));
-  sc.samples_per_pixel = uint32_t(as_u64(field(root, "samples_per_pixel", "Config"), "samples_per_pixel", 0xFFFFFFFFull));
-  sc.max_depth = uint32_t(as_u64(field(root, "max_depth", "Config"), "max_depth", 0x7FFFFFFFull));
+  sc.width = as_frame_u32(*cf[0], "width");
+  sc.height = as_frame_u32(*cf[1], "height");
+  sc.samples_per_pixel = uint32_t(as_u64(*cf[2], "samples_per_pixel", 0xFFFFFFFFull));   // u32 in the reference: beyond it serde errors too
+  {
+    const uint64_t d = as_u64(*cf[3], "max_depth", ~0ull);
+    if (d > 0x7FFFFFFFull) throw UnsupportedError{"max_depth = " + cf[3]->text + " does not fit 31 bits"};
+    sc.max_depth = uint32_t(d);
+  }
 
   std::map<std::string, uint32_t> cache;
   DecodeJobsGuard dj;
   start_all_decodes(root, dj.jobs);
   // config.rs:22-28, 49-64: Option<Sky>; texture "" -> None
-  const Value* sky = root.find("sky");
+  const Value* sky = cf[4];
   sc.sky_mode = RT_SKY_NONE;
   if (sky && sky->kind != Value::Null) {
-    const Value& tex = field(*sky, "texture", "Sky");
+    const Value* sk[1];
+    struct_fields(*sky, "Sky", {"texture"}, sk);
+    const Value& tex = *sk[0];
     if (tex.kind != Value::String) bad("Sky.texture: expected a string");
     if (tex.text.empty()) sc.sky_mode = RT_SKY_GRADIENT;
     else {
@@ -242,47 +285,56 @@ void build_scene(const Value& root, RtSceneFile& sf) {
   }
 
   // camera.rs:29-42 CameraParams -> Camera::new
-  const Value& cam = field(root, "camera", "Config");
-  as_point(field(cam, "look_from", "camera"), "camera.look_from", sf.look_from);
-  as_point(field(cam, "look_at", "camera"), "camera.look_at", sf.look_at);
-  as_point(field(cam, "vup", "camera"), "camera.vup", sf.vup);
-  sf.vfov = as_f64(field(cam, "vfov", "camera"), "camera.vfov");
-  sf.aspect = as_f64(field(cam, "aspect", "camera"), "camera.aspect");
+  const Value* cam[5];
+  struct_fields(*cf[5], "CameraParams", {"look_from", "look_at", "vup", "vfov", "aspect"}, cam);
+  as_point(*cam[0], "camera.look_from", sf.look_from);
+  as_point(*cam[1], "camera.look_at", sf.look_at);
+  as_point(*cam[2], "camera.vup", sf.vup);
+  sf.vfov = as_f64(*cam[3], "camera.vfov");
+  sf.aspect = as_f64(*cam[4], "camera.aspect");
   double c[13];
   rt_camera_derive(sf.look_from, sf.look_at, sf.vup, sf.vfov, sf.aspect, c);
   std::memcpy(sc.cam_origin, c, 24); std::memcpy(sc.cam_lower_left, c + 3, 24);
   std::memcpy(sc.cam_horizontal, c + 6, 24); std::memcpy(sc.cam_vertical, c + 9, 24);
   sf.focal_length = c[12];
 
-  const Value& objs = field(root, "objects", "Config");
+  const Value& objs = *cf[6];
   if (objs.kind != Value::Array) bad("objects: expected an array");
+  if (objs.items.size() > 0xFFFFFFFFull) throw UnsupportedError{"more than 2^32 - 1 objects"};
   sf.spheres.reserve(objs.items.size());
   for (auto& o : objs.items) {
     RtSphere s{};
-    as_point(field(*o, "center", "Sphere"), "Sphere.center", s.center);
-    s.radius = as_f64(field(*o, "radius", "Sphere"), "Sphere.radius");
-    const Value& m = field(*o, "material", "Sphere");
+    const Value* sp[3];
+    struct_fields(*o, "Sphere", {"center", "radius", "material"}, sp);
+    as_point(*sp[0], "Sphere.center", s.center);
+    s.radius = as_f64(*sp[1], "Sphere.radius");
+    const Value& m = *sp[2];
+    // externally tagged enum (materials.rs:35-42): a map with exactly one key (a second one — also the same one twice — is an error)
     if (m.kind != Value::Object || m.members.size() != 1) bad("material: expected a single-key enum object");
     const std::string& tag = m.members[0].first;
     const Value& body = *m.members[0].second;
+    const Value* f[5];
     if (tag == "Lambertian") {
-      s.kind = RT_MAT_LAMBERTIAN; parse_albedo(field(body, "albedo", "Lambertian"), s.albedo);
+      struct_fields(body, "Lambertian", {"albedo"}, f);
+      s.kind = RT_MAT_LAMBERTIAN; parse_albedo(*f[0], s.albedo);
     } else if (tag == "Metal") {
-      s.kind = RT_MAT_METAL; parse_albedo(field(body, "albedo", "Metal"), s.albedo);
-      s.fuzz_or_ior = as_f64(field(body, "fuzz", "Metal"), "Metal.fuzz");
+      struct_fields(body, "Metal", {"albedo", "fuzz"}, f);
+      s.kind = RT_MAT_METAL; parse_albedo(*f[0], s.albedo);
+      s.fuzz_or_ior = as_f64(*f[1], "Metal.fuzz");
     } else if (tag == "Glass") {
+      struct_fields(body, "Glass", {"index_of_refraction"}, f);
       s.kind = RT_MAT_GLASS;
-      s.fuzz_or_ior = as_f64(field(body, "index_of_refraction", "Glass"), "Glass.index_of_refraction");
+      s.fuzz_or_ior = as_f64(*f[0], "Glass.index_of_refraction");
     } else if (tag == "Texture") {
-      s.kind = RT_MAT_TEXTURE; parse_albedo(field(body, "albedo", "Texture"), s.albedo);
-      const Value& px = field(body, "pixels", "Texture");
-      if (px.kind != Value::String) bad("Texture.pixels: expected a path string");
-      s.tex_w = as_u64(field(body, "width", "Texture"), "Texture.width", ~0ull);
-      s.tex_h = as_u64(field(body, "height", "Texture"), "Texture.height", ~0ull);
-      s.h_offset = as_f64(field(body, "h_offset", "Texture"), "Texture.h_offset");
-      s.tex_id = load_texture(sf, cache, dj, px.text);
+      struct_fields(body, "Texture", {"albedo", "pixels", "width", "height", "h_offset"}, f);
+      s.kind = RT_MAT_TEXTURE; parse_albedo(*f[0], s.albedo);
+      if (f[1]->kind != Value::String) bad("Texture.pixels: expected a path string");
+      s.tex_w = as_u64(*f[2], "Texture.width", ~0ull);
+      s.tex_h = as_u64(*f[3], "Texture.height", ~0ull);
+      s.h_offset = as_f64(*f[4], "Texture.h_offset");
+      s.tex_id = load_texture(sf, cache, dj, f[1]->text);
     } else if (tag == "Light") {
-      if (body.kind != Value::Object) bad("Light: expected {}");
+      struct_fields(body, "Light", {}, f);   // materials.rs:56-57: `struct Light {}` — {} or []
       s.kind = RT_MAT_LIGHT;
     } else {
       bad("unknown variant `" + tag + "`, expected one of `Lambertian`, `Metal`, `Glass`, `Texture`, `Light`");
@@ -392,6 +444,8 @@ extern "C" int rt_scene_load_string(const char* json_text, size_t len, RtSceneFi
     build_scene(*root, *sf);
   } catch (const rtjson::ParseError& e) {
     return set_err(RT_ERR_PARSE, std::string("Unable to parse config json: ") + e.what());
+  } catch (const UnsupportedError& e) {
+    return set_err(RT_ERR_UNSUPPORTED, "config is valid but unsupported: " + e.msg);
   } catch (const SchemaError& e) {
     bool tex = e.msg.rfind("texture ", 0) == 0 || e.msg.rfind("sky texture ", 0) == 0;
     return set_err(tex ? RT_ERR_TEXTURE : RT_ERR_PARSE, (tex ? std::string() : std::string("Unable to parse config json: ")) + e.msg);

@@ -39,6 +39,7 @@ def _bind(path, probes):
     L.rt_hip_device_count.restype = C.c_int
     L.rt_hip_device_warm.argtypes = [C.c_int]
     L.rt_hip_last_error.restype = C.c_char_p
+    L.rt_hip_setup_profile.restype = C.c_char_p
     L.rt_strerror.argtypes = [C.c_int]
     L.rt_strerror.restype = C.c_char_p
     L.rt_hip_scene_create.argtypes = [C.POINTER(abi.RtScene), C.c_int, C.POINTER(C.c_void_p)]
@@ -113,6 +114,12 @@ def _check(rc, L=None):
     if rc != abi.RT_OK:
         L = L or lib()
         raise RtError(rc, f"{L.rt_strerror(rc).decode()}: {L.rt_hip_last_error().decode('utf-8', 'replace')}")
+
+
+def setup_profile():
+    """rt_hip_setup_profile: {stage: ms} of the most recent group creation / one-shot render of this process"""
+    import json
+    return json.loads(lib().rt_hip_setup_profile().decode())
 
 
 def device_count():
@@ -196,72 +203,73 @@ class HipGroup:
     """The scene resident on n_gpus devices of this node, frames sharded by interleaved scanline tiles
     inside librt_hip.so (rt_hip_group_*): host threads + streams + ONE gather per frame, no torch."""
 
-    def __init__(self, scene_ptr, n_gpus=0):
+    def __init__(self, scene_ptr, n_gpus=0, library=None):
+        self._L = library or lib()     # (library: probe_lib() for the tests that inject transport faults)
         self._h = C.c_void_p()
-        _check(lib().rt_hip_group_create(scene_ptr, n_gpus, C.byref(self._h)))
+        _check(self._L.rt_hip_group_create(scene_ptr, n_gpus, C.byref(self._h)), self._L)
         sc = scene_ptr.contents
         self.width, self.height = sc.width, sc.height
-        self.size = lib().rt_hip_group_size(self._h)
+        self.size = self._L.rt_hip_group_size(self._h)
 
     def set_option(self, key, value):
-        _check(lib().rt_hip_group_set_option(self._h, key.encode(), int(value)))
+        _check(self._L.rt_hip_group_set_option(self._h, key.encode(), int(value)), self._L)
 
     def set_camera(self, origin, lower_left, horizontal, vertical):
         v = [(C.c_double * 3)(*x) for x in (origin, lower_left, horizontal, vertical)]
-        _check(lib().rt_hip_group_set_camera(self._h, *v))
+        _check(self._L.rt_hip_group_set_camera(self._h, *v), self._L)
 
     def render_to_host(self, out=None):
         import numpy as np
         if out is None:
             out = np.zeros((self.height, self.width, 3), np.uint8)
         st = abi.RtStats()
-        _check(lib().rt_hip_group_render_to_host(self._h, out.ctypes.data, C.byref(st)))
+        _check(self._L.rt_hip_group_render_to_host(self._h, out.ctypes.data, C.byref(st)), self._L)
         return out, st.as_dict()
 
     def render(self):
         """one frame, left in HBM of the group's first device (frame_ptr()); blocking; returns the stats"""
         st = abi.RtStats()
-        _check(lib().rt_hip_group_render(self._h, C.byref(st)))
+        _check(self._L.rt_hip_group_render(self._h, C.byref(st)), self._L)
         return st.as_dict()
 
     def submit(self, out=None):
         """enqueue one frame (rt_hip_group_submit); `out`: a numpy uint8 [h,w,3] array the frame is copied into (it must stay
         alive until the frame is collected), or None to leave it in HBM.  Two frames may be in flight."""
-        _check(lib().rt_hip_group_submit(self._h, out.ctypes.data if out is not None else None))
+        _check(self._L.rt_hip_group_submit(self._h, out.ctypes.data if out is not None else None), self._L)
 
     def collect(self):
         """wait for the oldest submitted frame (rt_hip_group_collect); returns its stats"""
         st = abi.RtStats()
-        _check(lib().rt_hip_group_collect(self._h, C.byref(st)))
+        _check(self._L.rt_hip_group_collect(self._h, C.byref(st)), self._L)
         return st.as_dict()
 
     def frame_ptr(self):
         """(device pointer of the assembled RGB8 frame collected last, device ordinal)"""
         dev = C.c_int(0)
-        return lib().rt_hip_group_frame(self._h, C.byref(dev)), dev.value
+        return self._L.rt_hip_group_frame(self._h, C.byref(dev)), dev.value
 
     def info(self):
         """what the group runs on: ranks, distinct devices, gather transport, RCCL communicators (rt_hip_group_info)"""
         gi = abi.RtGroupInfo()
-        _check(lib().rt_hip_group_info(self._h, C.byref(gi)))
+        _check(self._L.rt_hip_group_info(self._h, C.byref(gi)), self._L)
         return {"n_ranks": gi.n_ranks, "n_devices": gi.n_devices, "transport": ("none", "rccl", "peer")[gi.transport],
                 "rccl_comms": gi.rccl_comms, "tile_rows": gi.tile_rows, "pad_rows": gi.pad_rows, "emulated": bool(gi.emulated),
                 "transport_fallback": bool(gi.transport_fallback),
-                "fallback_reason": (lib().rt_hip_group_fallback_reason(self._h) or b"").decode("utf-8", "replace"),
+                "fallback_reason": (self._L.rt_hip_group_fallback_reason(self._h) or b"").decode("utf-8", "replace"),
                 "rank_devices": [gi.device[r] for r in range(min(gi.n_ranks, abi.RT_GROUP_INFO_MAX_RANKS))]}
 
     def ranks(self):
         """per rank: where it runs (device, PCI id, NUMA node, CPUs its host thread is pinned to, peer access to the first rank's
         device) and its share of the last frame (kernel_ms of the frame collected last; t_wake_us / t_enq_us of the frame submitted last)"""
-        n = lib().rt_hip_group_ranks(self._h, None, 0)
+        n = self._L.rt_hip_group_ranks(self._h, None, 0)
         arr = (abi.RtGroupRank * n)()
-        lib().rt_hip_group_ranks(self._h, arr, n)
+        self._L.rt_hip_group_ranks(self._h, arr, n)
         return [{"device": a.device, "pci_bus_id": a.pci_bus_id.decode("ascii", "replace"), "numa_node": a.numa_node, "pinned_cpus": a.pinned_cpus,
                  "peer_to_root": a.peer_to_root, "kernel_ms": a.kernel_ms, "t_wake_us": a.t_wake_us, "t_enq_us": a.t_enq_us} for a in arr]
 
     def close(self):
         if self._h:
-            lib().rt_hip_group_destroy(self._h)
+            self._L.rt_hip_group_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

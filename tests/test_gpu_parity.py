@@ -873,7 +873,8 @@ def test_group_transport_fallback_never_costs_the_frame(pkg, gpu_render, load_sc
              ("selftest", {"RT_RCCL_INJECT": "selftest"}, "peer", "self-test gather delivered"), ("gather", {"RT_RCCL_INJECT": "gather"}, "peer", "ncclGather"))
     for name, extra, transport, reason in cases:
         def run():
-            grp = pkg.hip.HipGroup(sc.ptr, 1)
+            # (the fault-injection hooks exist in librt_hip_probe.so only — the same sources + -DRT_TEST_PROBES)
+            grp = pkg.hip.HipGroup(sc.ptr, 1, library=pkg.hip.probe_lib() if "RT_RCCL_INJECT" in extra else None)
             infos = [grp.info()]
             frames = []
             for _ in range(3):                  # (the injected gather failure hits the second submit of the group)
@@ -896,6 +897,19 @@ def test_group_transport_fallback_never_costs_the_frame(pkg, gpu_render, load_sc
             assert first["transport"] == "peer" and first["rccl_comms"] == 0
         assert len(ranks) == 1 and ranks[0]["device"] == 0 and ranks[0]["kernel_ms"] > 0 and ranks[0]["peer_to_root"] == 1 and len(ranks[0]["pci_bus_id"]) >= 7, ranks
         print(f"group transport case {name}: {last['transport']} fallback={last['transport_fallback']} reason={last['fallback_reason']!r} rank0={ranks[0]}")
+    # ... and the PRODUCT library does not read RT_RCCL_INJECT: a stray variable cannot switch its transport
+
+    def product_run():
+        grp = pkg.hip.HipGroup(sc.ptr, 1)
+        for _ in range(3):
+            out, _ = grp.render_to_host()
+            assert np.array_equal(out, rgb)
+        info = grp.info()
+        grp.close()
+        return info
+    for inj in ("selftest", "gather"):
+        info = _with_env(dict(base, RT_RCCL_INJECT=inj), product_run)
+        assert info["transport"] == "rccl" and not info["transport_fallback"], (inj, info)
 
 
 @pytest.mark.parametrize("world,env,bar_us", [(1, {}, 150.0), (8, {"RT_GPUS_EMULATE": "1"}, 400.0)])
@@ -1054,7 +1068,7 @@ def test_bench_line_contract(force_rccl):
             assert a["frames"] == 32 and a["pngs_on_disk"] == 32 and a["frames_per_s"] > 0 and len(a["kernel_ms_series"]) == 32
             assert a["kernel_ms_moving_camera"]["median"] > 0 and a["png_ms"]["median"] > 0 and a["bound_by"] in ("kernel", "png")
             assert 0 < a["overlap_efficiency"] <= 1.05
-        assert an[0]["moving_over_steady"] > 0.8
+        assert an[0]["moving_over_steady"] > 0.8 and len(an[0]["same_views"]["frames"]) == 5
 
 
 @pytest.mark.parametrize("kind", range(6))

@@ -403,3 +403,88 @@ def test_scene_load_timings(host, abi):
         assert read_ms > 0 and json_ms > 0 and total_ms >= json_ms and total_ms >= jpeg_ms
         assert (jpeg_ms > 1.0) == wants_jpeg, (path, jpeg_ms)
         assert total_ms < 5000
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# corner cases of serde-derive + serde_json the shipped scenes never touch.  What serde does:
+#   * a derived struct deserialises from a MAP (unknown keys ignored; a known key twice = "duplicate field"; a missing key =
+#     "missing field", an Option field = None) or from a SEQUENCE of exactly its fields in declaration order
+#     (point3d.rs:10-15 `"center":[0,0,0]`, materials.rs:56-57 `"Light":[]`, camera.rs:29-36, sphere.rs:18-23, config.rs:66-75);
+#   * an externally tagged enum (materials.rs:35-42) is a map with exactly ONE key;
+#   * usize fields (config.rs:67-70) take any u64 — a frame side beyond u32 is a valid document this build cannot render:
+#     RT_ERR_UNSUPPORTED, not a parse error; samples_per_pixel is u32 in the reference: beyond it serde errors too.
+_P = '{"x":0.0,"y":0.0,"z":-1.0}'
+_LAMB = '{"Lambertian":{"albedo":[0.8,0.3,0.3]}}'
+_SERDE_CASES = [
+    # ---- sequence form of structs: accepted
+    ("point_as_sequence", CFG_DEFAULT_SKY.replace('"center":' + _P, '"center":[0.0,0.0,-1.0]'), "ok"),
+    ("camera_points_as_sequences", CFG_DEFAULT_SKY.replace('"look_at":' + _P, '"look_at":[0,0,-1]').replace('"vup":{"x":0.0,"y":1.0,"z":0.0}', '"vup":[0,1,0]'), "ok"),
+    ("camera_params_as_sequence", CFG_DEFAULT_SKY.replace('"camera":{"look_from":{"x":0.0,"y":0.0,"z":0.0},"look_at":' + _P + ',"vup":{"x":0.0,"y":1.0,"z":0.0},"vfov":90.0,"aspect":1.0}',
+                                                          '"camera":[[0,0,0],[0,0,-1],[0,1,0],90.0,1.0]'), "ok"),
+    ("sphere_as_sequence", CFG_DEFAULT_SKY.replace('{"center":' + _P + ',"radius":0.5,"material":' + _LAMB + '}', '[[0,0,-1],0.5,' + _LAMB + ']'), "ok"),
+    ("lambertian_payload_as_sequence", CFG_DEFAULT_SKY.replace(_LAMB, '{"Lambertian":[[0.8,0.3,0.3]]}'), "ok"),
+    ("metal_payload_as_sequence", CFG_DEFAULT_SKY.replace(_LAMB, '{"Metal":[[0.8,0.3,0.3],0.25]}'), "ok"),
+    ("glass_payload_as_sequence", CFG_DEFAULT_SKY.replace(_LAMB, '{"Glass":[1.5]}'), "ok"),
+    ("light_as_empty_sequence", CFG_DEFAULT_SKY.replace(_LAMB, '{"Light":[]}'), "ok"),
+    ("light_as_empty_map", CFG_DEFAULT_SKY.replace(_LAMB, '{"Light":{}}'), "ok"),
+    ("light_map_with_unknown_key", CFG_DEFAULT_SKY.replace(_LAMB, '{"Light":{"watts":60}}'), "ok"),
+    ("texture_payload_as_sequence", CFG_DEFAULT_SKY.replace(_LAMB, '{"Texture":[[1,1,1],"scenes/data/earth.jpg",2048,1024,0.75]}'), "ok"),
+    ("sky_as_sequence", CFG_DEFAULT_SKY.replace('"sky":{"texture":""}', '"sky":[""]'), "ok"),
+    ("config_as_sequence", '[100,100,1,1,null,' + CFG_DEFAULT_SKY[CFG_DEFAULT_SKY.index('"camera":') + 9:CFG_DEFAULT_SKY.index(',"objects"')] + ',' +
+     CFG_DEFAULT_SKY[CFG_DEFAULT_SKY.index('"objects":') + 10:-1] + ']', "ok"),
+    ("sky_field_missing_is_none", CFG_DEFAULT_SKY.replace('"sky":{"texture":""},', ''), "ok"),
+    # ---- sequence form with the wrong length: "invalid length"; other wrong types
+    ("point_sequence_too_short", CFG_DEFAULT_SKY.replace('"center":' + _P, '"center":[0.0,0.0]'), "RT_ERR_PARSE"),
+    ("point_sequence_too_long", CFG_DEFAULT_SKY.replace('"center":' + _P, '"center":[0.0,0.0,-1.0,2.0]'), "RT_ERR_PARSE"),
+    ("light_sequence_not_empty", CFG_DEFAULT_SKY.replace(_LAMB, '{"Light":[1]}'), "RT_ERR_PARSE"),
+    ("light_null", CFG_DEFAULT_SKY.replace(_LAMB, '{"Light":null}'), "RT_ERR_PARSE"),
+    ("point_as_number", CFG_DEFAULT_SKY.replace('"center":' + _P, '"center":3'), "RT_ERR_PARSE"),
+    ("metal_sequence_missing_fuzz", CFG_DEFAULT_SKY.replace(_LAMB, '{"Metal":[[0.8,0.3,0.3]]}'), "RT_ERR_PARSE"),
+    # ---- duplicate keys: "duplicate field" for a known key, fine for an ignored one
+    ("duplicate_width", CFG_DEFAULT_SKY.replace('"width":100', '"width":8,"width":9'), "RT_ERR_PARSE"),
+    ("duplicate_sky", CFG_DEFAULT_SKY.replace('"sky":{"texture":""}', '"sky":null,"sky":null'), "RT_ERR_PARSE"),
+    ("duplicate_point_coordinate", CFG_DEFAULT_SKY.replace('"center":' + _P, '"center":{"x":0.0,"x":1.0,"y":0.0,"z":-1.0}'), "RT_ERR_PARSE"),
+    ("duplicate_radius", CFG_DEFAULT_SKY.replace('"radius":0.5', '"radius":0.5,"radius":0.5'), "RT_ERR_PARSE"),
+    ("duplicate_albedo", CFG_DEFAULT_SKY.replace('{"albedo":[0.8,0.3,0.3]}', '{"albedo":[0.8,0.3,0.3],"albedo":[0.1,0.1,0.1]}'), "RT_ERR_PARSE"),
+    ("duplicate_enum_tag", CFG_DEFAULT_SKY.replace(_LAMB, '{"Light":{},"Light":{}}'), "RT_ERR_PARSE"),
+    ("two_enum_tags", CFG_DEFAULT_SKY.replace(_LAMB, '{"Light":{},"Glass":{"index_of_refraction":1.5}}'), "RT_ERR_PARSE"),
+    ("duplicate_unknown_key_is_ignored_twice", CFG_DEFAULT_SKY.replace('"radius":0.5', '"radius":0.5,"note":1,"note":2'), "ok"),
+    # ---- usize / u32 ranges
+    ("width_2_pow_32", CFG_DEFAULT_SKY.replace('"width":100', '"width":4294967296'), "RT_ERR_UNSUPPORTED"),
+    ("height_u64_max", CFG_DEFAULT_SKY.replace('"height":100', '"height":18446744073709551615'), "RT_ERR_UNSUPPORTED"),
+    ("width_beyond_u64", CFG_DEFAULT_SKY.replace('"width":100', '"width":18446744073709551616'), "RT_ERR_PARSE"),
+    ("max_depth_2_pow_40", CFG_DEFAULT_SKY.replace('"max_depth":1', '"max_depth":1099511627776'), "RT_ERR_UNSUPPORTED"),
+    ("spp_beyond_u32", CFG_DEFAULT_SKY.replace('"samples_per_pixel":1', '"samples_per_pixel":4294967296'), "RT_ERR_PARSE"),
+    ("width_u32_max_is_a_config", CFG_DEFAULT_SKY.replace('"width":100', '"width":4294967295'), "ok"),
+]
+
+
+@pytest.mark.parametrize("name,text,want", _SERDE_CASES, ids=[c[0] for c in _SERDE_CASES])
+def test_serde_corner_cases(host, abi, name, text, want):
+    assert text != CFG_DEFAULT_SKY, name     # (the case's replacement took)
+    if want == "ok":
+        sc = host.Scene.loads(text)
+        assert sc.c.n_spheres == 1
+        ref = host.Scene.loads(CFG_DEFAULT_SKY)
+        # the sequence forms describe the SAME scene as the map forms (where the case did not change a value)
+        if name in ("point_as_sequence", "camera_points_as_sequences", "camera_params_as_sequence", "sphere_as_sequence", "lambertian_payload_as_sequence", "sky_as_sequence"):
+            assert sc.to_json() == ref.to_json()
+        if name == "config_as_sequence":
+            assert sc.to_json() == host.Scene.loads(CFG_NULL_SKY).to_json()
+        if name == "sky_field_missing_is_none":
+            assert sc.c.sky_mode == abi.RT_SKY_NONE
+        if name == "metal_payload_as_sequence":
+            assert sc.c.spheres[0].kind == abi.RT_MAT_METAL and sc.c.spheres[0].fuzz_or_ior == 0.25
+        if name == "texture_payload_as_sequence":
+            s0 = sc.c.spheres[0]
+            assert s0.kind == abi.RT_MAT_TEXTURE and (s0.tex_w, s0.tex_h, s0.h_offset) == (2048, 1024, 0.75) and sc.c.n_textures == 1
+        if name.startswith("light_"):
+            assert sc.c.spheres[0].kind == abi.RT_MAT_LIGHT and sc.lights() == [0]
+    else:
+        with pytest.raises(host.RtError) as e:
+            host.Scene.loads(text)
+        assert e.value.code == getattr(abi, want), (name, str(e.value))
+        if name.startswith("duplicate_") and "enum" not in name:
+            assert "duplicate field" in str(e.value)
+        if "too_" in name or name in ("light_sequence_not_empty", "metal_sequence_missing_fuzz"):
+            assert "invalid length" in str(e.value)

@@ -263,3 +263,54 @@ def test_shared_atan2_against_a_million_correctly_rounded_results(oracle, abi):
     oracle.lib(abi).rt_oracle_atan2_v(y.ctypes.data, x.ctypes.data, got.ctypes.data, y.size)
     differs = check_atan2_against_the_fixture(got, y, x)
     assert differs <= 0.1 * y.size   # (numpy's vectorised arctan2 — not glibc's — is off by an ulp for ~6 % of these arguments; never more than a few)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# VERDICT r5 #5 / missing #6: the reference's KATs pin leaf functions; ray_color's CONTROL FLOW (light loop, per-level clamp,
+# absorbed / emitter returns, raytracer.rs:86-131) is pinned by nothing the reference holds.  tests/mini_oracle.py is a second
+# restatement, written from the .rs sources without opening rt_oracle.c; the two must agree BIT FOR BIT.
+def _three_lights_world():
+    objs = ['{"center":{"x":0.0,"y":-100.5,"z":-1.0},"radius":100.0,"material":{"Lambertian":{"albedo":[0.7,0.7,0.7]}}}']
+    for i, x in enumerate((-2.0, 0.0, 2.0)):
+        objs.append('{"center":{"x":%f,"y":2.5,"z":-2.0},"radius":0.5,"material":{"Light":{}}}' % x)
+        objs.append('{"center":{"x":%f,"y":0.0,"z":-1.5},"radius":0.5,"material":{"%s}}' %
+                    (x, ['Lambertian":{"albedo":[0.9,0.2,0.2]}', 'Glass":{"index_of_refraction":1.5}', 'Metal":{"albedo":[0.8,0.8,0.9],"fuzz":0.2}'][i]))
+        objs.append('{"center":{"x":%f,"y":1.2,"z":-1.8},"radius":0.3,"material":{"Lambertian":{"albedo":[0.3,0.9,0.4]}}}' % x)
+    return ('{"width":30,"height":20,"samples_per_pixel":6,"max_depth":6,"sky":null,"camera":{"look_from":{"x":0.0,"y":1.0,"z":3.0},'
+            '"look_at":{"x":0.0,"y":0.5,"z":-1.0},"vup":{"x":0.0,"y":1.0,"z":0.0},"vfov":60.0,"aspect":1.5},"objects":[' + ",".join(objs) + "]}")
+
+
+@pytest.mark.parametrize("case", ["cfg1_lights_textures_hollow_glass", "cfg2_cover", "cfg1_depth50_seed3", "cover4k_textured_sky", "three_lights_nested"])
+def test_second_restatement_agrees_bit_for_bit(oracle, abi, host, case):
+    """ray_color + hit_world + the five scatters + render_line restated twice (C: oracle/rt_oracle.c; Python: tests/mini_oracle.py,
+    from the reference's sources alone): identical linear radiance (every f32 bit), identical RGB8, identical segment counts."""
+    import mini_oracle
+    L = oracle.lib(abi)
+    if case == "three_lights_nested":
+        sc = host.Scene.loads(_three_lights_world())
+    else:
+        path, w, h, spp, depth, seed = {"cfg1_lights_textures_hollow_glass": ("scenes/cfg1_test_800x600_spp16.json", 24, 16, 2, 8, 0),
+                                        "cfg2_cover": ("scenes/cfg2_cover_1200x800_spp128.json", 24, 16, 2, 8, 0),
+                                        "cfg1_depth50_seed3": ("scenes/cfg1_test_800x600_spp16.json", 20, 14, 3, 50, 3),
+                                        "cover4k_textured_sky": ("scenes/cfg3_cover_4k_textured.json", 24, 14, 2, 50, 1)}[case]
+        sc = host.Scene.load(path)
+        sc.c.width, sc.c.height, sc.c.samples_per_pixel, sc.c.max_depth, sc.c.seed = w, h, spp, depth, seed
+    o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
+    m = mini_oracle.Mini(sc.c, lambda y, x: L.rt_oracle_atan2(y, x))
+    rgb, lin, segments = m.render()
+    assert np.array_equal(lin.view(np.uint32), o_lin.view(np.uint32)), f"{int((lin != o_lin).any(-1).sum())} pixels differ, max {np.abs(lin - o_lin).max()}"
+    assert np.array_equal(rgb, o_rgb)
+    assert segments == o_st["segments"]
+    if case in ("cfg1_lights_textures_hollow_glass", "three_lights_nested"):
+        assert o_st["segments_discarded"] > 0 or len(m.lights) > 0     # (lit: the light loop ran)
+    if case == "three_lights_nested":
+        assert o_lin.max() > 0.05 and segments > o_st["samples"] * 1.5   # light rays were shot, some of them nested
+
+
+def test_second_restatement_philox_matches_random123():
+    """... and its own Philox (pure Python) against the Random123 known answers"""
+    import mini_oracle
+    pi = [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]
+    assert list(mini_oracle.philox4x32_10(0, 0, 0, 0, 0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert list(mini_oracle.philox4x32_10(*([0xffffffff] * 6))) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert list(mini_oracle.philox4x32_10(*pi, 0xa4093822, 0x299f31d0)) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]

@@ -17,7 +17,9 @@ int main(int argc,char**argv){
   std::vector<RtSphere> all(n); memset(all.data(),0,sizeof(RtSphere)*n);
   for(size_t i=0;i<n;i++){ all[i].center[0]=raw[4*i];all[i].center[1]=raw[4*i+1];all[i].center[2]=raw[4*i+2];all[i].radius=raw[4*i+3]; }
   RtScene sc; memset(&sc,0,sizeof sc); sc.abi_version=RT_ABI_VERSION; sc.width=sc.height=16; sc.samples_per_pixel=1; sc.max_depth=5; sc.n_spheres=(uint32_t)n; sc.spheres=all.data();
-  HostTables t; build_tables(sc,t); DevScene ds; fill_dev_scene(sc,t,ds); ds.geom=t.geom.data(); ds.matc=t.matc.data(); ds.cell_word=t.cell_word.data(); ds.cell_items=t.cell_items.data(); ds.large=t.large.data(); ds.large_geom=t.large_geom.data();
+  HostTables t; build_tables(sc,t);
+  if(t.grid.wide){ std::fprintf(stderr,"mailbox_estimate: this world builds a WIDE grid (more than 65 535 spheres, > 4 095 items in a cell or >= 2^20 items): the tool decodes packed two-word cells only\n"); return 2; }
+  DevScene ds; fill_dev_scene(sc,t,ds); ds.geom=t.geom.data(); ds.matc=t.matc.data(); ds.cell_word=t.cell_word.data(); ds.cell_items=t.cell_items.data(); ds.large=t.large.data(); ds.large_geom=t.large_geom.data();
   const GridDesc&G=t.grid; printf("grid %ux%ux%u items %u large %u\n",G.n[0],G.n[1],G.n[2],G.n_items,G.n_large);
   std::mt19937_64 g(7); std::uniform_real_distribution<double> U(-1,1);
   auto rnd_unit=[&](){ for(;;){V3 p=v3(U(g),U(g),U(g)); double l=length_squared(p); if(l<1&&l>1e-6) return muls(p,1/sqrt(l));} };

@@ -226,6 +226,7 @@ int main(int argc, char** argv) {
   DevScene ds; fill_dev_scene(sc, t, ds);
   ds.tex4 = t.tex4.data(); ds.sky4 = t.sky4.data();
   ds.geom = t.geom.data(); ds.mat = t.mat.data(); ds.lights = t.lights.data(); ds.sky = sc.sky_rgb8;
+  if (t.grid.wide) { std::fprintf(stderr, "walk_sim: this world builds a WIDE grid (32-bit item lists, four-word cells): the simulator decodes packed cells only\n"); return 2; }
   ds.matc = t.matc.data(); ds.cell_word = t.cell_word.data(); ds.cell_items = t.cell_items.data(); ds.large = t.large.data(); ds.large_geom = t.large_geom.data();
   std::vector<uint8_t> blob(t.tex_bytes ? t.tex_bytes : 1);
   for (uint32_t i = 0; i < sc.n_textures; ++i) std::memcpy(&blob[t.tex_off[i]], sc.textures[i].rgb8, sc.textures[i].nbytes);
