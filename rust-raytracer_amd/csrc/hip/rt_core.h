@@ -1597,9 +1597,20 @@ RT_HD bool lane_may_sample_lights(const DevScene& sc, const LaneT& L) {
 // lane's current sample finished (its radiance is in L.val; the caller starts the next one), LANE_REPEAT when nothing was
 // consumed (pooled lit kernels: no light frame free — the same ray is traced again next iteration), else LANE_CONTINUE.
 enum { LANE_CONTINUE = 0, LANE_FINISHED = 1, LANE_REPEAT = 2 };
+// the census build of the lit kernels (-DRT_PROFILE -DRT_PROF_LIT, rt_kernel.hip): shader-clock cycles of lane_shade's parts
+struct ShadeProf { unsigned long long* t; unsigned long long* last; uint32_t* n_iter_sample; uint32_t* n_iter_return; };
+#if defined(RT_PROF_LIT) && defined(__HIP_DEVICE_COMPILE__)
+#define RT_SHADE_MARK(k) do { if (sp) { const unsigned long long now_ = __builtin_readcyclecounter(); sp->t[k] += now_ - *sp->last; *sp->last = now_; } } while (0)
+#define RT_SHADE_COUNT(act_) do { if (sp) { const unsigned long long sm_ = __builtin_amdgcn_ballot_w64((act_) == ACT_SAMPLE), rm_ = __builtin_amdgcn_ballot_w64((act_) == ACT_RETURN); \
+    if (sm_) (*sp->n_iter_sample)++; if (rm_) (*sp->n_iter_return)++; sp->t[5] += (unsigned long long)__builtin_popcountll(sm_) | ((unsigned long long)__builtin_popcountll(rm_) << 32); } } while (0)
+#else
+#define RT_SHADE_MARK(k) do { } while (0)
+#define RT_SHADE_COUNT(act_) do { } while (0)
+#endif
 template <class LaneT, class Tables>
 RT_HD int lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, double t, const V3* rnd_pre = nullptr,
-                      const double* glass_u_pre = nullptr, const double* light_u_pre = nullptr) {
+                      const double* glass_u_pre = nullptr, const double* light_u_pre = nullptr, ShadeProf* sp = nullptr) {
+  (void)sp;
   constexpr bool HL = LaneT::kLights;
   const float zero3[3] = {0.0f, 0.0f, 0.0f};
   if constexpr (!HL) {
@@ -1654,6 +1665,33 @@ RT_HD int lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, do
         } else act = ACT_CONTINUE;
       }
     }
+#if defined(RT_PROF_LIT) && defined(__HIP_DEVICE_COMPILE__)
+    // (census build: the continuations one after the other, each closed by a wave-level mark; no lane leaves early, so that the
+    //  lane whose clock is reported — lane 0 — passes every mark.  The product's form is below.)
+    RT_SHADE_MARK(1);
+    RT_SHADE_COUNT(act);
+    int result = LANE_CONTINUE;
+    if (act == ACT_SAMPLE) {
+      if (!lane_light_begin(sc, L, light_ray)) result = LANE_REPEAT;
+      else {
+        if (!light_ray) light_frame(L.ls).saved_d = out_dir;
+        LightFrame& f = light_frame(L.ls).cur;
+        f.P = point; f.a[0] = att[0]; f.a[1] = att[1]; f.a[2] = att[2];
+        f.acc[0] = f.acc[1] = f.acc[2] = 0.0f; f.j = 0; f.node = L.node;
+        lane_aim_light(sc, tb, L);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    RT_SHADE_MARK(2);
+    if (act == ACT_RETURN) result = lane_light_return(sc, tb, L, col) ? LANE_FINISHED : LANE_CONTINUE;
+    __builtin_amdgcn_wave_barrier();
+    RT_SHADE_MARK(3);
+    if (act == ACT_FINISH) { lane_finish_sample(sc, L, col); result = LANE_FINISHED; }
+    else if (act == ACT_CONTINUE) result = lane_continue_main(sc, L, point, out_dir, zero3, att) ? LANE_FINISHED : LANE_CONTINUE;
+    __builtin_amdgcn_wave_barrier();
+    RT_SHADE_MARK(4);
+    return result;
+#else
     if (act == ACT_SAMPLE) {
       // (a light ray's hit suspends the activation whose light ray it is; a camera-path hit that finds a pool of the device
       //  form exhausted has changed nothing yet: the same segment is traced again; the caller counts the segment once — its
@@ -1669,6 +1707,7 @@ RT_HD int lane_shade(const DevScene& sc, const Tables& tb, LaneT& L, int idx, do
     if (act == ACT_RETURN) return lane_light_return(sc, tb, L, col) ? LANE_FINISHED : LANE_CONTINUE;
     if (act == ACT_FINISH) { lane_finish_sample(sc, L, col); return LANE_FINISHED; }
     return lane_continue_main(sc, L, point, out_dir, zero3, att) ? LANE_FINISHED : LANE_CONTINUE;
+#endif
   }
 }
 

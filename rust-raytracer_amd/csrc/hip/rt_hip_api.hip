@@ -102,6 +102,7 @@ struct RtHipScene {
     }
   } order_key;              // n_tiles == 0: none yet
   bool order_ready = false; // d_tile_order holds an order for order_key
+  bool depth_fresh = false; // d_tile_depth holds depths of THIS view (measured by its last frame) that d_tile_order does not reflect yet
   int order_age = 0;        // frames since the order was last invalidated (geometry / camera / option change)
   int tile_affinity = 1;    // "tile_affinity" option: runs of tiles belong to one XCD's queue (framebuffer lines complete in one L2)
   int order_mode = 2;       // "tile_order" option: 0 top row first, 1 bottom row first, 2 deepest tiles of the previous frame first
@@ -337,8 +338,8 @@ extern "C" int rt_hip_set_option(RtHipScene* s, const char* key, int64_t value) 
   if (!std::strcmp(key, "variant")) { if (value < 0 || value > max_variant) return fail(RT_ERR_INVALID, "variant must be 0 (grid walk) or 1 (brute force)"); s->variant = (int)value; return RT_OK; }
   if (!std::strcmp(key, "tile_log2")) { if (value < -1 || value > 3) return fail(RT_ERR_INVALID, "tile_log2 must be -1..3"); s->tile_log2 = (int)value; return RT_OK; }
   if (!std::strcmp(key, "tile_shape")) { if (value < 0 || value > 3) return fail(RT_ERR_INVALID, "tile_shape must be 0 (square), 1 (scanline runs), 2 (4:1) or 3 (16:1)"); s->tile_shape = (int)value; return RT_OK; }
-  if (!std::strcmp(key, "tile_affinity")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_affinity must be 0 (off), 1 (large frames) or 2 (any frame of 8+ runs: tests)"); s->tile_affinity = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
-  if (!std::strcmp(key, "tile_order")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_order must be 0, 1 or 2"); s->order_mode = (int)value; s->order_ready = false; s->order_age = 0; return RT_OK; }
+  if (!std::strcmp(key, "tile_affinity")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_affinity must be 0 (off), 1 (large frames) or 2 (any frame of 8+ runs: tests)"); s->tile_affinity = (int)value; s->order_ready = false; s->depth_fresh = false; s->order_age = 0; return RT_OK; }
+  if (!std::strcmp(key, "tile_order")) { if (value < 0 || value > 2) return fail(RT_ERR_INVALID, "tile_order must be 0, 1 or 2"); s->order_mode = (int)value; s->order_ready = false; s->depth_fresh = false; s->order_age = 0; return RT_OK; }
   if (!std::strcmp(key, "light_pool")) { if (value < 0 || value > 1024 || (value != 0 && value < 32)) return fail(RT_ERR_INVALID, "light_pool must be 0 (automatic) or 32..1024"); s->light_pool_cap = (int)value; return RT_OK; }
   if (!std::strcmp(key, "light_base_pool")) { if (value < 0 || value > 1024 || (value != 0 && value < 32)) return fail(RT_ERR_INVALID, "light_base_pool must be 0 (automatic) or 32..1024"); s->light_base_cap = (int)value; return RT_OK; }
   if (!std::strcmp(key, "light_nest_pool")) { if (value < 0 || value > 1) return fail(RT_ERR_INVALID, "light_nest_pool must be 0 or 1"); s->light_nest_pool = (int)value; return RT_OK; }
@@ -651,7 +652,16 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
       RT_HIP_TRY(hipMalloc((void**)&s->d_tile_order, (size_t)ka.n_tiles * 4));
       s->order_cap = ka.n_tiles;
     }
-    if (!(key == s->order_key)) { s->order_key = key; s->order_ready = false; s->order_age = 0; }
+    if (!(key == s->order_key)) { s->order_key = key; s->order_ready = false; s->depth_fresh = false; s->order_age = 0; }
+    // The order of THIS frame from the depths the previous frame of the SAME view measured (sorted here, stream-ordered ahead of
+    // the launch — until round 5 behind the frame that measured them, which an animation paid every frame for an order it never
+    // used).  Which tiles breed deep paths is a property of scene and camera: rebuilt after each of a view's first two frames,
+    // then kept; rt_hip_set_camera with a different camera starts over WITHOUT an order (below).
+    if (s->depth_fresh) {
+      hipLaunchKernelGGL(rtk::rt_order_tiles, dim3(1), dim3(1024), 0, stream, (const uint32_t*)s->d_tile_depth, s->d_tile_order, ka.n_tiles, ka.aff_group_log2);
+      RT_HIP_TRY(hipGetLastError());
+      s->order_ready = true; s->depth_fresh = false;
+    }
     if (s->order_mode == 2 && s->order_age < 2) ka.tile_depth = s->d_tile_depth;  // (measured only while the order is still being built)
     if (s->order_ready) ka.tile_order = s->d_tile_order;
   }
@@ -664,11 +674,6 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
     return RT_OK;
   };
   if ((rc = dispatch_grid(s, has_lights, lds_tables, ka.sc.grid.wide != 0u, true, nullptr, lds_bytes, 0, stream)) != RT_OK) return rc;  // (host-side set-up: before the start event)
-  auto sort_tiles = [&]() -> int {
-    hipLaunchKernelGGL(rtk::rt_order_tiles, dim3(1), dim3(1024), 0, stream, (const uint32_t*)s->d_tile_depth, s->d_tile_order, ka.n_tiles, ka.aff_group_log2);
-    RT_HIP_TRY(hipGetLastError());
-    return RT_OK;
-  };
   RT_HIP_TRY(hipEventRecord(sl.ev_start, stream));
   // A frame without a measured order (the first of a scene, a one-shot render) leaves the queue bottom row first and ends on
   // whatever deep path started last: 13.3 instead of 12.8 ms on the headline frame.  Two ways to SEED an order — a depth guess
@@ -677,14 +682,7 @@ extern "C" int rt_hip_render(RtHipScene* s, const RtRowTiles* tiles, void* d_rgb
   // knows is WHICH tiles hold one of the rare 50-segment paths, which a replay of the same seeds predicts and nothing cheaper does.
   if ((rc = launch(ka, n_items)) != RT_OK) return rc;
   RT_HIP_TRY(hipEventRecord(sl.ev_stop, stream));
-  // The next frame's order from this frame's depths (stream-ordered: ready before the next launch reads it).  Which tiles
-  // breed deep paths is a property of scene and camera, so the order is rebuilt after the first two frames of a view
-  // only — later frames of the same view reuse it and pay nothing; rt_hip_set_camera starts over.
-  if (ka.tile_depth) {
-    s->order_age++;
-    if ((rc = sort_tiles()) != RT_OK) return rc;
-    s->order_ready = true;
-  }
+  if (ka.tile_depth) { s->order_age++; s->depth_fresh = true; }  // (the NEXT frame of this view sorts them into its order)
   return finish_launch(true);
 }
 
@@ -781,13 +779,25 @@ extern "C" int64_t rt_hip_scene_query(const RtHipScene* s, const char* key) {
 extern "C" int rt_hip_set_camera(RtHipScene* s, const double origin[3], const double lower_left[3], const double horizontal[3],
                                  const double vertical[3]) {
   if (!s || !origin || !lower_left || !horizontal || !vertical) return fail(RT_ERR_INVALID, "null argument");
+  bool same = true;
+  for (int i = 0; i < 3; ++i)
+    same = same && s->host.cam_origin[i] == origin[i] && s->host.cam_lower_left[i] == lower_left[i] && s->host.cam_horizontal[i] == horizontal[i] &&
+           s->host.cam_vertical[i] == vertical[i];
+  if (same) return RT_OK;  // (the same view: its order stays)
   for (int i = 0; i < 3; ++i) {
     s->host.cam_origin[i] = s->dev.cam_origin[i] = origin[i];
     s->host.cam_lower_left[i] = s->dev.cam_ll[i] = lower_left[i];
     s->host.cam_horizontal[i] = s->dev.cam_h[i] = horizontal[i];
     s->host.cam_vertical[i] = s->dev.cam_v[i] = vertical[i];
   }
-  s->order_age = 0;  // the previous view's order stays in use (the views of an animation are close); rebuilt from this frame on
+  // A new view starts WITHOUT an order (bottom row first) and measures its own.  Until round 5 the previous view's order stayed
+  // in use ("the views of an animation are close") — measured in round 6 on the headline scene turning 3 degrees per frame:
+  // the stale order costs 3 - 10 % against the view's own order and is WORSE than no order (+3 - 4 %): the tiles that hold a
+  // view's rare 50-segment paths are 4x4 pixels, and a 3 degree turn moves the spheres by tens of pixels
+  // (bench.py `animation.same_views`, profiles/r06_run*_bench.json).  RT_STALE_ORDER=1: the round-5 behaviour, for the A/B.
+  static const bool keep_stale = std::getenv("RT_STALE_ORDER") != nullptr;
+  if (!keep_stale) { s->order_ready = false; s->depth_fresh = false; }   // (stale arm: the previous view's depths are sorted into this frame's order)
+  s->order_age = 0;
   return RT_OK;
 }
 
@@ -831,7 +841,7 @@ int rt_hip_scene_warm(RtHipScene* s, hipStream_t stream) {
   if (rc == RT_OK) rtp::add("rank0.warm_up_kernel_ms_by_events", wst.kernel_ms);
   s->order_mode = saved_order;
   s->n_launches = 0; s->in_flight = false; s->last_stream = nullptr; s->last_waves = 0;
-  s->order_key = RtHipScene::OrderKey(); s->order_ready = false; s->order_age = 0;
+  s->order_key = RtHipScene::OrderKey(); s->order_ready = false; s->depth_fresh = false; s->order_age = 0;
   for (auto& sl : s->slot) { sl.rows = 0; sl.samples = 0; sl.waves = 0; sl.launched = false; }
   (void)hipFree(row);
   return rc;

@@ -75,7 +75,16 @@ __host__ __device__ inline uint32_t tile_xcd(uint32_t tile, uint32_t gl) { retur
 
 #ifdef RT_PROFILE
 #define RT_PROF_DECL unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_last = __builtin_readcyclecounter(); const unsigned long long prof_begin = prof_last; const unsigned long long prof_wall0 = wall_clock64(); unsigned long long prof_wall_qdone = 0; uint32_t prof_tail_iters = 0, prof_tail_lanes = 0; bool prof_in_tail = false; unsigned long long prof_tail_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define RT_PROF(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof_t[k] += now_ - prof_last; if (prof_in_tail) prof_tail_t[k] += now_ - prof_last; prof_last = now_; } while (0)
+#define RT_PROF_RAW(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof_t[k] += now_ - prof_last; if (prof_in_tail) prof_tail_t[k] += now_ - prof_last; prof_last = now_; } while (0)
+#ifdef RT_PROF_LIT
+// the lit kernels' CENSUS build (round 6): the six section slots are re-used — 0: everything outside lane_shade,
+// 1: lane_shade up to its decision (surface, scatter, light trigger), 2: the ACT_SAMPLE continuation (pool takes, frame record,
+// aim), 3: the ACT_RETURN continuation (accumulate, next light / compose + release + step), 4: the ACT_FINISH / ACT_CONTINUE tail,
+// 5: lanes that took ACT_SAMPLE | lanes that took ACT_RETURN << 32; wave_iters[1] / [2]: wave iterations in which SOME lane took them
+#define RT_PROF(k) RT_PROF_RAW(0)
+#else
+#define RT_PROF(k) RT_PROF_RAW(k)
+#endif
 #define RT_PROF_COUNT(c) do { (c)++; } while (0)
 #else
 #define RT_PROF_COUNT(c) do { } while (0)
@@ -767,7 +776,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         const bool moving = it == end;
         {  // (no wave vote around the block: the lane mask of `if (moving)` already skips it when empty)
 #ifdef RT_PROFILE
+#ifndef RT_PROF_LIT
           if (wave_any(moving)) cnt_w_step++;
+#endif
 #endif
           if (moving) {
             float tc = (float)(closest - t0);
@@ -824,7 +835,9 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
         const bool testing = it < end;
         {  // (b) one exact Sphere::hit per lane standing in a cell with spheres left
 #ifdef RT_PROFILE
+#ifndef RT_PROF_LIT
           if (wave_any(testing)) cnt_w_test++;
+#endif
 #endif
           if (testing) {
             uint32_t idx;
@@ -909,7 +922,12 @@ __global__ __launch_bounds__(BLOCK) RT_WAVES_ATTR void rt_megakernel(const KArgs
     // (d) shade the hits
     int status = LANE_CONTINUE;
     if (has_ray) {
+#ifdef RT_PROF_LIT
+      rtc::ShadeProf shade_prof{prof_t, &prof_last, &cnt_w_step, &cnt_w_test};
+      status = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u, HL ? &light_u : nullptr, &shade_prof);
+#else
       status = lane_shade(fresh_args().sc, tb, L, best, closest, &rnd, &glass_u, HL ? &light_u : nullptr);
+#endif
       if constexpr (HL) { if (status == LANE_REPEAT) L.n_tex_oob = 0u; }  // (the hit is shaded again next iteration: its out-of-range texel counts THEN, once — RtStats.tex_oob equals the oracle's)
       flush_oob();
     }
