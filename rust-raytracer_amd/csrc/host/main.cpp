@@ -12,7 +12,7 @@
 // [--orbit DEG]` renders N frames to `<output_prefix>_%03d.png` — the file naming main.rs:17
 // keeps commented out and README.md:43-57 / "Make animation" feed to ffmpeg — turning the camera
 // around look_at by DEG per frame (default 360/N).  The scene is uploaded once and stays in HBM;
-// the PNG of frame i is encoded on writer threads (RT_ANIM_WRITERS, default 2) while the GPU renders frame i+1.  With RT_GPUS=G every frame is sharded
+// the PNG of frame i is encoded on writer threads (RT_ANIM_WRITERS, default 4) while the GPU renders frame i+1.  With RT_GPUS=G every frame is sharded
 // over the G devices and frames are pipelined two deep (RT_ANIM=sharded, default), or the frames are distributed over the
 // devices, each rendering whole frames (RT_ANIM=frames); RT_STATS=1 prints frames per second and the per-frame kernel / frame / PNG
 // times to stderr (one JSON line).
@@ -75,7 +75,7 @@ struct AnimStats {
   }
 };
 
-// PNG writers of an animation: W threads (RT_ANIM_WRITERS, default 2) take finished frames off a queue; a frame's host buffer
+// PNG writers of an animation: W threads (RT_ANIM_WRITERS, default 4) take finished frames off a queue; a frame's host buffer
 // goes back to the free list when its file is on disk.  A frame's PNG is itself deflated in parallel bands (scene.cpp), so one
 // writer keeps up with the headline frame; the second one is for frames whose kernel is shorter than their PNG (the
 // reference's 1 ms test scene).
@@ -127,10 +127,15 @@ struct PngWriters {
     th.clear();
   }
 };
+// Several frames' PNGs are written at once, each by a FEW band threads: four writers x 8 threads keep up with the reference's 0.9 ms
+// test-scene frames (one writer x 32 threads: 1.2 ms per PNG = slower than the kernel; three writers x 32 threads each: slower
+// still, the threads of three PNGs at once — profiles/r06_run1_anim_writers.log).  RT_ANIM_WRITERS / RT_PNG_THREADS override.
 unsigned anim_writers() {
   const char* e = std::getenv("RT_ANIM_WRITERS");
-  const long v = e ? std::strtol(e, nullptr, 10) : 2;
-  return v < 1 ? 1u : (v > 16 ? 16u : (unsigned)v);
+  const long v = e ? std::strtol(e, nullptr, 10) : 4;
+  const unsigned w = v < 1 ? 1u : (v > 16 ? 16u : (unsigned)v);
+  if (w > 1) setenv("RT_PNG_THREADS", "8", 0);
+  return w;
 }
 
 // Every frame SHARDED over the RT_GPUS devices (rt_hip_group_*), frames pipelined two deep: frame f+1 is submitted before
