@@ -56,6 +56,7 @@ double ms_between(std::chrono::steady_clock::time_point a, std::chrono::steady_c
 struct AnimStats {
   std::mutex mu;
   std::vector<double> kernel_ms, frame_ms, png_ms;
+  double host_us[4] = {0, 0, 0, 0};   // the submitting thread's time, summed over the frames: waiting for a free buffer, camera + submit, collect, stdout + hand-over
   explicit AnimStats(int n) : kernel_ms(n, 0.0), frame_ms(n, 0.0), png_ms(n, 0.0) {}
   void report(const char* mode, int frames, unsigned gpus, unsigned writers, double wall_s, double setup_ms) {
     if (!std::getenv("RT_STATS")) return;
@@ -70,6 +71,9 @@ struct AnimStats {
       s += "]";
     };
     arr("kernel_ms", kernel_ms); arr("frame_ms", frame_ms); arr("png_ms", png_ms);
+    std::snprintf(buf, sizeof buf, ",\"host_us_per_frame\":{\"wait_for_buffer\":%.1f,\"camera_and_submit\":%.1f,\"collect\":%.1f,\"stdout_and_hand_over\":%.1f}",
+                  host_us[0] / frames, host_us[1] / frames, host_us[2] / frames, host_us[3] / frames);
+    s += buf;
     s += "}\n";
     std::fputs(s.c_str(), stderr);
   }
@@ -160,22 +164,30 @@ int animate_sharded(RtSceneFile* sf, const char* prefix, int frames, double orbi
   std::vector<uint8_t*> in_flight;  // oldest first
   auto finish = [&](int f) -> bool {  // collect frame f, print its two lines, hand its pixels to the PNG writers
     RtStats st{};
+    const auto t0 = std::chrono::steady_clock::now();
     const int rc = rt_hip_group_collect(hs, &st);
+    const auto t1 = std::chrono::steady_clock::now();
+    stats.host_us[2] += ms_between(t0, t1) * 1e3;
     if (rc != RT_OK) { std::fprintf(stderr, "render failed: %s: %s\n", rt_strerror(rc), rt_hip_last_error()); status = 101; return false; }
     std::printf("\nRendering %s\nFrame time: %lldms\n", frame_name(prefix, f).c_str(), (long long)st.frame_ms);
     stats.kernel_ms[f] = st.kernel_ms; stats.frame_ms[f] = st.frame_ms;
     uint8_t* px = in_flight.front();
     in_flight.erase(in_flight.begin());
     writers.push(f, px);
+    stats.host_us[3] += ms_between(t1, std::chrono::steady_clock::now()) * 1e3;
     return !writers.failed();
   };
   int submitted = 0, collected = 0;
   for (int f = 0; f < frames && status == 0 && !writers.failed(); ++f) {
     double out[13];
+    const auto t0 = std::chrono::steady_clock::now();
+    uint8_t* buf = writers.take_buffer();
+    const auto t1 = std::chrono::steady_clock::now();
     orbit_camera(cam, orbit_deg, f, out);
     rt_hip_group_set_camera(hs, out, out + 3, out + 6, out + 9);
-    uint8_t* buf = writers.take_buffer();
     rc = rt_hip_group_submit(hs, buf);
+    stats.host_us[0] += ms_between(t0, t1) * 1e3;
+    stats.host_us[1] += ms_between(t1, std::chrono::steady_clock::now()) * 1e3;
     if (rc != RT_OK) { std::fprintf(stderr, "render failed: %s: %s\n", rt_strerror(rc), rt_hip_last_error()); status = 101; break; }
     in_flight.push_back(buf);
     submitted++;

@@ -31,7 +31,7 @@ if [[ " $* " == *" pmc "* ]]; then
 fi
 if [[ " $* " == *" pmcs "* ]]; then
   # counters of the configs where the memory system takes part: textures (cfg3), tables in L2 (cfg5), the lit test scene (cfg1)
-  timeout 1500 bash tools/pmc_scene.sh "${RT_TAG:-rXX}" cfg1=scenes/cfg1_test_800x600_spp16.json cfg3=scenes/cfg3_cover_4k_textured.json cfg5=procedural:50:2048 litcover=build/ab/lit_cover_spp32.json > $OUT/pmcs.log 2>&1; stamp pmcs $?
+  timeout 2400 bash tools/pmc_scene.sh "${RT_TAG:-rXX}" cfg1=scenes/cfg1_test_800x600_spp16.json cfg3=scenes/cfg3_cover_4k_textured.json cfg4=scenes/cfg4_cover_4k_textured_spp512.json cfg5=procedural:50:2048 litcover=build/ab/lit_cover_spp32.json > $OUT/pmcs.log 2>&1; stamp pmcs $?
   grep -E "^cfg[0-9] (\{|pass)" $OUT/pmcs.log | cut -c1-400
 fi
 if [[ " $* " == *" group "* ]]; then
