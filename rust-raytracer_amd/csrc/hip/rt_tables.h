@@ -272,7 +272,9 @@ inline void build_grid(const RtScene& sc, HostTables& t, const GridParams& gp) {
 }
 
 // returns "" or a description of why the scene is invalid (RT_ERR_INVALID)
-inline std::string build_tables(const RtScene& sc, HostTables& t) {
+// want_cull: also the round-1 cull-pair table (HostTables::cull) — no kernel reads it any more; tests/hostsim's audit mode and
+// tools/analysis/walk_sim.cpp do (the product's rt_hip_scene_create leaves it out since round 6).
+inline std::string build_tables(const RtScene& sc, HostTables& t, bool want_cull = false) {
   if (sc.abi_version != RT_ABI_VERSION) return "abi_version mismatch";
   if (sc.width == 0 || sc.height == 0) return "empty image";
   if (sc.n_spheres && !sc.spheres) return "null sphere table";
@@ -296,7 +298,7 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
   const uint32_t padded = (n_pairs + CULL_CHUNK - 1) / CULL_CHUNK * CULL_CHUNK + CULL_CHUNK;
   CullPair never;
   for (int k = 0; k < 2; ++k) { never.cx[k] = never.cy[k] = never.cz[k] = 0.0f; never.R[k] = -INFINITY; }
-  t.cull.assign(padded, never);
+  if (want_cull) t.cull.assign(padded, never); else t.cull.clear();
   t.n_pairs = n_pairs;
   t.lights.clear();
   t.simple_colour = true;
@@ -338,10 +340,12 @@ inline std::string build_tables(const RtScene& sc, HostTables& t) {
     if (s.kind == RT_MAT_LAMBERTIAN || s.kind == RT_MAT_METAL)
       for (int c = 0; c < 3; ++c)
         if (!(s.albedo[c] >= 0.0f && s.albedo[c] <= 1.0f)) t.simple_colour = false;
-    CullPair& cp = t.cull[i / 2];
-    build_cull_entry(s, &cp.cx[i & 1], &cp.cy[i & 1], &cp.cz[i & 1], &cp.R[i & 1]);
+    if (want_cull) {
+      CullPair& cp = t.cull[i / 2];
+      build_cull_entry(s, &cp.cx[i & 1], &cp.cy[i & 1], &cp.cz[i & 1], &cp.R[i & 1]);
+    }
   }
-  if (n & 1) {  // odd count: the second half of the last real pair can never pass either
+  if (want_cull && (n & 1)) {  // odd count: the second half of the last real pair can never pass either
     CullPair& cp = t.cull[n / 2];
     cp.cx[1] = cp.cx[0]; cp.cy[1] = cp.cy[0]; cp.cz[1] = cp.cz[0]; cp.R[1] = -INFINITY;
   }

@@ -137,7 +137,7 @@ void render_rows(const RtScene& sc, const HostTables& t, const DevScene& ds, con
 extern "C" int hostsim_render(const RtScene* scene, const RtRowTiles* tiles, uint8_t* rgb8, float* linear,
                               RtStats* stats, int use_cull) {
   HostTables t;
-  if (!scene || !build_tables(*scene, t).empty()) return RT_ERR_INVALID;
+  if (!scene || !build_tables(*scene, t, true).empty()) return RT_ERR_INVALID;
   build_texels(*scene, t);  // (the 4-byte-texel path the device takes; the RGB8 blob serves the records outside its range)
   DevScene ds;
   fill_dev_scene(*scene, t, ds);
@@ -181,7 +181,7 @@ extern "C" int hostsim_hit_prefix(const double o[3], const double d[3], const Rt
 // grid layout of a scene (for tests): out = n[3], n_large, n_cells, n_items
 extern "C" int hostsim_grid_info(const RtScene* scene, uint32_t out[6]) {
   HostTables t;
-  if (!scene || !build_tables(*scene, t).empty()) return RT_ERR_INVALID;
+  if (!scene || !build_tables(*scene, t, true).empty()) return RT_ERR_INVALID;
   out[0] = t.grid.n[0]; out[1] = t.grid.n[1]; out[2] = t.grid.n[2];
   out[3] = t.grid.n_large; out[4] = t.grid.n_cells; out[5] = t.grid.n_items;
   return RT_OK;
@@ -190,14 +190,14 @@ extern "C" int hostsim_grid_info(const RtScene* scene, uint32_t out[6]) {
 // 1: the scene's grid is in the wide table format (GridDesc.wide: 32-bit item lists), 0: packed, < 0: error
 extern "C" int hostsim_grid_wide(const RtScene* scene) {
   HostTables t;
-  if (!scene || !build_tables(*scene, t).empty()) return RT_ERR_INVALID;
+  if (!scene || !build_tables(*scene, t, true).empty()) return RT_ERR_INVALID;
   return (int)t.grid.wide;
 }
 
 // how the walk of one ray begins (rt_core.h grid_begin): 0 = misses the grid, 1 = walks, 2 = numerically unsafe -> full scan; < 0: error / no grid
 extern "C" int hostsim_grid_mode(const RtScene* scene, const double o[3], const double d[3]) {
   HostTables t;
-  if (!scene || !build_tables(*scene, t).empty()) return RT_ERR_INVALID;
+  if (!scene || !build_tables(*scene, t, true).empty()) return RT_ERR_INVALID;
   if (t.grid.n[0] == 0u) return -100;
   GridWalk w;
   return grid_begin(t.grid, v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]), w);
@@ -207,7 +207,7 @@ extern "C" int hostsim_grid_mode(const RtScene* scene, const double o[3], const 
 // out = {best_grid, best_brute}, t_out = {t_grid, t_brute}
 extern "C" int hostsim_hit_world(const RtScene* scene, const double o[3], const double d[3], int out[2], double t_out[2]) {
   HostTables t;
-  if (!scene || !build_tables(*scene, t).empty()) return RT_ERR_INVALID;
+  if (!scene || !build_tables(*scene, t, true).empty()) return RT_ERR_INVALID;
   DevScene ds;
   fill_dev_scene(*scene, t, ds);
   ds.geom = t.geom.data(); ds.matc = t.matc.data(); ds.cell_word = t.cell_word.data(); ds.cell_items = t.grid.wide ? reinterpret_cast<const uint16_t*>(t.cell_items32.data()) : t.cell_items.data();

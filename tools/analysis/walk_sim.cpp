@@ -220,7 +220,7 @@ int main(int argc, char** argv) {
   const RtScene& sc = *scp;
   HostTables t;
   if (cps > 0.0) { char b[64]; snprintf(b, sizeof b, "%g", cps); setenv("RT_GRID_CELLS_PER_SPHERE", b, 1); }
-  const std::string why = build_tables(sc, t);
+  const std::string why = build_tables(sc, t, true);
   if (!why.empty()) { std::fprintf(stderr, "%s\n", why.c_str()); return 1; }
   build_texels(sc, t);
   DevScene ds; fill_dev_scene(sc, t, ds);
