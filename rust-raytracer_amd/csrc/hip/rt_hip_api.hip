@@ -70,6 +70,8 @@ constexpr uint32_t RT_TIMELINE_WAVES = 8192;  // profile builds: {start, end} wa
 
 struct RtHipScene {
   int device = 0;
+  bool owns_tables = true;  // false: a VIEW of another scene (rt_hip_scene_clone_view): it shares that scene's tables, textures and host copies
+                            // and owns only what a launch writes — counters, stats slots, queue order, light overflow, framebuffer
   RtScene host{};          // scalar fields only (pointers are not kept)
   rtc::DevScene dev{};     // device pointers filled in
   bool has_lights = false, simple_colour = false;
@@ -201,9 +203,11 @@ extern "C" int rt_hip_device_warm(int device) {
 extern "C" void rt_hip_scene_destroy(RtHipScene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  for (void* p : {s->d_geom, s->d_mat, s->d_lights, s->d_tex, s->d_sky, s->d_tex4, s->d_sky4, (void*)s->d_counters, s->d_matc,
-                  s->d_cell_word, s->d_cell_items, s->d_large, s->d_all, s->d_large_geom, s->d_frame, (void*)s->d_tile_depth,
-                  (void*)s->d_tile_order, s->d_light_overflow})
+  if (s->owns_tables)
+    for (void* p : {s->d_geom, s->d_mat, s->d_lights, s->d_tex, s->d_sky, s->d_tex4, s->d_sky4, s->d_matc, s->d_cell_word, s->d_cell_items, s->d_large,
+                    s->d_all, s->d_large_geom})
+      if (p) (void)hipFree(p);
+  for (void* p : {(void*)s->d_counters, s->d_frame, (void*)s->d_tile_depth, (void*)s->d_tile_order, s->d_light_overflow})
     if (p) (void)hipFree(p);
   for (auto& sl : s->slot) {
     for (hipEvent_t e : {sl.ev_start, sl.ev_stop, sl.ev_copied}) if (e) (void)hipEventDestroy(e);
@@ -221,6 +225,51 @@ int upload(void** dst, const V& v) {
   return RT_OK;
 }
 }  // namespace
+
+namespace {
+// what a LAUNCH of a scene writes: the counter block with the tile-queue cursors, the two stats slots (events + pinned words)
+int alloc_launch_state(RtHipScene* s) {
+  if (hipMalloc((void**)&s->d_counters, (32 + 4 * RT_TIMELINE_WAVES) * sizeof(unsigned long long)) != hipSuccess)
+    return fail(RT_ERR_HIP, "hipMalloc(counters) failed");
+  for (auto& sl : s->slot) {
+    if (hipEventCreate(&sl.ev_start) != hipSuccess || hipEventCreate(&sl.ev_stop) != hipSuccess ||
+        hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void**)&sl.h_counters, RT_SLOT_COUNTERS * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess)
+      return fail(RT_ERR_HIP, "hipEventCreate/hipHostMalloc failed");
+    std::memset(sl.h_counters, 0, RT_SLOT_COUNTERS * sizeof(unsigned long long));
+  }
+  if (hipMemset(s->d_counters, 0, (32 + 4 * RT_TIMELINE_WAVES) * sizeof(unsigned long long)) != hipSuccess)
+    return fail(RT_ERR_HIP, "hipMemset failed");
+  return RT_OK;
+}
+}  // namespace
+
+// A second VIEW of a resident scene (internal; the group's overlapped frames): the same tables and textures in HBM, its own
+// launch state — so that a launch of the view and a launch of the scene may be in flight on two streams AT ONCE (a scene itself
+// is not re-entrant: one tile-queue cursor, one counter block).  The view must be destroyed before the scene it was cloned from.
+int rt_hip_scene_clone_view(const RtHipScene* src, RtHipScene** out) {
+  if (!src || !out) return fail(RT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  RT_HIP_TRY(hipSetDevice(src->device));
+  RtHipScene* s = new RtHipScene;
+  s->device = src->device; s->owns_tables = false;
+  s->host = src->host; s->dev = src->dev;
+  s->has_lights = src->has_lights; s->simple_colour = src->simple_colour;
+  s->d_geom = src->d_geom; s->d_mat = src->d_mat; s->d_lights = src->d_lights; s->d_tex = src->d_tex; s->d_sky = src->d_sky;
+  s->d_tex4 = src->d_tex4; s->d_sky4 = src->d_sky4; s->texel_bytes = src->texel_bytes; s->d_matc = src->d_matc;
+  s->d_cell_word = src->d_cell_word; s->d_cell_items = src->d_cell_items; s->d_large = src->d_large; s->d_all = src->d_all;
+  s->d_large_geom = src->d_large_geom; s->grid = src->grid; s->num_cus = src->num_cus; s->lds_cap = src->lds_cap;
+  s->tile_affinity = src->tile_affinity; s->order_mode = src->order_mode; s->force_lit = src->force_lit; s->light_pool_cap = src->light_pool_cap;
+  s->light_base_cap = src->light_base_cap; s->light_nest_pool = src->light_nest_pool; s->chunk_spp = src->chunk_spp; s->tile_batch = src->tile_batch;
+  s->tile_log2 = src->tile_log2; s->tile_shape = src->tile_shape; s->variant = src->variant;
+  s->dev.light_overflow = nullptr;   // (its own: two launches at once park their lanes' records apart)
+  int rc = alloc_launch_state(s);
+  if (rc == RT_OK) rc = warm_up(s);  // (the launch configuration + the lit kernels' overflow slots, outside any frame)
+  if (rc == RT_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(RT_ERR_HIP, "hipDeviceSynchronize failed");
+  if (rc != RT_OK) { rt_hip_scene_destroy(s); return rc; }
+  *out = s;
+  return RT_OK;
+}
 
 extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene** out) {
   if (!scene || !out) return fail(RT_ERR_INVALID, "null argument");
@@ -294,17 +343,7 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   }
   if (!std::getenv("RT_FREE_HOST_TEXELS")) { s->keep_tex4.swap(t.tex4); s->keep_sky4.swap(t.sky4); }  // (the variable: the round-5 behaviour, for the A/B)
   pc.mark("scene.upload_texels");
-  if (hipMalloc((void**)&s->d_counters, (32 + 4 * RT_TIMELINE_WAVES) * sizeof(unsigned long long)) != hipSuccess)
-    return bail(fail(RT_ERR_HIP, "hipMalloc(counters) failed"));
-  for (auto& sl : s->slot) {
-    if (hipEventCreate(&sl.ev_start) != hipSuccess || hipEventCreate(&sl.ev_stop) != hipSuccess ||
-        hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc((void**)&sl.h_counters, RT_SLOT_COUNTERS * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess)
-      return bail(fail(RT_ERR_HIP, "hipEventCreate/hipHostMalloc failed"));
-    std::memset(sl.h_counters, 0, RT_SLOT_COUNTERS * sizeof(unsigned long long));
-  }
-  if (hipMemset(s->d_counters, 0, (32 + 4 * RT_TIMELINE_WAVES) * sizeof(unsigned long long)) != hipSuccess)
-    return bail(fail(RT_ERR_HIP, "hipMemset failed"));
+  if ((rc = alloc_launch_state(s)) != RT_OK) return bail(rc);
   s->dev.geom = (const rtc::SphereGeom*)s->d_geom; s->dev.mat = (const rtc::SphereMat*)s->d_mat;
   s->dev.lights = (const uint32_t*)s->d_lights;
   s->dev.tex = (const uint8_t*)s->d_tex; s->dev.sky = (const uint8_t*)s->d_sky;

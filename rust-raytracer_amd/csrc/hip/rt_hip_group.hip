@@ -114,6 +114,16 @@ struct RtHipGroup {
   bool gather = false;               // G > 1 (or the one-rank self-test): gather + de-interleave after the kernels
   std::vector<int> device;
   std::vector<RtHipScene*> scene;
+  // OVERLAPPED FRAMES (round 6).  A frame ends on its deepest paths: while the last waves of frame i trace them, the CUs whose
+  // persistent workgroups found the queue empty sit idle — 3 % of a whole headline frame without a learned queue order, 14 % of
+  // an 1/8 shard (tools/experiments/overlap_tail.py, profiles/r06_run11_overlap_tail.log).  Kernels on different HIP streams are
+  // independent, so odd frames run on a second VIEW of the rank's scene (rt_hip_scene_clone_view: the same tables in HBM, its
+  // own tile queue / counters / stats slots) through a second render stream: frame i + 1's workgroups start on every CU frame i
+  // has left.  Only with two frames in flight (rt_hip_group_submit / _collect); a blocking frame and a one-shot group never
+  // touch the second view.  RT_GROUP_OVERLAP=0: one scene, one render stream (rounds 4 - 5).
+  std::vector<RtHipScene*> scene2;   // rank r: the view odd frames render through (empty: no overlap)
+  std::vector<hipStream_t> stream2;  // ... and its render stream
+  std::vector<hipEvent_t> prev_stop; // rank r: ev_stop of the kernel of the frame submitted before the current one (its effective time starts there at the earliest)
   std::vector<RtRowTiles> tiles;     // rank r renders RtRowTiles{RT_GROUP_TILE_ROWS, r, G}
   std::vector<hipStream_t> stream;   // rank r: its kernels
   std::vector<hipStream_t> xstream;  // rank r: the transfer of its tiles (peer copy / its side of the gather); xstream[0] also
@@ -125,7 +135,9 @@ struct RtHipGroup {
     std::vector<void*> d_tiles;        // rank r's packed tiles on ITS device (rank 0: a slice of `d_stacked`)
     std::vector<hipEvent_t> ev_done;   // rank r: its kernel finished (recorded on stream[r])
     std::vector<hipEvent_t> ev_sent;   // peer transport, r > 0: its tiles are in `d_stacked` (recorded on xstream[r])
-    std::vector<int> slot;             // the stats slot of scene[r] this frame's launch used
+    std::vector<int> slot;             // the stats slot of scene[r] (or scene2[r]) this frame's launch used
+    int which = 0;                     // 0: the ranks' scenes, 1: their second views (overlapped frames)
+    std::vector<hipEvent_t> ev_prev_stop;  // rank r: the previous frame's kernel-end event at the time this frame was submitted (null: none)
     hipEvent_t ev_assembled = nullptr; // frame in scanline order on device 0 (xstream[0]; timed)
     hipEvent_t ev_final = nullptr;     // ... and in the caller's buffer, if one was given
     bool busy = false;                 // submitted, not collected
@@ -296,12 +308,16 @@ void use_peer_transport(RtHipGroup* g, const std::string& reason) {
 // its slice of the gather (peer transport; RCCL's gather is enqueued for all ranks together by the submitting thread)
 void enqueue_rank(RtHipGroup* g, RtHipGroup::Frame& f, uint32_t r) {
   g->t_wake_us[r] = us_since(f.t0);
-  f.slot[r] = (int)(g->scene[r]->n_launches & 1);
-  int rc = rt_hip_render(g->scene[r], g->G > 1 ? &g->tiles[r] : nullptr, f.d_tiles[r], nullptr, g->stream[r]);
+  RtHipScene* sc = f.which ? g->scene2[r] : g->scene[r];
+  hipStream_t rs = f.which ? g->stream2[r] : g->stream[r];
+  f.slot[r] = (int)(sc->n_launches & 1);
+  f.ev_prev_stop[r] = g->prev_stop[r];
+  int rc = rt_hip_render(sc, g->G > 1 ? &g->tiles[r] : nullptr, f.d_tiles[r], nullptr, rs);
+  g->prev_stop[r] = sc->slot[f.slot[r] & 1].ev_stop;
   std::string err;
   if (rc != RT_OK) err = rt_hip_last_error();
   auto hip = [&](hipError_t e, const char* what) { if (rc == RT_OK && e != hipSuccess) { rc = RT_ERR_HIP; err = std::string(what) + ": " + hipGetErrorString(e); } };
-  if (rc == RT_OK) hip(hipEventRecord(f.ev_done[r], g->stream[r]), "hipEventRecord");
+  if (rc == RT_OK) hip(hipEventRecord(f.ev_done[r], rs), "hipEventRecord");
   if (rc == RT_OK && g->gather) {
     hip(hipStreamWaitEvent(g->xstream[r], f.ev_done[r], 0), "hipStreamWaitEvent");
     if (!g->rccl && r != 0) {
@@ -356,6 +372,7 @@ extern "C" void rt_hip_group_destroy(RtHipGroup* g) {
   for (uint32_t r = 0; r < g->scene.size(); ++r) {  // nothing of ours may be running when buffers and communicators go
     (void)hipSetDevice(g->device[r]);
     if (r < g->stream.size() && (g->stream[r] || !g->own_streams)) (void)hipStreamSynchronize(g->stream[r]);
+    if (r < g->stream2.size() && g->stream2[r]) (void)hipStreamSynchronize(g->stream2[r]);
     if (r < g->xstream.size() && g->xstream[r]) (void)hipStreamSynchronize(g->xstream[r]);
   }
   for (uint32_t r = 0; r < g->comm.size(); ++r)
@@ -367,7 +384,9 @@ extern "C" void rt_hip_group_destroy(RtHipGroup* g) {
       if (r < f.ev_done.size() && f.ev_done[r]) (void)hipEventDestroy(f.ev_done[r]);
       if (r < f.ev_sent.size() && f.ev_sent[r]) (void)hipEventDestroy(f.ev_sent[r]);
     }
+    if (r < g->scene2.size() && g->scene2[r]) rt_hip_scene_destroy(g->scene2[r]);  // (the views first: they share their scene's tables)
     if (g->scene[r]) rt_hip_scene_destroy(g->scene[r]);
+    if (r < g->stream2.size() && g->stream2[r]) (void)hipStreamDestroy(g->stream2[r]);
     if (g->own_streams && r < g->stream.size() && g->stream[r]) (void)hipStreamDestroy(g->stream[r]);
     if (g->own_streams && r < g->xstream.size() && g->xstream[r]) (void)hipStreamDestroy(g->xstream[r]);
   }
@@ -418,7 +437,11 @@ int rtg::group_create(const RtScene* scene, uint32_t n_gpus, RtHipGroup** out, b
 #ifdef RT_TEST_PROBES
   if (const char* inj = std::getenv("RT_RCCL_INJECT")) g->inject = !std::strcmp(inj, "selftest") ? 1 : (!std::strcmp(inj, "gather") ? 2 : 0);
 #endif
-  for (auto& f : g->frame) { f.d_tiles.assign(G, nullptr); f.ev_done.assign(G, nullptr); f.ev_sent.assign(G, nullptr); f.slot.assign(G, 0); }
+  for (auto& f : g->frame) { f.d_tiles.assign(G, nullptr); f.ev_done.assign(G, nullptr); f.ev_sent.assign(G, nullptr); f.slot.assign(G, 0); f.ev_prev_stop.assign(G, nullptr); }
+  g->prev_stop.assign(G, nullptr);
+  const char* ov = std::getenv("RT_GROUP_OVERLAP");
+  const bool overlap = !one_shot && !(ov && ov[0] == '0');
+  if (overlap) { g->scene2.assign(G, nullptr); g->stream2.assign(G, nullptr); }
   bool& shared_device = g->shared_device;
   for (uint32_t r = 0; r < G; ++r) {
     g->device[r] = (int)(r % (uint32_t)ndev);
@@ -471,6 +494,13 @@ int rtg::group_create(const RtScene* scene, uint32_t n_gpus, RtHipGroup** out, b
           if (g->rc[r] != RT_OK) g->err[r] = rt_hip_last_error();
         }
         rc_clock.mark("rank0.kernel_warm_up_one_scanline");
+        if (!g->scene2.empty() && g->rc[r] == RT_OK) {  // the second view + its render stream (overlapped frames)
+          g->rc[r] = rt_hip_scene_clone_view(g->scene[r], &g->scene2[r]);
+          if (g->rc[r] == RT_OK && hipStreamCreateWithFlags(&g->stream2[r], hipStreamNonBlocking) != hipSuccess) { g->rc[r] = RT_ERR_HIP; g->err[r] = "hipStreamCreate (second render stream) failed"; }
+          else if (g->rc[r] != RT_OK) g->err[r] = rt_hip_last_error();
+          if (g->rc[r] == RT_OK && !std::getenv("RT_NO_KERNEL_WARMUP")) { g->rc[r] = rt_hip_scene_warm(g->scene2[r], g->stream2[r]); if (g->rc[r] != RT_OK) g->err[r] = rt_hip_last_error(); }
+          rc_clock.mark("rank0.second_view_and_stream");
+        }
       });
     for (auto& t : th) t.join();
     pc.mark("group.replicas_total_incl_scene_and_rank0_stages");
@@ -505,7 +535,8 @@ extern "C" int rt_hip_group_set_camera(RtHipGroup* g, const double origin[3], co
                                        const double vertical[3]) {
   if (!g) return fail(RT_ERR_INVALID, "null argument");
   for (uint32_t r = 0; r < g->G; ++r) {
-    const int rc = rt_hip_set_camera(g->scene[r], origin, lower_left, horizontal, vertical);
+    int rc = rt_hip_set_camera(g->scene[r], origin, lower_left, horizontal, vertical);
+    if (rc == RT_OK && !g->scene2.empty()) rc = rt_hip_set_camera(g->scene2[r], origin, lower_left, horizontal, vertical);
     if (rc != RT_OK) return rc;
   }
   return RT_OK;
@@ -519,7 +550,8 @@ extern "C" int rt_hip_group_set_option(RtHipGroup* g, const char* key, int64_t v
     return RT_OK;
   }
   for (uint32_t r = 0; r < g->G; ++r) {
-    const int rc = rt_hip_set_option(g->scene[r], key, value);
+    int rc = rt_hip_set_option(g->scene[r], key, value);
+    if (rc == RT_OK && !g->scene2.empty()) rc = rt_hip_set_option(g->scene2[r], key, value);
     if (rc != RT_OK) return rc;
   }
   return RT_OK;
@@ -574,6 +606,8 @@ void drain(RtHipGroup* g) {
     (void)hipSetDevice(g->device[q]);
     (void)hipStreamSynchronize(g->stream[q]); (void)hipStreamSynchronize(g->xstream[q]);
     g->scene[q]->in_flight = false;
+    if (!g->scene2.empty()) { (void)hipStreamSynchronize(g->stream2[q]); g->scene2[q]->in_flight = false; }
+    g->prev_stop[q] = nullptr;
   }
   (void)hipGetLastError();
   for (auto& f : g->frame) f.busy = false;
@@ -615,6 +649,12 @@ int group_submit(RtHipGroup* g, uint8_t* out_rgb8) {
   RtHipGroup::Frame& f = g->frame[b];
   f.t0 = std::chrono::steady_clock::now();
   f.out = out_rgb8;
+  // a frame submitted while another one is in flight goes through the ranks' OTHER view and render stream: the two kernels overlap
+  // (a frame submitted onto an idle group uses the first: blocking frames keep their scene's learned queue order)
+  {
+    const RtHipGroup::Frame& other = g->frame[b ^ 1];
+    f.which = (!g->scene2.empty() && other.busy) ? (other.which ^ 1) : 0;
+  }
   for (double& u : f.us) u = 0.0;
   if (G > 1) {
     {
@@ -733,8 +773,18 @@ int group_collect(RtHipGroup* g, RtStats* stats) {
     std::memset(&total, 0, sizeof total);
     for (uint32_t r = 0; r < G; ++r) {  // (with RCCL the other ranks' sides of the gather are behind ev_copied of their launch only on the render stream: their transfer streams are drained by the root's receive)
       RtStats st;
-      const int rc = wait_slot(g->scene[r], f.slot[r], &st);
+      RtHipScene* fsc = f.which ? g->scene2[r] : g->scene[r];
+      const int rc = wait_slot(fsc, f.slot[r], &st);
       if (rc != RT_OK) return rc;
+      // overlapped frames: a kernel's start event fires when ITS stream reaches it — while the previous frame's kernel (other
+      // stream) still holds most CUs.  The time this frame can be charged with starts at the later of its own start and the
+      // previous frame's kernel end: min(start -> stop, previous stop -> stop).  Serial frames: unchanged (start >= previous stop).
+      if (f.ev_prev_stop[r] && fsc->slot[f.slot[r] & 1].launched) {
+        float since_prev = 0.f;
+        if (hipEventElapsedTime(&since_prev, f.ev_prev_stop[r], fsc->slot[f.slot[r] & 1].ev_stop) == hipSuccess) {
+          if (since_prev > 0.f && (double)since_prev < st.kernel_ms) st.kernel_ms = (double)since_prev;
+        } else (void)hipGetLastError();
+      }
       total.samples += st.samples; total.segments += st.segments; total.sphere_tests += st.sphere_tests;
       total.exact_tests += st.exact_tests; total.tex_oob += st.tex_oob; total.grid_steps += st.grid_steps;
       total.segments_repeated = (uint32_t)std::min<uint64_t>((uint64_t)total.segments_repeated + st.segments_repeated, 0xFFFFFFFFull);
@@ -748,11 +798,15 @@ int group_collect(RtHipGroup* g, RtStats* stats) {
       *stats = total;
       stats->n_gpus_used = G;
       stats->frame_ms = frame_ms;
-      const RtHipScene::Slot& s0 = g->scene[0]->slot[f.slot[0] & 1];
+      const RtHipScene::Slot& s0 = (f.which ? g->scene2[0] : g->scene[0])->slot[f.slot[0] & 1];
       if (s0.launched) {
         RT_HIP_TRY(hipSetDevice(g->device[0]));
         float ms = 0.f;  // device 0's clock: rank 0's kernel start -> frame in scanline order; minus the slowest rank's kernel =
         RT_HIP_TRY(hipEventElapsedTime(&ms, s0.ev_start, f.ev_assembled));  // what the frame spent NOT rendering (start skew, gather, de-interleave)
+        if (f.ev_prev_stop[0]) {  // (overlapped frames: the span starts at the previous frame's kernel end at the earliest, like kernel_ms above)
+          float ms2 = 0.f;
+          if (hipEventElapsedTime(&ms2, f.ev_prev_stop[0], f.ev_assembled) == hipSuccess) { if (ms2 > 0.f && ms2 < ms) ms = ms2; } else (void)hipGetLastError();
+        }
         stats->gather_ms = (double)ms > total.kernel_ms ? (double)ms - total.kernel_ms : 0.0;
       }
       for (int k = 0; k < 8; ++k) stats->group_us[k] = f.us[k];

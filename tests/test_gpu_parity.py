@@ -1462,7 +1462,8 @@ def test_scene_may_change_streams_once_the_first_stream_is_drained(pkg, load_sce
     gs.close()
 
 
-@pytest.mark.parametrize("world,env", [(1, {}), (1, {"RT_GATHER_SELFTEST": "1", "RT_GATHER": "rccl"}), (3, {"RT_GPUS_EMULATE": "1"}), (8, {"RT_GPUS_EMULATE": "1"})])
+@pytest.mark.parametrize("world,env", [(1, {}), (1, {"RT_GATHER_SELFTEST": "1", "RT_GATHER": "rccl"}), (3, {"RT_GPUS_EMULATE": "1"}), (8, {"RT_GPUS_EMULATE": "1"}),
+                                       (1, {"RT_GROUP_OVERLAP": "0"}), (3, {"RT_GPUS_EMULATE": "1", "RT_GROUP_OVERLAP": "0"})])   # (round 6: odd frames in flight run through a second view + stream; "0" = the single-scene form)
 def test_group_submit_collect_pipelines_frames_bit_identically(pkg, gpu_render, load_scene, world, env):
     """rt_hip_group_submit / _collect (ABI v4): two frames in flight — frame i's gather, de-interleave and device-to-host
     copy under frame i+1's kernels, every buffer twice — deliver the bytes and the path counts of blocking frames with the
