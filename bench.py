@@ -906,6 +906,7 @@ def animation_runs(steady_kernel_ms, first_frame_kernel_ms, frames=32, orbit=3.0
                "process_wall_s": round(wall, 3), "frames_per_s_incl_process_startup": round(st["frames"] / wall, 2), "setup_ms": round(st["setup_ms"], 1),
                "kernel_ms_moving_camera": {"median": round(med(moving), 3), "min": round(min(moving), 3), "max": round(max(moving), 3), "first_frame": round(k[0], 3)},
                "kernel_ms_series": [round(x, 2) for x in k],
+               "kernel_ms_note": "frames of an animation OVERLAP (every other frame through a second view + stream fills the previous frame's tail): a frame's kernel_ms counts from the later of its own start and the previous frame's kernel end",
                "png_ms": {"median": round(med(pz), 2), "max": round(max(pz), 2)}, "png_writers": st.get("png_writers"), "png_mb_per_frame": round(png_bytes / max(1, n_png) / 1e6, 3),
                "host_us_per_frame": st.get("host_us_per_frame"),   # the submitting thread: waiting for a buffer / camera + submit (the FIRST submit allocates the pinned staging buffer and brings the device-to-host copy engine up: ~9 ms, 0.3 ms per frame of 32) / collect / stdout + hand-over
                "bound_by": "kernel" if med(moving) >= med(pz) / max(1, st.get("png_writers") or 1) else "png",
