@@ -41,6 +41,8 @@ namespace rtp {
 std::mutex g_mu;
 std::vector<std::pair<std::string, double>> g_stages;
 thread_local bool tl_record = true;     // (the group's upload threads of ranks >= 1 switch it off)
+thread_local bool tl_in_group = false;  // a group is being created on this thread: its scene's stages are appended to the group's
+                                        // (a scene created on its own starts a profile of its own: the list never grows without bound)
 thread_local std::string tl_text;
 void reset() { std::lock_guard<std::mutex> lk(g_mu); g_stages.clear(); }
 void add(const char* name, double ms) { if (!tl_record) return; std::lock_guard<std::mutex> lk(g_mu); g_stages.emplace_back(name, ms); }
@@ -280,6 +282,7 @@ extern "C" int rt_hip_scene_create(const RtScene* scene, int device, RtHipScene*
   static const bool trace = std::getenv("RT_GROUP_TRACE") != nullptr;  // (development: where a scene's creation time goes)
   const auto t_create = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count(); };
+  if (!rtp::tl_in_group) rtp::reset();
   rtp::Clock pc;
   rtc::HostTables t;
   std::string why = rtc::build_tables(*scene, t);

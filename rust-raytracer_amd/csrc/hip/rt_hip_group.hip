@@ -472,6 +472,7 @@ int rtg::group_create(const RtScene* scene, uint32_t n_gpus, RtHipGroup** out, b
     for (uint32_t r = 0; r < G; ++r)
       th.emplace_back([g, scene, r]() {
         rtp::tl_record = r == 0;
+        rtp::tl_in_group = true;
         rtp::Clock rc_clock;
         rtg::pin_to_rank(g, r);  // (the replica's pinned counter words and staging copies are first touched on the device's node)
         g->rc[r] = rt_hip_scene_create(scene, g->device[r], &g->scene[r]);
