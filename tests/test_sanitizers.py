@@ -53,3 +53,13 @@ def test_tables_grid_and_walk_under_sanitizers(tmp_path):
     assert out.strip()
     out = _run([exe, "12", "6"], 600, env=dict(ENV, RT_GRID_WIDE="1"))   # the same sets through the wide table format (32-bit item lists)
     assert out.strip()
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
+def test_png_writer_under_sanitizers(tmp_path):
+    """rt_png_write_rgb8 (round 6: parallel bands, one IDAT chunk per band, a z_stream per thread): 81 frames around the band / thread
+    boundaries x deflate strategies x thread caps under ASan + UBSan; every file inflated again and compared with its scanlines."""
+    exe = _build(tmp_path, "fuzz_png", ["tools/fuzz/fuzz_png.cpp", "rust-raytracer_amd/csrc/host/scene.cpp", "rust-raytracer_amd/csrc/host/jpeg.cpp"],
+                 extra=("-fopenmp", "-lz", "-lpthread"))
+    out = _run([exe, "5", str(tmp_path / "f.png")], 600)
+    assert "ok 81 files" in out
