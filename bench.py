@@ -910,7 +910,10 @@ def animation_runs(steady_kernel_ms, first_frame_kernel_ms, frames=32, orbit=3.0
                "png_ms": {"median": round(med(pz), 2), "max": round(max(pz), 2)}, "png_writers": st.get("png_writers"), "png_mb_per_frame": round(png_bytes / max(1, n_png) / 1e6, 3),
                "host_us_per_frame": st.get("host_us_per_frame"),   # the submitting thread: waiting for a buffer / camera + submit (the FIRST submit allocates the pinned staging buffer and brings the device-to-host copy engine up: ~9 ms, 0.3 ms per frame of 32) / collect / stdout + hand-over
                "bound_by": "kernel" if med(moving) >= med(pz) / max(1, st.get("png_writers") or 1) else "png",
-               "overlap_efficiency": round(st["frames_per_s"] * max(med(moving), med(pz) / max(1, st.get("png_writers") or 1)) / 1e3, 3)}
+               "overlap_efficiency": round(st["frames_per_s"] * max(med(moving), med(pz) / max(1, st.get("png_writers") or 1)) / 1e3, 3),
+               # what the run spent beside frames x the slower stage: pipeline fill / drain and the FIRST submit (pinned staging buffers + the
+               # device-to-host copy engine's queue, ~9 ms once) — 1 % of a 32-frame cfg2 run, 30 % of 32 frames of the 0.9 ms test scene
+               "transients_ms": round(st["wall_s"] * 1e3 - st["frames"] * max(med(moving), med(pz) / max(1, st.get("png_writers") or 1)), 1)}
         if steady:
             rec["steady_state_kernel_ms_view0"] = round(steady, 3)
             rec["first_frame_kernel_ms_view0_fixed_order"] = first
