@@ -251,12 +251,18 @@ int main(int argc, char** argv) {
   std::vector<double> hist_wave(65, 0.0), hist_lane0(65, 0.0), hist_lane1(65, 0.0);
   unsigned long long mismatches = 0;
   double g_kl_sum[6] = {0, 0, 0, 0, 0, 0}, g_kl_any[6] = {0, 0, 0, 0, 0, 0};
+  // (round 6) K RAYS PER LANE: a lane walks K independent segments one after the other inside ONE lock-step loop, so the wave pays
+  // max over lanes of the SUM of their rounds instead of the sum over K iterations of the max.  Estimated from K consecutive
+  // iterations of the same simulated wave (lane l's K segments = its segments of those iterations): g_multi[k][0] += sum of the K maxima
+  // (what the product pays), g_multi[k][1] += max over lanes of the K-sums (what K rays per lane would pay), k = 2, 4.
+  double g_multi[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #pragma omp parallel
   {
     std::vector<double> hw(65, 0.0), hl0(65, 0.0), hl1(65, 0.0);
     double a_w = 0, a_s = 0, a_t = 0, a_ls = 0, a_lst = 0, a_lt = 0, a_tr = 0, c_s[2] = {0, 0}, c_r[2] = {0, 0}, c_st[2] = {0, 0}, c_t[2] = {0, 0}, m_c[2] = {0, 0};
     unsigned long long mm = 0;
     double kl_sum[6] = {0, 0, 0, 0, 0, 0}, kl_any[6] = {0, 0, 0, 0, 0, 0};
+    double multi[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #pragma omp for schedule(dynamic, 4)
     for (uint32_t wv = 0; wv < n_waves; ++wv) {
       Lane<false, false> L[64];
@@ -284,6 +290,7 @@ int main(int argc, char** argv) {
         }
       };
       for (int l = 0; l < 64; ++l) has_ray[l] = take(l);
+      uint32_t hist_r[4][64]; uint32_t hist_max[4]; uint32_t n_hist = 0;   // the last 4 iterations' per-lane rounds
       for (;;) {
         int live = 0;
         for (int l = 0; l < 64; ++l) live += has_ray[l];
@@ -291,6 +298,8 @@ int main(int argc, char** argv) {
         uint64_t any_move = 0, any_test = 0;
         uint32_t max_r[2] = {0, 0}, over = 0;
         uint32_t kind_lanes[6] = {0, 0, 0, 0, 0, 0};  // lanes of this iteration by what their segment ends in: [0] miss, [1 + RT_MAT_*] hit material
+        uint32_t* cur_r = hist_r[n_hist & 3u];
+        for (int l = 0; l < 64; ++l) cur_r[l] = 0;
         for (int l = 0; l < 64; ++l) {
           if (!has_ray[l]) continue;
           RoundLog lg;
@@ -300,6 +309,7 @@ int main(int argc, char** argv) {
           { double c2 = T_MAX; int b2 = -1; uint32_t ne = 0, ns = 0; hit_world_grid(ds, tb, L[l].o, L[l].d, c2, b2, ne, ns); if (b2 != best || (b2 >= 0 && c2 != closest)) mm++; }
 #endif
           any_move |= lg.move; any_test |= lg.test; over = std::max(over, lg.over);
+          cur_r[l] = lg.rounds;
           const int cls = L[l].k == 0 ? 0 : 1;
           c_s[cls] += 1; c_r[cls] += lg.rounds; c_st[cls] += lg.steps; c_t[cls] += lg.tests;
           max_r[cls] = std::max(max_r[cls], lg.rounds);
@@ -310,6 +320,14 @@ int main(int argc, char** argv) {
           if (fin) has_ray[l] = take(l);
         }
         const uint32_t mr = std::max(max_r[0], max_r[1]);
+        hist_max[n_hist & 3u] = mr; n_hist++;
+        for (uint32_t K : {2u, 4u})
+          if (n_hist % K == 0) {
+            uint32_t sum_of_max = 0, max_of_sum = 0;
+            for (uint32_t j = 0; j < K; ++j) sum_of_max += hist_max[(n_hist - 1 - j) & 3u];
+            for (int l = 0; l < 64; ++l) { uint32_t sm = 0; for (uint32_t j = 0; j < K; ++j) sm += hist_r[(n_hist - 1 - j) & 3u][l]; max_of_sum = std::max(max_of_sum, sm); }
+            multi[K][0] += sum_of_max; multi[K][1] += max_of_sum;
+          }
         a_w += 1; a_s += __builtin_popcountll(any_move) + over; a_t += __builtin_popcountll(any_test) + over; a_tr += mr;
         hw[std::min<uint32_t>(mr, 64)] += 1;
         for (int q = 0; q < 6; ++q) { kl_sum[q] += kind_lanes[q]; kl_any[q] += kind_lanes[q] != 0; }
@@ -322,8 +340,12 @@ int main(int argc, char** argv) {
       for (int c = 0; c < 2; ++c) { cls_segs[c] += c_s[c]; cls_rounds[c] += c_r[c]; cls_steps[c] += c_st[c]; cls_tests[c] += c_t[c]; max_by_cls[c] += m_c[c]; }
       for (int i = 0; i < 65; ++i) { hist_wave[i] += hw[i]; hist_lane0[i] += hl0[i]; hist_lane1[i] += hl1[i]; }
       for (int q = 0; q < 6; ++q) { g_kl_sum[q] += kl_sum[q]; g_kl_any[q] += kl_any[q]; }
+      for (int k = 0; k < 5; ++k) { g_multi[k][0] += multi[k][0]; g_multi[k][1] += multi[k][1]; }
     }
   }
+  for (int K : {2, 4})
+    std::printf("K = %d rays per lane (K consecutive iterations of a wave folded into one lock-step loop): rounds %.0f -> %.0f = %.3f x  (the walk is ~41 %% of a wave iteration)\n", K,
+                g_multi[K][0], g_multi[K][1], g_multi[K][1] / std::max(1.0, g_multi[K][0]));
   std::printf("wave iterations %.0f, lanes with a ray per iteration %.2f\n", w_iters, lane_segs / w_iters);
   std::printf("per lane segment: steps %.3f  gridded tests %.3f\n", lane_steps / lane_segs, lane_tests / lane_segs);
   std::printf("per wave iteration: rounds %.3f  step rounds %.3f  test rounds %.3f   (model cost 50*S + 70*T = %.0f instr)\n", tot_rounds / w_iters,
