@@ -280,7 +280,8 @@ def _three_lights_world():
             '"look_at":{"x":0.0,"y":0.5,"z":-1.0},"vup":{"x":0.0,"y":1.0,"z":0.0},"vfov":60.0,"aspect":1.5},"objects":[' + ",".join(objs) + "]}")
 
 
-@pytest.mark.parametrize("case", ["cfg1_lights_textures_hollow_glass", "cfg2_cover", "cfg1_depth50_seed3", "cover4k_textured_sky", "three_lights_nested"])
+@pytest.mark.parametrize("case", ["cfg1_lights_textures_hollow_glass", "cfg2_cover", "cfg1_depth50_seed3", "cover4k_textured_sky", "three_lights_nested",
+                                  "cfg1_max_depth_1_usize_wrap", "cfg1_max_depth_0", "cfg1_null_sky"])
 def test_second_restatement_agrees_bit_for_bit(oracle, abi, host, case):
     """ray_color + hit_world + the five scatters + render_line restated twice (C: oracle/rt_oracle.c; Python: tests/mini_oracle.py,
     from the reference's sources alone): identical linear radiance (every f32 bit), identical RGB8, identical segment counts."""
@@ -292,9 +293,16 @@ def test_second_restatement_agrees_bit_for_bit(oracle, abi, host, case):
         path, w, h, spp, depth, seed = {"cfg1_lights_textures_hollow_glass": ("scenes/cfg1_test_800x600_spp16.json", 24, 16, 2, 8, 0),
                                         "cfg2_cover": ("scenes/cfg2_cover_1200x800_spp128.json", 24, 16, 2, 8, 0),
                                         "cfg1_depth50_seed3": ("scenes/cfg1_test_800x600_spp16.json", 20, 14, 3, 50, 3),
-                                        "cover4k_textured_sky": ("scenes/cfg3_cover_4k_textured.json", 24, 14, 2, 50, 1)}[case]
+                                        "cover4k_textured_sky": ("scenes/cfg3_cover_4k_textured.json", 24, 14, 2, 50, 1),
+                                        # raytracer.rs:101 `depth > (max_depth - 2)` in usize: max_depth 1 wraps (release build) -> no light is ever sampled;
+                                        # max_depth 0: ray_color returns black at once (:80-82); sky None -> black background (:137-139)
+                                        "cfg1_max_depth_1_usize_wrap": ("scenes/cfg1_test_800x600_spp16.json", 20, 14, 3, 1, 0),
+                                        "cfg1_max_depth_0": ("scenes/cfg1_test_800x600_spp16.json", 8, 6, 2, 0, 0),
+                                        "cfg1_null_sky": ("scenes/cfg1_test_800x600_spp16.json", 20, 14, 3, 8, 5)}[case]
         sc = host.Scene.load(path)
         sc.c.width, sc.c.height, sc.c.samples_per_pixel, sc.c.max_depth, sc.c.seed = w, h, spp, depth, seed
+        if case == "cfg1_null_sky":
+            sc.c.sky_mode = 0
     o_rgb, o_lin, o_st = oracle.render(abi, sc.ptr)
     m = mini_oracle.Mini(sc.c, lambda y, x: L.rt_oracle_atan2(y, x))
     rgb, lin, segments = m.render()
