@@ -543,8 +543,15 @@ extern "C" int rt_hip_group_set_camera(RtHipGroup* g, const double origin[3], co
   return RT_OK;
 }
 
+namespace rtg { void prepare_staging(RtHipGroup* g, int n_frames); }
 extern "C" int rt_hip_group_set_option(RtHipGroup* g, const char* key, int64_t value) {
   if (!g || !key) return fail(RT_ERR_INVALID, "null argument");
+  if (!std::strcmp(key, "prepare_host_output")) {  // the caller WILL pass host buffers to submit / render_to_host: make the pinned staging buffers (1 or 2
+    // frames) and bring the device-to-host copy path up now, at set-up, instead of inside the first submit (~9 ms: the copy engine's queue)
+    if (value < 1 || value > 2) return fail(RT_ERR_INVALID, "prepare_host_output must be 1 or 2 (frames in flight)");
+    rtg::prepare_staging(g, (int)value);
+    return RT_OK;
+  }
   if (!std::strcmp(key, "spin_us")) {  // the group's own option: how long an idle rank thread polls before it sleeps
     if (value < 0 || value > 1000000) return fail(RT_ERR_INVALID, "spin_us must be 0 .. 1000000");
     g->spin_us.store((int)value, std::memory_order_relaxed);

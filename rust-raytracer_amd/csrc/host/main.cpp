@@ -151,6 +151,7 @@ int animate_sharded(RtSceneFile* sf, const char* prefix, int frames, double orbi
   const auto t_create = std::chrono::steady_clock::now();
   int rc = rt_hip_group_create(sc, 0, &hs);
   if (rc != RT_OK) { std::fprintf(stderr, "render failed: %s: %s\n", rt_strerror(rc), rt_hip_last_error()); return 101; }
+  (void)rt_hip_group_set_option(hs, "prepare_host_output", 2);  // (pinned staging for the two frames in flight + the copy path, at set-up: not inside the first submit)
   const auto t_begin = std::chrono::steady_clock::now();
   double cam[11];
   rt_scene_camera(sf, cam);
